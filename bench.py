@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""bench.py -- train imgs/sec of the reference's aggregation step (train.py:312-335 semantics) on the HIP path.
+
+Workload (BASELINE.json configs[1]): ResNet-50 DeepLabV3+ + memory, bs=8 per GPU, 768x768 synthetic Cityscapes-shaped
+batch, fp32, one step = train forward (memory read + non-detached write) -> 5-term loss -> backward -> SGD ->
+eval-mode second forward that commits the memory (all of it inside the timed region).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS_F32_MFMA = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+STEP_GFLOP_PER_IMG = 1311.8            # train fwd 334.16 + bwd 665.55 + eval-mode 2nd fwd 312.07
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=8, help='images per GPU (weak scaling)')
+    ap.add_argument('--size', type=int, default=768)
+    ap.add_argument('--truncate-second-forward', action='store_true',
+                    help='skip the decoder in the memory-commit forward (identical results; NOT the default measurement)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=2)
+    ap.add_argument('--no-profile', action='store_true', help='do not bracket conv launches with HIP events')
+    return ap.parse_args()
+
+
+def cpu_baseline(batch, size):
+    """The oracle (CPU restatement == imported reference, bit-exact) timed on this box's host cores: one agg step."""
+    import torch
+    from oracle.ref_cpu import deeplab, harness
+    from pinthememory_amd import synth
+    cores = torch.get_num_threads()
+    crit = torch.nn.CrossEntropyLoss(reduction='mean', ignore_index=255)
+    net = synth.load_det_weights(deeplab.DeepR50V3PlusD(synth.model_args(), 19, crit, crit))
+    opt, _ = harness.make_optimizer(net)
+    x, y = synth.make_batch(batch, size)
+    t0 = time.time()
+    harness.agg_train_step(net, opt, x, y)
+    dt = time.time() - t0
+    return {'value': batch / dt, 'unit': 'imgs/sec', 'cores': cores, 'kind': 'port',
+            'sample': '1 agg train step (fwd+bwd+SGD+memory-commit fwd), bs=%d %dx%d fp32, torch CPU oracle, %d threads, %.1f s'
+                      % (batch, size, size, cores, dt)}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU: the HIP path has no CPU fallback'
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local))
+    dev = torch.device('cuda', local)
+
+    from pinthememory_amd import dist as D, harness, synth
+    from pinthememory_amd.hip import kernels as K
+    from pinthememory_amd.network import deepv3plus, mynn
+    crit = torch.nn.CrossEntropyLoss(reduction='mean', ignore_index=255)
+    if world > 1:
+        mynn.set_bnfunc(torch.nn.SyncBatchNorm)        # train.py:95 converts to SyncBN under DDP
+    net = synth.load_det_weights(deepv3plus.DeepR50V3PlusD(synth.model_args(gumbel_off=False), 19, crit, crit)).to(dev)
+    opt, sched = harness.make_optimizer(net)
+    buckets = D.GradBuckets(net.parameters()) if world > 1 else None
+    x, y = synth.make_batch(a.batch, a.size, seed=304 + rank)          # rank r: its own 8 images (config 4)
+    x, y = x.to(dev), y.to(dev)
+
+    def step():
+        return harness.agg_train_step(net, opt, x, y, sched=sched, buckets=buckets, truncate_second_forward=a.truncate_second_forward)
+
+    for _ in range(a.warmup):
+        step()
+    prof = not a.no_profile
+    if prof:
+        K.profile_enable(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        losses = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    roof = None
+    if prof:
+        K.profile_enable(False)
+        ms, fl, n = K.profile_read(mode=0, bn=128)     # dominant kernel: conv_igemm_kernel<FWD,128,128,2,2>
+        tot_ms, tot_fl, tot_n = K.profile_read(clear=True)
+        if n:
+            ach = fl / (ms * 1e-3) / 1e12
+            roof = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<FWD,128x128> (v_mfma_f32_32x32x2_f32)', 'achieved': round(ach, 2),
+                    'peak': PEAK_TFLOPS_F32_MFMA, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_TFLOPS_F32_MFMA, 4), 'traffic': None,
+                    'launches_per_step': n / a.steps, 'avg_launch_ms': round(ms / n, 5), 'gflop_per_launch': round(fl / n / 1e9, 3),
+                    'all_conv_kernels': {'achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), 'ms_per_step': round(tot_ms / a.steps, 3),
+                                         'launches_per_step': tot_n / a.steps}}
+    if rank == 0:
+        imgs = a.batch * world * a.steps
+        out = {'metric': 'train imgs/sec 768x768 bs=8 R50-DeepLabV3+ +mem', 'value': round(imgs / dt, 3), 'unit': 'imgs/sec', 'n_gpus': world,
+               'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+               'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': 'configs[1]: ResNet-50 DeepLabV3+ + memory, bs=%d/GPU %dx%d synthetic, fp32 reference-faithful agg train step '
+                                      '(fwd + bwd + SGD + eval-mode memory-commit fwd%s)' % (a.batch, a.size, a.size,
+                                                                                            ', decoder skipped in the commit fwd' if a.truncate_second_forward else ''),
+                          'global_batch': a.batch * world, 'crop': a.size, 'parallelism': 'dp%d' % world,
+                          'conv_tflop_per_step': round(STEP_GFLOP_PER_IMG * a.batch / 1e3, 3),
+                          'step_mfma_frac': round(STEP_GFLOP_PER_IMG * a.batch * world * a.steps / 1e3 / dt / (PEAK_TFLOPS_F32_MFMA * world), 4),
+                          'final_loss': round(float(losses['total']), 5)},
+               'roofline': roof}
+        if not a.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(a.cpu_batch, a.size)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

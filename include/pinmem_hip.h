@@ -1,0 +1,159 @@
+/* pinmem_hip.h -- C ABI of libpinmem_hip.so: hand-written gfx950 (MI355X) kernels for the dense hot path of
+ * Genie-Kim/PintheMemory (DeepLabV3+/V2 over ResNet, plus the categorical memory read/update).
+ *
+ * The reference is pure Python on stock torch ops: no FFI exists there. Each entry point below therefore names
+ * the reference op sequence (file:line under /root/reference) it replaces; INTEGRATION.md shows the ctypes stub
+ * that binds it. Conventions:
+ *   - every pointer is a BORROWED device pointer (torch owns the memory); the library never allocates or frees
+ *     tensor memory; scratch comes from the caller through (ws, ws_bytes);
+ *   - activations are NHWC fp32: pixel-major rows of `c` channels, `pitch` floats between pixels
+ *     (pitch >= c lets a kernel write into a channel slice of a wider concat buffer);
+ *   - conv weights are KRSC fp32 ([Cout][kh][kw][Cin] == a torch channels_last [Cout,Cin,kh,kw] tensor);
+ *   - labels are int64 as the reference's callers provide them (transforms/transforms.py:95-97), 255 = ignore;
+ *   - all work is enqueued on `stream` (a hipStream_t), no host synchronisation inside;
+ *   - return value: 0 = PM_OK, negative = pm_status; pm_last_error() gives the message (thread-local). */
+#ifndef PINMEM_HIP_H
+#define PINMEM_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum pm_status { PM_OK = 0, PM_EINVAL = -1, PM_EWORKSPACE = -2, PM_ELAUNCH = -3, PM_EUNSUPPORTED = -4 } pm_status;
+
+typedef struct pm_tensor {      /* NHWC fp32 activation view */
+  void* ptr;
+  int32_t n, h, w, c;
+  int64_t pitch;                /* floats between consecutive pixels */
+} pm_tensor;
+
+typedef struct pm_conv_params { /* nn.Conv2d geometry (square kernels/strides as used by the reference) */
+  int32_t kh, kw, stride, pad, dil;
+} pm_conv_params;
+
+typedef struct pm_conv_epilogue { /* optional fused epilogue of pm_conv_fwd; all pointers may be NULL */
+  const float* bias;            /* [Cout]  conv bias (deepv3plus.py:417,420,424) */
+  const float* scale;           /* [Cout]  folded eval-mode BN: y = conv*scale + shift (mynn.py:8-14 in .eval()) */
+  const float* shift;           /* [Cout] */
+  const float* residual;        /* NHWC, same n,h,w,c as y; += (Resnet.py:207) */
+  int64_t residual_pitch;
+  int32_t relu;                 /* max(.,0) last (Resnet.py:216) */
+} pm_conv_epilogue;
+
+const char* pm_last_error(void);
+int pm_version(void);
+
+/* ---- K1/K2/K3 convolution, implicit GEMM on v_mfma_f32_32x32x2_f32 -------------------------------------------
+ * Replaces nn.Conv2d forward/backward at Resnet.py:145-150,195,404,453-457; deepv3plus.py:72-81,87,398-424;
+ * deepv2.py:44-51,138-151; memory.py:75,104.  y: [n,ho,wo,cout], x: [n,h,w,cin], cin % 4 == 0. */
+size_t pm_conv_workspace(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p, int which /*0 fwd,1 dgrad,2 wgrad*/);
+int pm_conv_fwd(const pm_tensor* x, const float* w_krsc, const pm_tensor* y, const pm_conv_params* p,
+                const pm_conv_epilogue* ep, void* ws, size_t ws_bytes, void* stream);
+/* dx = dgrad(dy) [+ add]: `add` (nullable, same shape as dx) fuses the sum with a second gradient path, e.g. the
+ * identity/downsample branch of a Bottleneck (Resnet.py:207). */
+int pm_conv_bwd_data(const pm_tensor* dy, const float* w_krsc, const pm_tensor* dx, const pm_conv_params* p,
+                     const pm_tensor* add, void* ws, size_t ws_bytes, void* stream);
+/* dw_krsc [Cout][kh][kw][Cin]; dbias [Cout] or NULL. Deterministic (split-K partials reduced in fixed order). */
+int pm_conv_bwd_weight(const pm_tensor* x, const pm_tensor* dy, float* dw_krsc, float* dbias, const pm_conv_params* p,
+                       void* ws, size_t ws_bytes, void* stream);
+
+/* In-library HIP-event timing of the implicit-GEMM kernel (bench.py's roofline leg). While enabled every conv launch is
+ * bracketed by two events on its stream; pm_profile_read sums duration and algorithmic FLOPs (2*M*N*K) of one
+ * instantiation (mode 0/1/2, N-tile 128/64/32; negative / zero = any) and optionally clears the records. */
+int pm_profile_enable(int on);
+int pm_profile_read(int mode, int bn, double* total_ms, double* total_flops, int64_t* launches, int clear);
+
+/* ---- K4 BatchNorm2d (mynn.py:8-14 -> nn.BatchNorm2d / SyncBatchNorm, eps 1e-5, momentum 0.1) -------------------
+ * stats: per-channel shifted sums -> (count, mean, M2) so that ranks can be merged exactly (SyncBN, train.py:95).
+ * moments layout: float[3*C] = mean[C] | m2[C] | count (replicated [C]). */
+size_t pm_bn_workspace(const pm_tensor* x);
+int pm_bn_stats(const pm_tensor* x, float* moments, void* ws, size_t ws_bytes, void* stream);
+/* mean/var(biased) -> invstd; optionally updates running stats (unbiased var), momentum as torch. */
+int pm_bn_finalize(const float* moments, int c, float eps, float* mean, float* invstd,
+                   float* running_mean, float* running_var, float momentum, void* stream);
+/* y = relu?( (x-mean)*invstd*gamma + beta + residual? ) */
+int pm_bn_apply(const pm_tensor* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                const pm_tensor* residual /*nullable*/, int relu, const pm_tensor* y, void* stream);
+/* backward: dyz = dy * (relu ? y>0 : 1). sums[2*C] = sum(dyz) | sum(dyz * xhat). */
+int pm_bn_bwd_reduce(const pm_tensor* dy, const pm_tensor* y /*nullable if !relu*/, const pm_tensor* x, const float* mean,
+                     const float* invstd, int relu, float* sums, void* ws, size_t ws_bytes, void* stream);
+/* dx = gamma*invstd*(dyz - sum_dy/count - xhat*sum_dy_xhat/count); dres = dyz (nullable); count = global element count */
+int pm_bn_bwd_apply(const pm_tensor* dy, const pm_tensor* y, const pm_tensor* x, const float* mean, const float* invstd,
+                    const float* gamma, const float* sums, float count, int relu, const pm_tensor* dx,
+                    const pm_tensor* dres /*nullable*/, void* stream);
+/* eval-mode fold: scale = gamma/sqrt(running_var+eps); shift = beta - running_mean*scale + (conv_bias ? conv_bias*scale : 0) */
+int pm_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var, const float* conv_bias,
+               int c, float eps, float* scale, float* shift, void* stream);
+/* eval-mode / frozen-stat backward helper and plain elementwise ops */
+int pm_relu_bwd(const pm_tensor* dy, const pm_tensor* y, const pm_tensor* dx, void* stream);
+int pm_add(const pm_tensor* a, const pm_tensor* b, const pm_tensor* y, void* stream);
+int pm_copy(const pm_tensor* src, const pm_tensor* dst, void* stream);
+int pm_scale_shift_act(const pm_tensor* x, const float* scale, const float* shift, const pm_tensor* residual, int relu,
+                       const pm_tensor* y, void* stream);
+
+/* ---- K3 pooling (Resnet.py:432 MaxPool2d(3,2,1); deepv3plus.py:85 AdaptiveAvgPool2d(1)) ------------------------- */
+int pm_maxpool3x3s2_fwd(const pm_tensor* x, const pm_tensor* y, uint8_t* argmax, void* stream);
+int pm_maxpool3x3s2_bwd(const pm_tensor* dy, const uint8_t* argmax, const pm_tensor* dx, void* stream);
+int pm_global_avgpool_fwd(const pm_tensor* x, const pm_tensor* y /*n,1,1,c*/, void* stream);
+int pm_global_avgpool_bwd(const pm_tensor* dy, const pm_tensor* dx, int accumulate, void* stream);
+
+/* ---- K5 bilinear resize, align_corners=True (mynn.py:57-62), fp32 index math as ATen ---------------------------- */
+int pm_resize_bilinear_fwd(const pm_tensor* x, const pm_tensor* y, void* stream);
+int pm_resize_bilinear_bwd(const pm_tensor* dy, const pm_tensor* dx, int accumulate, void* stream);
+
+/* ---- layout edges ------------------------------------------------------------------------------------------------ */
+int pm_nchw_to_nhwc(const float* x_nchw, int c_src, const pm_tensor* y, void* stream);   /* zero-fills y.c > c_src */
+int pm_nhwc_to_nchw(const pm_tensor* x, float* y_nchw, void* stream);
+int pm_label_nearest(const int64_t* lab, int n, int H, int W, int64_t* out, int h, int w, void* stream); /* deepv3plus.py:592-594 */
+
+/* ---- K6 fused bilinear-upsample(align_corners) + CrossEntropy(ignore_index=255, mean) ---------------------------
+ * Replaces Upsample + criterion (deepv3plus.py:575-578) and the read loss (memory.py:173-176) without materialising
+ * the [B,19,H,W] logits. logits: NHWC [n,h,w,C<=32]; labels int64 [n,H,W]. loss_out[0]=mean loss, [1]=valid count. */
+size_t pm_upsample_ce_workspace(int n, int H, int W);
+int pm_upsample_ce_fwd(const pm_tensor* logits, float inv_temp, const int64_t* labels, int H, int W, float* loss_out,
+                       void* ws, size_t ws_bytes, void* stream);
+/* dlogits (+)= gscale * d(mean CE)/dlogits ; gscale is a device scalar pointer (upstream grad), may be NULL (=1) */
+int pm_upsample_ce_bwd(const pm_tensor* logits, float inv_temp, const int64_t* labels, int H, int W, const float* loss_out,
+                       const float* gscale, const pm_tensor* dlogits, void* stream);
+
+/* ---- K7 memory read (memory.py:317-336 + get_score :167-189) ---------------------------------------------------
+ * x: [N rows of d=256] (NHWC feature map); mem [m<=32][d]; writes qr = [qhat | P_m.M] (2d channels, input of
+ * memory.output), score S [N][m] (raw cosine scores), P_m [N][m] (softmax over slots, or gumbel if noise given). */
+int pm_mem_read_fwd(const pm_tensor* x, const float* mem, int m, const float* gumbel_noise /*nullable [N][m]*/,
+                    const pm_tensor* qr, float* score, float* p_mem, void* stream);
+/* softmax over all N queries per slot (memory.py:186); two-pass column reduce, deterministic */
+size_t pm_mem_colsoftmax_workspace(int64_t rows, int m);
+int pm_mem_colsoftmax(const float* score, const float* noise /*nullable*/, int64_t rows, int m, float* p_query,
+                      void* ws, size_t ws_bytes, void* stream);
+/* backward into x (and into mem when dmem != NULL): dqr [N][2d], dscore_extra [N][m] (from the read loss; nullable) */
+size_t pm_mem_read_bwd_workspace(int64_t rows, int m, int d);
+int pm_mem_read_bwd(const pm_tensor* x, const float* mem, int m, const float* p_mem, const pm_tensor* dqr,
+                    const float* dscore_extra, const pm_tensor* dx, float* dmem /*nullable [m][d]*/,
+                    void* ws, size_t ws_bytes, void* stream);
+
+/* ---- K8 memory write (memory.py:206-239) -----------------------------------------------------------------------
+ * accum: zhat = z/max(|z|,1e-12); 4-tap bilinear(align_corners) soft labels of the H x W mask at each h x w pixel
+ * (== one_hot(20) -> F.interpolate, memory.py:220-223, without the one-hot); nomden[(m+1)*(d+1)] =
+ * nominator[m+1][d] | denominator[m+1], summed over batch and pixels. Deterministic two-stage reduce. */
+size_t pm_mem_write_accum_workspace(const pm_tensor* z, int m);
+int pm_mem_write_accum(const pm_tensor* z, const int64_t* labels, int H, int W, int m, int normalize,
+                       float* nomden, void* ws, size_t ws_bytes, void* stream);
+/* dz from dnom [m+1][d] (label weights are constants) through the row normalisation */
+int pm_mem_write_accum_bwd(const pm_tensor* z, const int64_t* labels, int H, int W, int m, int normalize,
+                           const float* dnom, const pm_tensor* dz, void* stream);
+/* update: U = den!=0 ? mu*M + (1-mu)*nom/den : M ; M' = U/max(|U|,1e-12) (memory.py:233-239), device-side predicate */
+int pm_mem_write_update(const float* mem, const float* nomden, int m, int d, float momentum, float* mem_out,
+                        float* u_out /*nullable, saved for bwd*/, void* stream);
+int pm_mem_write_update_bwd(const float* u, const float* nomden, int m, int d, float momentum, const float* dmem_out,
+                            float* dnom /*[m+1][d]*/, float* dmem_in /*nullable [m][d]*/, void* stream);
+
+/* ---- optimizer (optimizer.py:21-25: SGD momentum 0.9, wd 5e-4, no nesterov) on a flat parameter arena -------------- */
+int pm_sgd_momentum(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
+                    float weight_decay, int first_step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

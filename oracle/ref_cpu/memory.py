@@ -84,19 +84,20 @@ class Memory_sup(nn.Module):
         return u, sq.view(b, h, w, self.memory_size), sm.view(b, h, w, self.memory_size), readloss
 
     # -- write --------------------------------------------------------------------------------
-    def soft_labels(self, mask, h, w):
-        """memory.py:220-225: 255 -> slot 19, one-hot(20) int64 -> float -> bilinear(align_corners) to h x w."""
+    def soft_labels(self, mask, h, w, dtype=torch.float32):
+        """memory.py:220-225: 255 -> slot 19, one-hot(20) int64 -> float -> bilinear(align_corners) to h x w.
+        dtype is float32 in the reference; the fp64 "truth" runs of the parity tests pass float64."""
         t = mask.clone().detach()
         t[t == 255] = self.memory_size
         t = F.one_hot(t, num_classes=self.memory_size + 1)
-        t = F.interpolate(t.permute(0, 3, 1, 2).contiguous().type(torch.float32), [h, w],
+        t = F.interpolate(t.permute(0, 3, 1, 2).contiguous().type(dtype), [h, w],
                           mode='bilinear', align_corners=True).permute(0, 2, 3, 1).contiguous()
         return t.view(mask.shape[0], -1, self.memory_size + 1)
 
     def accumulate(self, zhat, mask):
         """memory.py:219-231: nominator [20,d] and denominator [20], summed over batch and pixels."""
         b, d, h, w = zhat.shape
-        y = self.soft_labels(mask, h, w)
+        y = self.soft_labels(mask, h, w, zhat.dtype)
         den = y.sum(1).unsqueeze(1)
         nom = torch.matmul(zhat.view(b, d, -1), y)
         return nom.sum(0).t(), den.sum(0).squeeze()

@@ -1,0 +1,240 @@
+// K4: BatchNorm2d over NHWC fp32 (train statistics, apply + ReLU + residual, backward), HBM-bound.
+// Replaces mynn.Norm2d (/root/reference/network/mynn.py:8-14) == nn.BatchNorm2d / SyncBatchNorm everywhere it is
+// used (Resnet.py:146-151,405,456; deepv3plus.py:73,79,88,399,405,410,413,421; memory.py:76,105).
+// Statistics are shifted sums (shift = first pixel of each channel) -> (mean, M2, count), combined in double in a
+// fixed order: one pass over the activation, no catastrophic cancellation, deterministic, mergeable across ranks.
+#include "pm_common.h"
+
+namespace {
+
+constexpr int CB = 64;    // channels per block
+constexpr int RL = 16;    // row lanes per block (256 threads = 16 float4 groups x 16 rows)
+
+inline int chunk_rows(long P) {  // pixels per block: aim for ~2048 blocks total, >= 64 rows each
+  long r = (P + 511) / 512;
+  r = std::max<long>(r, 64);
+  return (int)((r + RL - 1) / RL * RL);
+}
+
+// partial[blk][c][2] : sum(x - K[c]), sum((x - K[c])^2) over the block's pixel chunk
+__global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ x, long pitch, long P, int C, int rows, float* __restrict__ part) {
+  __shared__ float sm[RL][CB][2];
+  const int g = threadIdx.x & 15, r = threadIdx.x >> 4;
+  const int c = blockIdx.y * CB + g * 4;
+  const long p0 = (long)blockIdx.x * rows, p1 = min(P, p0 + rows);
+  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  if (c < C) {
+    const float4 k = PM_LD4(x + c);
+    for (long p = p0 + r; p < p1; p += RL) {
+      const float4 v = PM_LD4(x + p * pitch + c);
+      const float d0 = v.x - k.x, d1 = v.y - k.y, d2 = v.z - k.z, d3 = v.w - k.w;
+      s1[0] += d0, s1[1] += d1, s1[2] += d2, s1[3] += d3;
+      s2[0] += d0 * d0, s2[1] += d1 * d1, s2[2] += d2 * d2, s2[3] += d3 * d3;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sm[r][g * 4 + j][0] = s1[j], sm[r][g * 4 + j][1] = s2[j];
+  __syncthreads();
+  if (threadIdx.x < CB * 2) {
+    const int cc = threadIdx.x >> 1, w = threadIdx.x & 1;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < RL; ++i) s += sm[i][cc][w];
+    const int ch = blockIdx.y * CB + cc;
+    if (ch < C) part[((long)blockIdx.x * C + ch) * 2 + w] = s;
+  }
+}
+
+__global__ void bn_stats_final(const float* __restrict__ part, int nb, const float* __restrict__ x, long P, int C, float* __restrict__ moments) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < nb; ++b) s1 += (double)part[((long)b * C + c) * 2], s2 += (double)part[((long)b * C + c) * 2 + 1];
+  const double n = (double)P;
+  moments[c] = (float)((double)x[c] + s1 / n);
+  moments[C + c] = (float)fmax(s2 - s1 * s1 / n, 0.0);
+  moments[2 * C + c] = (float)n;
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ moments, int C, float eps, float* __restrict__ mean, float* __restrict__ invstd,
+                                   float* running_mean, float* running_var, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float m = moments[c], m2 = moments[C + c], n = moments[2 * C + c];
+  const float var = m2 / n;
+  mean[c] = m;
+  invstd[c] = 1.f / sqrtf(var + eps);
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (m2 / (n - 1.f));
+}
+
+// backward reductions: partial[blk][c][2] = sum(dyz), sum(dyz * xhat)
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ dy, long dpitch, const float* __restrict__ y, long ypitch,
+                                                      const float* __restrict__ x, long xpitch, const float* __restrict__ mean,
+                                                      const float* __restrict__ invstd, long P, int C, int rows, float* __restrict__ part) {
+  __shared__ float sm[RL][CB][2];
+  const int g = threadIdx.x & 15, r = threadIdx.x >> 4;
+  const int c = blockIdx.y * CB + g * 4;
+  const long p0 = (long)blockIdx.x * rows, p1 = min(P, p0 + rows);
+  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  if (c < C) {
+    const float4 mu = PM_LD4(mean + c), is = PM_LD4(invstd + c);
+    for (long p = p0 + r; p < p1; p += RL) {
+      float4 d = PM_LD4(dy + p * dpitch + c);
+      const float4 v = PM_LD4(x + p * xpitch + c);
+      if (RELU) {
+        const float4 o = PM_LD4(y + p * ypitch + c);
+        d.x = o.x > 0.f ? d.x : 0.f, d.y = o.y > 0.f ? d.y : 0.f, d.z = o.z > 0.f ? d.z : 0.f, d.w = o.w > 0.f ? d.w : 0.f;
+      }
+      s1[0] += d.x, s1[1] += d.y, s1[2] += d.z, s1[3] += d.w;
+      s2[0] += d.x * ((v.x - mu.x) * is.x), s2[1] += d.y * ((v.y - mu.y) * is.y);
+      s2[2] += d.z * ((v.z - mu.z) * is.z), s2[3] += d.w * ((v.w - mu.w) * is.w);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sm[r][g * 4 + j][0] = s1[j], sm[r][g * 4 + j][1] = s2[j];
+  __syncthreads();
+  if (threadIdx.x < CB * 2) {
+    const int cc = threadIdx.x >> 1, w = threadIdx.x & 1;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < RL; ++i) s += sm[i][cc][w];
+    const int ch = blockIdx.y * CB + cc;
+    if (ch < C) part[((long)blockIdx.x * C + ch) * 2 + w] = s;
+  }
+}
+__global__ void bn_bwd_final(const float* __restrict__ part, int nb, int C, float* __restrict__ sums) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < nb; ++b) s1 += (double)part[((long)b * C + c) * 2], s2 += (double)part[((long)b * C + c) * 2 + 1];
+  sums[c] = (float)s1;
+  sums[C + c] = (float)s2;
+}
+
+__global__ void bn_fold_kernel(const float* __restrict__ g, const float* __restrict__ b, const float* __restrict__ rm, const float* __restrict__ rv,
+                               const float* __restrict__ cb, int C, float eps, float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float s = g[c] / sqrtf(rv[c] + eps);
+  scale[c] = s;
+  shift[c] = b[c] - rm[c] * s + (cb ? cb[c] * s : 0.f);
+}
+
+int check_bn(const pm_tensor* x, const char* who) {
+  PM_REQUIRE(x && x->ptr && pm_vec4(x), PM_EINVAL, "%s: tensor must be 16B aligned, pitch %% 4 == 0 and C %% 4 == 0", who);
+  return PM_OK;
+}
+
+}  // namespace
+
+extern "C" size_t pm_bn_workspace(const pm_tensor* x) {
+  const long P = pm_pixels(x);
+  const int nb = pm_cdiv(P, chunk_rows(P));
+  return pm_align_up((size_t)nb * x->c * 2 * sizeof(float), 256);
+}
+
+extern "C" int pm_bn_stats(const pm_tensor* x, float* moments, void* ws, size_t ws_bytes, void* stream) {
+  if (int e = check_bn(x, "bn_stats")) return e;
+  PM_REQUIRE(moments && ws && ws_bytes >= pm_bn_workspace(x), PM_EWORKSPACE, "bn_stats: workspace too small");
+  const long P = pm_pixels(x);
+  PM_REQUIRE(P > 0, PM_EINVAL, "bn_stats: empty tensor");
+  const int rows = chunk_rows(P), nb = pm_cdiv(P, rows);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_stats_partial, dim3(nb, pm_cdiv(x->c, CB)), dim3(256), 0, st, (const float*)x->ptr, (long)x->pitch, P, x->c, rows, (float*)ws);
+  hipLaunchKernelGGL(bn_stats_final, dim3(pm_cdiv(x->c, 64)), dim3(64), 0, st, (const float*)ws, nb, (const float*)x->ptr, P, x->c, moments);
+  return pm_check_launch("bn_stats");
+}
+
+extern "C" int pm_bn_finalize(const float* moments, int c, float eps, float* mean, float* invstd, float* running_mean, float* running_var,
+                              float momentum, void* stream) {
+  PM_REQUIRE(moments && mean && invstd && c > 0, PM_EINVAL, "bn_finalize: bad args");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(pm_cdiv(c, 64)), dim3(64), 0, (hipStream_t)stream, moments, c, eps, mean, invstd, running_mean, running_var,
+                     momentum);
+  return pm_check_launch("bn_finalize");
+}
+
+extern "C" int pm_bn_fold(const float* gamma, const float* beta, const float* rm, const float* rv, const float* conv_bias, int c, float eps, float* scale,
+                          float* shift, void* stream) {
+  PM_REQUIRE(gamma && beta && rm && rv && scale && shift && c > 0, PM_EINVAL, "bn_fold: bad args");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(pm_cdiv(c, 64)), dim3(64), 0, (hipStream_t)stream, gamma, beta, rm, rv, conv_bias, c, eps, scale, shift);
+  return pm_check_launch("bn_fold");
+}
+
+extern "C" int pm_bn_apply(const pm_tensor* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const pm_tensor* res,
+                           int relu, const pm_tensor* y, void* stream) {
+  if (int e = check_bn(x, "bn_apply")) return e;
+  if (int e = check_bn(y, "bn_apply")) return e;
+  PM_REQUIRE(pm_same_shape(x, y) && mean && invstd && gamma && beta, PM_EINVAL, "bn_apply: bad args");
+  if (res) {
+    if (int e = check_bn(res, "bn_apply")) return e;
+    PM_REQUIRE(pm_same_shape(x, res), PM_EINVAL, "bn_apply: residual shape mismatch");
+  }
+  const float *px = (const float*)x->ptr, *pr = res ? (const float*)res->ptr : nullptr;
+  float* py = (float*)y->ptr;
+  const long a = x->pitch, b = res ? res->pitch : 0, c = y->pitch;
+  return pm_ew_launch(true, pm_pixels(x), x->c, (hipStream_t)stream, "bn_apply", [=] __device__(long p, int ch) {
+    const float4 v = PM_LD4(px + p * a + ch), mu = PM_LD4(mean + ch), is = PM_LD4(invstd + ch), ga = PM_LD4(gamma + ch), be = PM_LD4(beta + ch);
+    const float s0 = is.x * ga.x, s1 = is.y * ga.y, s2 = is.z * ga.z, s3 = is.w * ga.w;
+    float4 o = make_float4(v.x * s0 + (be.x - mu.x * s0), v.y * s1 + (be.y - mu.y * s1), v.z * s2 + (be.z - mu.z * s2), v.w * s3 + (be.w - mu.w * s3));
+    if (pr) {
+      const float4 q = PM_LD4(pr + p * b + ch);
+      o.x += q.x, o.y += q.y, o.z += q.z, o.w += q.w;
+    }
+    if (relu) o.x = fmaxf(o.x, 0.f), o.y = fmaxf(o.y, 0.f), o.z = fmaxf(o.z, 0.f), o.w = fmaxf(o.w, 0.f);
+    PM_ST4(py + p * c + ch, o);
+  });
+}
+
+extern "C" int pm_bn_bwd_reduce(const pm_tensor* dy, const pm_tensor* y, const pm_tensor* x, const float* mean, const float* invstd, int relu,
+                                float* sums, void* ws, size_t ws_bytes, void* stream) {
+  if (int e = check_bn(dy, "bn_bwd_reduce")) return e;
+  if (int e = check_bn(x, "bn_bwd_reduce")) return e;
+  PM_REQUIRE(pm_same_shape(dy, x) && mean && invstd && sums, PM_EINVAL, "bn_bwd_reduce: bad args");
+  PM_REQUIRE(!relu || (y && pm_vec4(y) && pm_same_shape(y, x)), PM_EINVAL, "bn_bwd_reduce: relu needs the forward output");
+  PM_REQUIRE(ws && ws_bytes >= pm_bn_workspace(x), PM_EWORKSPACE, "bn_bwd_reduce: workspace too small");
+  const long P = pm_pixels(x);
+  const int rows = chunk_rows(P), nb = pm_cdiv(P, rows);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(nb, pm_cdiv(x->c, CB));
+  if (relu)
+    hipLaunchKernelGGL(bn_bwd_partial<true>, grid, dim3(256), 0, st, (const float*)dy->ptr, (long)dy->pitch, (const float*)y->ptr, (long)y->pitch,
+                       (const float*)x->ptr, (long)x->pitch, mean, invstd, P, x->c, rows, (float*)ws);
+  else
+    hipLaunchKernelGGL(bn_bwd_partial<false>, grid, dim3(256), 0, st, (const float*)dy->ptr, (long)dy->pitch, (const float*)nullptr, 0l,
+                       (const float*)x->ptr, (long)x->pitch, mean, invstd, P, x->c, rows, (float*)ws);
+  hipLaunchKernelGGL(bn_bwd_final, dim3(pm_cdiv(x->c, 64)), dim3(64), 0, st, (const float*)ws, nb, x->c, sums);
+  return pm_check_launch("bn_bwd_reduce");
+}
+
+extern "C" int pm_bn_bwd_apply(const pm_tensor* dy, const pm_tensor* y, const pm_tensor* x, const float* mean, const float* invstd, const float* gamma,
+                               const float* sums, float count, int relu, const pm_tensor* dx, const pm_tensor* dres, void* stream) {
+  if (int e = check_bn(dy, "bn_bwd_apply")) return e;
+  if (int e = check_bn(x, "bn_bwd_apply")) return e;
+  if (int e = check_bn(dx, "bn_bwd_apply")) return e;
+  PM_REQUIRE(pm_same_shape(dy, x) && pm_same_shape(dx, x) && mean && invstd && gamma && sums && count > 0.f, PM_EINVAL, "bn_bwd_apply: bad args");
+  PM_REQUIRE(!relu || (y && pm_vec4(y) && pm_same_shape(y, x)), PM_EINVAL, "bn_bwd_apply: relu needs the forward output");
+  PM_REQUIRE(!dres || (pm_vec4(dres) && pm_same_shape(dres, x)), PM_EINVAL, "bn_bwd_apply: dres shape mismatch");
+  const float *pd = (const float*)dy->ptr, *po = relu ? (const float*)y->ptr : nullptr, *px = (const float*)x->ptr;
+  float *pdx = (float*)dx->ptr, *pdr = dres ? (float*)dres->ptr : nullptr;
+  const long a = dy->pitch, b = relu ? y->pitch : 0, c = x->pitch, d = dx->pitch, e2 = dres ? dres->pitch : 0;
+  const int C = x->c;
+  const float inv_n = 1.f / count;
+  return pm_ew_launch(true, pm_pixels(x), C, (hipStream_t)stream, "bn_bwd_apply", [=] __device__(long p, int ch) {
+    float4 g = PM_LD4(pd + p * a + ch);
+    if (po) {
+      const float4 o = PM_LD4(po + p * b + ch);
+      g.x = o.x > 0.f ? g.x : 0.f, g.y = o.y > 0.f ? g.y : 0.f, g.z = o.z > 0.f ? g.z : 0.f, g.w = o.w > 0.f ? g.w : 0.f;
+    }
+    if (pdr) PM_ST4(pdr + p * e2 + ch, g);
+    const float4 v = PM_LD4(px + p * c + ch), mu = PM_LD4(mean + ch), is = PM_LD4(invstd + ch), ga = PM_LD4(gamma + ch);
+    const float4 s1 = PM_LD4(sums + ch), s2 = PM_LD4(sums + C + ch);
+    float4 r;
+    r.x = (g.x - s1.x * inv_n - (v.x - mu.x) * is.x * (s2.x * inv_n)) * (is.x * ga.x);
+    r.y = (g.y - s1.y * inv_n - (v.y - mu.y) * is.y * (s2.y * inv_n)) * (is.y * ga.y);
+    r.z = (g.z - s1.z * inv_n - (v.z - mu.z) * is.z * (s2.z * inv_n)) * (is.z * ga.z);
+    r.w = (g.w - s1.w * inv_n - (v.w - mu.w) * is.w * (s2.w * inv_n)) * (is.w * ga.w);
+    PM_ST4(pdx + p * d + ch, r);
+  });
+}

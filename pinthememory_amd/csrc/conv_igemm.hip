@@ -1,0 +1,664 @@
+// K1/K2/K3: im2col-free implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 157 TF peak).
+//
+// One kernel template, three gather modes over  C[M][N] = sum_k A[m][k] * B[k][n] :
+//   FWD    M = n*ho*wo output pixels, N = Cout,      K = taps*Cin   A = gathered x rows (k-contiguous), B = w[Cout][K]
+//   DGRAD  M = n*h*w   input  pixels, N = Cin,       K = taps*Cout  A = gathered dy rows,               B = w viewed [k][Cin]
+//   WGRAD  M = Cout,                  N = taps*Cin,  K = pixels     A = dy[p][Cout] (m-contiguous),     B = gathered x rows
+// NHWC keeps every gathered row a contiguous channel vector, so global loads are 16 B/lane and coalesced; dilation
+// (6/12/18/24) costs nothing because taps are gathered from L2, never staged as a spatial halo.
+// 256 threads = 4 waves; each wave owns TMxTN MFMA tiles of 32x32; LDS double-buffered, next K-slab prefetched to
+// registers while the current one feeds the matrix pipe (one barrier per K-step).
+// Replaces nn.Conv2d fwd/bwd of /root/reference/network/Resnet.py:145-150,404,453-457, deepv3plus.py:72-81,398-424.
+#include <algorithm>
+#include <vector>
+
+#include "pm_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
+constexpr int BK = 32;
+constexpr int LDK = 36;  // k-contiguous LDS row stride (floats): 144 B rows -> conflict-free ds_read_b128
+
+struct ConvK {
+  const float* A;
+  const float* B;
+  float* C;
+  int N, H, W, Cin;       // conv input tensor (x / dx)
+  int Ho, Wo, Cout;       // conv output tensor (y / dy)
+  long x_pitch, y_pitch;  // floats between pixels
+  int kh, kw, stride, pad, dil, sshift;
+  int M, Nn, K;           // GEMM extents
+  int ksplit;             // gridDim.z
+  int kper;               // K range per split (multiple of BK)
+  long c_pitch;           // row pitch of C
+  long c_split;           // floats between split-K slabs (ksplit > 1 -> C is the workspace)
+  int tiles_m, tiles_n;
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  const float* residual;
+  long res_pitch;
+  int relu;
+};
+
+__device__ __forceinline__ float4 ld4(const float* p, bool ok) {
+  return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+// keep the first `nv` (1..4) lanes of a float4
+__device__ __forceinline__ float4 mask4(float4 v, int nv) {
+  if (nv < 4) v.w = 0.f;
+  if (nv < 3) v.z = 0.f;
+  if (nv < 2) v.y = 0.f;
+  return v;
+}
+
+// XCD-aware bijective remap: consecutive logical ids (which share the A row-panel) land on one XCD's L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+template <int MODE, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
+  constexpr bool A_KC = (MODE != MODE_WGRAD);  // A tile stored [BM][LDK] (k contiguous) else [BK][BM]
+  constexpr bool B_KC = (MODE == MODE_FWD);    // B tile stored [BN][LDK] else [BK][BN]
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int A_FLOATS = A_KC ? BM * LDK : BK * BM;
+  constexpr int B_FLOATS = B_KC ? BN * LDK : BK * BN;
+  constexpr int STAGE = A_FLOATS + B_FLOATS;
+  constexpr int A_ROWS = A_KC ? BM / 32 : BK / (256 / (BM / 4));  // rows per thread
+  constexpr int B_ROWS = B_KC ? BN / 32 : BK / (256 / (BN / 4));
+  constexpr int A_RSTEP = A_KC ? 32 : 256 / (BM / 4);
+  constexpr int B_RSTEP = B_KC ? 32 : 256 / (BN / 4);
+  static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && A_ROWS >= 1 && B_ROWS >= 1, "bad tile config");
+
+  extern __shared__ __align__(16) float smem[];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  const int ntile = a.tiles_m * a.tiles_n;
+  const int lid = xcd_remap(blockIdx.x, ntile);
+  const int tile_m = lid / a.tiles_n, tile_n = lid % a.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int z = blockIdx.z;
+  const int k_begin = z * a.kper;
+  const int k_end = min(a.K, k_begin + a.kper);
+  const int nk = (k_end - k_begin + BK - 1) / BK;
+
+  const int T = a.kh * a.kw;
+
+  // ------------------------------------------------------------------------------------------------------------
+  // per-thread gather state
+  // KC tiles: thread -> (k-group g = t&7 of 4 floats, rows t>>3 + 32*i);  MC tiles: thread -> (col group, k rows)
+  // ------------------------------------------------------------------------------------------------------------
+  // ---- A ----
+  int a_pix[A_ROWS], a_y0[A_ROWS], a_x0[A_ROWS];  // FWD/DGRAD: image pixel base + window origin per row
+  int a_ch = 0, a_tap = 0, a_ky = 0, a_kx = 0;    // FWD/DGRAD: running (tap, channel) of this thread's k-group
+  int a_col = 0, a_nv = 0;                        // WGRAD: channel column of dy, valid lanes
+  if constexpr (MODE == MODE_FWD || MODE == MODE_DGRAD) {
+    const int rh = (MODE == MODE_FWD) ? a.Ho : a.H, rw = (MODE == MODE_FWD) ? a.Wo : a.W;
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {
+      const int m = m0 + (t >> 3) + 32 * i;
+      if (m < a.M) {
+        const int img = m / (rh * rw), rem = m - img * (rh * rw);
+        const int py = rem / rw, px = rem - py * rw;
+        if constexpr (MODE == MODE_FWD) {
+          a_pix[i] = img * a.H * a.W;
+          a_y0[i] = py * a.stride - a.pad;
+          a_x0[i] = px * a.stride - a.pad;
+        } else {
+          a_pix[i] = img * a.Ho * a.Wo;
+          a_y0[i] = py + a.pad;
+          a_x0[i] = px + a.pad;
+        }
+      } else {
+        a_pix[i] = 0;
+        a_y0[i] = -(1 << 28);
+        a_x0[i] = -(1 << 28);
+      }
+    }
+    const int cdim = (MODE == MODE_FWD) ? a.Cin : a.Cout;
+    const int k = k_begin + (t & 7) * 4;
+    a_tap = k / cdim;
+    a_ch = k - a_tap * cdim;
+    a_ky = a_tap / a.kw;
+    a_kx = a_tap - a_ky * a.kw;
+  } else {
+    a_col = m0 + (t % (BM / 4)) * 4;
+    a_nv = min(4, a.Cout - a_col);
+  }
+  // ---- B ----
+  int b_row[B_ROWS];                              // FWD: weight row (cout) ; DGRAD: running co ; WGRAD: running ox
+  int b_aux[B_ROWS], b_aux2[B_ROWS];              // DGRAD: running tap ; WGRAD: running oy, img
+  int b_col = 0, b_nv = 0, b_ky = 0, b_kx = 0, b_ci = 0;
+  if constexpr (MODE == MODE_FWD) {
+#pragma unroll
+    for (int i = 0; i < B_ROWS; ++i) b_row[i] = n0 + (t >> 3) + 32 * i;
+  } else if constexpr (MODE == MODE_DGRAD) {
+    b_col = n0 + (t % (BN / 4)) * 4;
+    b_nv = min(4, a.Cin - b_col);
+#pragma unroll
+    for (int i = 0; i < B_ROWS; ++i) {
+      const int k = k_begin + t / (BN / 4) + B_RSTEP * i;
+      b_aux[i] = k / a.Cout;
+      b_row[i] = k - b_aux[i] * a.Cout;
+    }
+  } else {
+    const int n = n0 + (t % (BN / 4)) * 4;
+    b_nv = n < a.Nn ? 4 : 0;
+    const int tap = b_nv ? n / a.Cin : 0;
+    b_ci = n - tap * a.Cin;
+    b_ky = tap / a.kw;
+    b_kx = tap - b_ky * a.kw;
+    b_nv = b_nv ? min(4, a.Cin - b_ci) : 0;
+#pragma unroll
+    for (int i = 0; i < B_ROWS; ++i) {
+      const int p = k_begin + t / (BN / 4) + B_RSTEP * i;
+      const int img = p / (a.Ho * a.Wo), rem = p - img * (a.Ho * a.Wo);
+      b_aux2[i] = img;
+      b_aux[i] = rem / a.Wo;
+      b_row[i] = rem - b_aux[i] * a.Wo;
+    }
+  }
+
+  float4 ra[A_ROWS], rb[B_ROWS];
+
+  auto load_tiles = [&](int kt) {
+    const int kbase = k_begin + kt * BK;
+    // ---------------- A ----------------
+    if constexpr (MODE == MODE_FWD) {
+      const bool kok = a_tap < T;
+      const int nv = min(4, a.Cin - a_ch);
+#pragma unroll
+      for (int i = 0; i < A_ROWS; ++i) {
+        const int iy = a_y0[i] + a_ky * a.dil, ix = a_x0[i] + a_kx * a.dil;
+        const bool ok = kok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const float* p = a.A + (long)(a_pix[i] + iy * a.W + ix) * a.x_pitch + a_ch;
+        ra[i] = mask4(ld4(p, ok), nv);
+      }
+    } else if constexpr (MODE == MODE_DGRAD) {
+      const bool kok = a_tap < T;
+      const int nv = min(4, a.Cout - a_ch);
+      const int smask = a.stride - 1;
+#pragma unroll
+      for (int i = 0; i < A_ROWS; ++i) {
+        const int ty = a_y0[i] - a_ky * a.dil, tx = a_x0[i] - a_kx * a.dil;
+        const int oy = ty >> a.sshift, ox = tx >> a.sshift;
+        const bool ok = kok && ty >= 0 && tx >= 0 && ((ty | tx) & smask) == 0 && oy < a.Ho && ox < a.Wo;
+        const float* p = a.A + (long)(a_pix[i] + oy * a.Wo + ox) * a.y_pitch + a_ch;
+        ra[i] = mask4(ld4(p, ok), nv);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_ROWS; ++i) {
+        const int p = kbase + t / (BM / 4) + A_RSTEP * i;
+        const bool ok = p < k_end && a_nv > 0;
+        ra[i] = mask4(ld4(a.A + (long)p * a.y_pitch + a_col, ok), a_nv);
+      }
+    }
+    // ---------------- B ----------------
+    if constexpr (MODE == MODE_FWD) {
+      const int k = kbase + (t & 7) * 4;
+#pragma unroll
+      for (int i = 0; i < B_ROWS; ++i) {
+        const bool ok = b_row[i] < a.Cout && k < k_end;
+        rb[i] = mask4(ld4(a.B + (long)b_row[i] * a.K + k, ok), k_end - k);
+      }
+    } else if constexpr (MODE == MODE_DGRAD) {
+#pragma unroll
+      for (int i = 0; i < B_ROWS; ++i) {
+        const bool ok = b_aux[i] < T && b_nv > 0 && (kbase + t / (BN / 4) + B_RSTEP * i) < k_end;
+        rb[i] = mask4(ld4(a.B + ((long)b_row[i] * T + b_aux[i]) * a.Cin + b_col, ok), b_nv);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < B_ROWS; ++i) {
+        const int p = kbase + t / (BN / 4) + B_RSTEP * i;
+        const int iy = b_aux[i] * a.stride - a.pad + b_ky * a.dil, ix = b_row[i] * a.stride - a.pad + b_kx * a.dil;
+        const bool ok = p < k_end && b_nv > 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        rb[i] = mask4(ld4(a.B + ((long)b_aux2[i] * a.H * a.W + iy * a.W + ix) * a.x_pitch + b_ci, ok), b_nv);
+      }
+    }
+  };
+
+  auto advance = [&]() {  // move the running gather state one K-step (BK) forward
+    if constexpr (MODE == MODE_FWD || MODE == MODE_DGRAD) {
+      const int cdim = (MODE == MODE_FWD) ? a.Cin : a.Cout;
+      a_ch += BK;
+      while (a_ch >= cdim) {
+        a_ch -= cdim;
+        ++a_tap;
+        if (++a_kx == a.kw) {
+          a_kx = 0;
+          ++a_ky;
+        }
+      }
+    }
+    if constexpr (MODE == MODE_DGRAD) {
+#pragma unroll
+      for (int i = 0; i < B_ROWS; ++i) {
+        b_row[i] += BK;
+        while (b_row[i] >= a.Cout) {
+          b_row[i] -= a.Cout;
+          ++b_aux[i];
+        }
+      }
+    } else if constexpr (MODE == MODE_WGRAD) {
+#pragma unroll
+      for (int i = 0; i < B_ROWS; ++i) {
+        b_row[i] += BK;
+        while (b_row[i] >= a.Wo) {
+          b_row[i] -= a.Wo;
+          if (++b_aux[i] == a.Ho) {
+            b_aux[i] = 0;
+            ++b_aux2[i];
+          }
+        }
+      }
+    }
+  };
+
+  auto store_tiles = [&](int buf) {
+    float* As = smem + buf * STAGE;
+    float* Bs = As + A_FLOATS;
+    if constexpr (A_KC) {
+#pragma unroll
+      for (int i = 0; i < A_ROWS; ++i)
+        *reinterpret_cast<float4*>(As + ((t >> 3) + 32 * i) * LDK + (t & 7) * 4) = ra[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_ROWS; ++i)
+        *reinterpret_cast<float4*>(As + (t / (BM / 4) + A_RSTEP * i) * BM + (t % (BM / 4)) * 4) = ra[i];
+    }
+    if constexpr (B_KC) {
+#pragma unroll
+      for (int i = 0; i < B_ROWS; ++i)
+        *reinterpret_cast<float4*>(Bs + ((t >> 3) + 32 * i) * LDK + (t & 7) * 4) = rb[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < B_ROWS; ++i)
+        *reinterpret_cast<float4*>(Bs + (t / (BN / 4) + B_RSTEP * i) * BN + (t % (BN / 4)) * 4) = rb[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto compute = [&](int buf) {
+    const float* As = smem + buf * STAGE;
+    const float* Bs = As + A_FLOATS;
+#pragma unroll
+    for (int kg = 0; kg < BK / 8; ++kg) {
+      const int kk = kg * 8 + half * 4;  // this lane-half's 4 consecutive k of the 8-k group
+      float fa[TM][4], fb[TN][4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * (BM / WM) + i * 32 + l31;
+        if constexpr (A_KC) {
+          const float4 v = *reinterpret_cast<const float4*>(As + row * LDK + kk);
+          fa[i][0] = v.x, fa[i][1] = v.y, fa[i][2] = v.z, fa[i][3] = v.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fa[i][j] = As[(kk + j) * BM + row];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int col = wn * (BN / WN) + i * 32 + l31;
+        if constexpr (B_KC) {
+          const float4 v = *reinterpret_cast<const float4*>(Bs + col * LDK + kk);
+          fb[i][0] = v.x, fb[i][1] = v.y, fb[i][2] = v.z, fb[i][3] = v.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fb[i][j] = Bs[(kk + j) * BN + col];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int n = 0; n < TN; ++n)
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[n][j], acc[i][n], 0, 0, 0);
+    }
+  };
+
+  // ---- main loop: register prefetch of slab kt+1 overlaps the MFMAs of slab kt ---------------------------------
+  if (nk > 0) {
+    load_tiles(0);
+    advance();
+    store_tiles(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) {
+      load_tiles(kt + 1);
+      advance();
+    }
+    compute(kt & 1);
+    if (more) store_tiles((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------------------------------
+  float* Cb = a.C + (a.ksplit > 1 ? (long)z * a.c_split : 0);
+  const bool plain = a.ksplit > 1;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+      const int col = n0 + wn * (BN / WN) + n * 32 + l31;
+      if (col >= a.Nn) continue;
+      float bi = 0.f, sc = 1.f, sh = 0.f;
+      if (!plain) {
+        if (a.bias) bi = a.bias[col];
+        if (a.scale) sc = a.scale[col], sh = a.shift[col];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row >= a.M) continue;
+        float v = acc[i][n][r];
+        if (!plain) {
+          v = (v + bi) * sc + sh;
+          if (a.residual) v += a.residual[(long)row * a.res_pitch + col];
+          if (a.relu) v = fmaxf(v, 0.f);
+        }
+        Cb[(long)row * a.c_pitch + col] = v;
+      }
+    }
+}
+
+// split-K combine: C[row][col] = epilogue( sum_z ws[z][row][col] ), fixed z order (deterministic).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, long slab, int M, int Nn,
+                                                            float* __restrict__ C, long c_pitch, const float* bias,
+                                                            const float* scale, const float* shift, const float* residual,
+                                                            long res_pitch, int relu) {
+  const long total = (long)M * Nn;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int row = (int)(i / Nn), col = (int)(i - (long)row * Nn);
+    float v = 0.f;
+    for (int z = 0; z < ksplit; ++z) v += ws[(long)z * slab + i];
+    if (bias) v += bias[col];
+    if (scale) v = v * scale[col] + shift[col];
+    if (residual) v += residual[(long)row * res_pitch + col];
+    if (relu) v = fmaxf(v, 0.f);
+    C[(long)row * c_pitch + col] = v;
+  }
+}
+
+// column sum of dy for the conv bias gradient: one block per 64 channels x pixel chunk, fixed-order second stage.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, long pitch, long P, int C, int rows_per_block,
+                                                             float* __restrict__ part) {
+  __shared__ float sm[4][64];
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
+  const long p0 = (long)blockIdx.x * rows_per_block, p1 = min(P, p0 + rows_per_block);
+  float s = 0.f;
+  if (c < C)
+    for (long p = p0 + r; p < p1; p += 4) s += x[p * pitch + c];
+  sm[r][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (r == 0 && c < C) part[(long)blockIdx.x * C + c] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int nb, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int b = 0; b < nb; ++b) s += part[(long)b * C + c];
+  out[c] = s;
+}
+
+struct Plan {
+  int bn;        // 128 / 64 / 32
+  int tiles_m, tiles_n, ksplit, kper;
+  size_t ws_bytes;
+};
+
+Plan make_plan(int mode, long M, long Nn, long K) {
+  Plan p;
+  p.bn = Nn > 64 ? 128 : (Nn > 32 ? 64 : 32);
+  p.tiles_m = pm_cdiv(M, 128);
+  p.tiles_n = pm_cdiv(Nn, p.bn);
+  const long tiles = (long)p.tiles_m * p.tiles_n;
+  const long ksteps = (K + BK - 1) / BK;
+  int ks = 1;
+  const long target = (mode == MODE_WGRAD) ? 1024 : 768;
+  if (tiles < target) {
+    ks = (int)((target + tiles - 1) / tiles);
+    const long max_by_k = ksteps / 8 > 0 ? ksteps / 8 : 1;  // at least 8 K-steps per split
+    if (ks > max_by_k) ks = (int)max_by_k;
+    if (ks > 64) ks = 64;
+    if (ks < 1) ks = 1;
+  }
+  long steps_per = (ksteps + ks - 1) / ks;
+  ks = (int)((ksteps + steps_per - 1) / steps_per);
+  p.ksplit = ks;
+  p.kper = (int)(steps_per * BK);
+  p.ws_bytes = ks > 1 ? (size_t)ks * M * Nn * sizeof(float) : 0;
+  return p;
+}
+
+template <int MODE, int BM, int BN, int WM, int WN>
+void launch_one(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
+  static const bool attr_set = [] {  // > 64 KB of dynamic LDS needs an explicit opt-in, once per kernel
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<MODE, BM, BN, WM, WN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return true;
+  }();
+  (void)attr_set;
+  hipLaunchKernelGGL((conv_igemm_kernel<MODE, BM, BN, WM, WN>), grid, dim3(256), smem, st, k);
+}
+
+// ---- optional in-library timing of the implicit-GEMM kernel itself (HIP events on the launch stream) ----------------
+struct ProfRec {
+  hipEvent_t a, b;
+  int mode, bn;
+  double flops;
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+
+template <int MODE>
+int launch(const ConvK& k0, const Plan& p, hipStream_t st) {
+  ConvK k = k0;
+  k.tiles_m = p.tiles_m;
+  k.tiles_n = p.tiles_n;
+  k.ksplit = p.ksplit;
+  k.kper = p.kper;
+  dim3 grid(p.tiles_m * p.tiles_n, 1, p.ksplit);
+  ProfRec rec;
+  if (g_prof_on) {
+    (void)hipEventCreate(&rec.a), (void)hipEventCreate(&rec.b);
+    rec.mode = MODE, rec.bn = p.bn, rec.flops = 2.0 * (double)k.M * (double)k.Nn * (double)k.K;
+    (void)hipEventRecord(rec.a, st);
+  }
+  constexpr bool akc = MODE != MODE_WGRAD, bkc = MODE == MODE_FWD;
+  auto smem = [&](int bm, int bn) { return (size_t)2 * ((akc ? bm * LDK : BK * bm) + (bkc ? bn * LDK : BK * bn)) * sizeof(float); };
+  if (p.bn == 128) {
+    launch_one<MODE, 128, 128, 2, 2>(k, grid, smem(128, 128), st);
+  } else if (p.bn == 64) {
+    launch_one<MODE, 128, 64, 2, 2>(k, grid, smem(128, 64), st);
+  } else {
+    launch_one<MODE, 128, 32, 4, 1>(k, grid, smem(128, 32), st);
+  }
+  if (g_prof_on) {
+    (void)hipEventRecord(rec.b, st);
+    g_prof.push_back(rec);
+  }
+  return pm_check_launch("conv_igemm");
+}
+
+int check_common(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p) {
+  PM_REQUIRE(x && y && p && x->ptr && y->ptr, PM_EINVAL, "conv: null tensor");
+  PM_REQUIRE(p->kh >= 1 && p->kw >= 1 && p->dil >= 1 && p->pad >= 0, PM_EINVAL, "conv: bad geometry");
+  PM_REQUIRE(p->stride == 1 || p->stride == 2, PM_EUNSUPPORTED, "conv: stride %d unsupported (1 or 2)", p->stride);
+  const int ho = (x->h + 2 * p->pad - p->dil * (p->kh - 1) - 1) / p->stride + 1;
+  const int wo = (x->w + 2 * p->pad - p->dil * (p->kw - 1) - 1) / p->stride + 1;
+  PM_REQUIRE(ho == y->h && wo == y->w && x->n == y->n, PM_EINVAL, "conv: output %dx%d does not match geometry (%dx%d)", y->h, y->w, ho, wo);
+  PM_REQUIRE(pm_vec_ok(x) && pm_vec_ok(y), PM_EINVAL, "conv: tensors must be 16B aligned with pitch %% 4 == 0");
+  PM_REQUIRE(x->c % 4 == 0, PM_EUNSUPPORTED, "conv: Cin %% 4 != 0 unsupported (pad the input channels)");
+  PM_REQUIRE((y->c % 4 == 0) || (p->kh * p->kw == 1), PM_EUNSUPPORTED, "conv: Cout %% 4 != 0 only for 1x1");
+  PM_REQUIRE(x->pitch >= x->c && y->pitch >= y->c, PM_EINVAL, "conv: pitch < channels");
+  PM_REQUIRE(pm_pixels(x) * x->pitch < (1ll << 31) && pm_pixels(y) * y->pitch < (1ll << 31) && (int64_t)y->c * x->c * p->kh * p->kw < (1ll << 31),
+             PM_EUNSUPPORTED, "conv: tensor too large for 32-bit pixel indexing");
+  return PM_OK;
+}
+
+void fill_geom(ConvK& k, const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p) {
+  k.N = x->n, k.H = x->h, k.W = x->w, k.Cin = x->c, k.x_pitch = x->pitch;
+  k.Ho = y->h, k.Wo = y->w, k.Cout = y->c, k.y_pitch = y->pitch;
+  k.kh = p->kh, k.kw = p->kw, k.stride = p->stride, k.pad = p->pad, k.dil = p->dil;
+  k.sshift = p->stride == 2 ? 1 : 0;
+  k.bias = k.scale = k.shift = k.residual = nullptr;
+  k.res_pitch = 0, k.relu = 0;
+}
+
+void gemm_dims(int which, const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p, long& M, long& Nn, long& K) {
+  const long T = (long)p->kh * p->kw;
+  if (which == MODE_FWD) M = pm_pixels(y), Nn = y->c, K = T * x->c;
+  else if (which == MODE_DGRAD) M = pm_pixels(x), Nn = x->c, K = T * y->c;
+  else M = y->c, Nn = T * x->c, K = pm_pixels(y);
+}
+
+}  // namespace
+
+extern "C" int pm_profile_enable(int on) {
+  g_prof_on = on != 0;
+  return PM_OK;
+}
+// Sums (and clears) the records of one kernel instantiation: mode 0 fwd / 1 dgrad / 2 wgrad, bn = 128 / 64 / 32 (N tile).
+// mode < 0 or bn <= 0 act as wildcards. Synchronises on the recorded events only.
+extern "C" int pm_profile_read(int mode, int bn, double* total_ms, double* total_flops, int64_t* launches, int clear) {
+  double ms = 0.0, fl = 0.0;
+  int64_t n = 0;
+  for (const ProfRec& r : g_prof) {
+    if ((mode >= 0 && r.mode != mode) || (bn > 0 && r.bn != bn)) continue;
+    float t = 0.f;
+    if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+    ms += t, fl += r.flops, ++n;
+  }
+  if (clear) {
+    for (const ProfRec& r : g_prof) (void)hipEventDestroy(r.a), (void)hipEventDestroy(r.b);
+    g_prof.clear();
+  }
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  if (launches) *launches = n;
+  return PM_OK;
+}
+
+extern "C" size_t pm_conv_workspace(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p, int which) {
+  long M, Nn, K;
+  gemm_dims(which, x, y, p, M, Nn, K);
+  size_t b = make_plan(which, M, Nn, K).ws_bytes;
+  if (which == MODE_WGRAD) b += pm_align_up((size_t)pm_cdiv(pm_pixels(y), 2048) * y->c * sizeof(float), 256);  // bias partials
+  return pm_align_up(b, 256);
+}
+
+extern "C" int pm_conv_fwd(const pm_tensor* x, const float* w, const pm_tensor* y, const pm_conv_params* p,
+                           const pm_conv_epilogue* ep, void* ws, size_t ws_bytes, void* stream) {
+  if (int e = check_common(x, y, p)) return e;
+  PM_REQUIRE(w && pm_aligned16(w), PM_EINVAL, "conv_fwd: weight null or unaligned");
+  long M, Nn, K;
+  gemm_dims(MODE_FWD, x, y, p, M, Nn, K);
+  Plan pl = make_plan(MODE_FWD, M, Nn, K);
+  PM_REQUIRE(pl.ws_bytes <= ws_bytes && (pl.ws_bytes == 0 || ws), PM_EWORKSPACE, "conv_fwd: workspace %zu < %zu", ws_bytes, pl.ws_bytes);
+  ConvK k;
+  fill_geom(k, x, y, p);
+  k.A = (const float*)x->ptr, k.B = w;
+  k.M = (int)M, k.Nn = (int)Nn, k.K = (int)K;
+  pm_conv_epilogue e0 = {nullptr, nullptr, nullptr, nullptr, 0, 0};
+  if (ep) e0 = *ep;
+  PM_REQUIRE((e0.scale == nullptr) == (e0.shift == nullptr), PM_EINVAL, "conv_fwd: scale and shift go together");
+  hipStream_t st = (hipStream_t)stream;
+  if (pl.ksplit > 1) {
+    k.C = (float*)ws, k.c_pitch = Nn, k.c_split = M * Nn;
+    if (int e = launch<MODE_FWD>(k, pl, st)) return e;
+    const int nb = (int)std::min<long>((M * Nn + 255) / 256, 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, (const float*)ws, pl.ksplit, M * Nn, (int)M, (int)Nn, (float*)y->ptr,
+                       (long)y->pitch, e0.bias, e0.scale, e0.shift, e0.residual, (long)e0.residual_pitch, e0.relu);
+    return pm_check_launch("splitk_reduce");
+  }
+  k.C = (float*)y->ptr, k.c_pitch = y->pitch, k.c_split = 0;
+  k.bias = e0.bias, k.scale = e0.scale, k.shift = e0.shift, k.residual = e0.residual, k.res_pitch = e0.residual_pitch, k.relu = e0.relu;
+  return launch<MODE_FWD>(k, pl, st);
+}
+
+extern "C" int pm_conv_bwd_data(const pm_tensor* dy, const float* w, const pm_tensor* dx, const pm_conv_params* p, const pm_tensor* add,
+                                void* ws, size_t ws_bytes, void* stream) {
+  if (int e = check_common(dx, dy, p)) return e;
+  PM_REQUIRE(!add || (add->ptr && pm_same_shape(add, dx)), PM_EINVAL, "conv_bwd_data: `add` must match dx");
+  const float* addp = add ? (const float*)add->ptr : nullptr;
+  const long add_pitch = add ? add->pitch : 0;
+  PM_REQUIRE(w && pm_aligned16(w), PM_EINVAL, "conv_bwd_data: weight null or unaligned");
+  long M, Nn, K;
+  gemm_dims(MODE_DGRAD, dx, dy, p, M, Nn, K);
+  Plan pl = make_plan(MODE_DGRAD, M, Nn, K);
+  PM_REQUIRE(pl.ws_bytes <= ws_bytes && (pl.ws_bytes == 0 || ws), PM_EWORKSPACE, "conv_bwd_data: workspace %zu < %zu", ws_bytes, pl.ws_bytes);
+  ConvK k;
+  fill_geom(k, dx, dy, p);
+  k.A = (const float*)dy->ptr, k.B = w;
+  k.M = (int)M, k.Nn = (int)Nn, k.K = (int)K;
+  hipStream_t st = (hipStream_t)stream;
+  if (pl.ksplit > 1) {
+    k.C = (float*)ws, k.c_pitch = Nn, k.c_split = M * Nn;
+    if (int e = launch<MODE_DGRAD>(k, pl, st)) return e;
+    const int nb = (int)std::min<long>((M * Nn + 255) / 256, 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, (const float*)ws, pl.ksplit, M * Nn, (int)M, (int)Nn, (float*)dx->ptr,
+                       (long)dx->pitch, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, addp, add_pitch, 0);
+    return pm_check_launch("splitk_reduce");
+  }
+  k.C = (float*)dx->ptr, k.c_pitch = dx->pitch, k.c_split = 0;
+  k.residual = addp, k.res_pitch = add_pitch;
+  return launch<MODE_DGRAD>(k, pl, st);
+}
+
+extern "C" int pm_conv_bwd_weight(const pm_tensor* x, const pm_tensor* dy, float* dw, float* dbias, const pm_conv_params* p, void* ws,
+                                  size_t ws_bytes, void* stream) {
+  if (int e = check_common(x, dy, p)) return e;
+  PM_REQUIRE(dw && pm_aligned16(dw), PM_EINVAL, "conv_bwd_weight: dw null or unaligned");
+  long M, Nn, K;
+  gemm_dims(MODE_WGRAD, x, dy, p, M, Nn, K);
+  Plan pl = make_plan(MODE_WGRAD, M, Nn, K);
+  const size_t need = pm_conv_workspace(x, dy, p, MODE_WGRAD);
+  PM_REQUIRE(need <= ws_bytes && ws, PM_EWORKSPACE, "conv_bwd_weight: workspace %zu < %zu", ws_bytes, need);
+  ConvK k;
+  fill_geom(k, x, dy, p);
+  k.A = (const float*)dy->ptr, k.B = (const float*)x->ptr;
+  k.M = (int)M, k.Nn = (int)Nn, k.K = (int)K;
+  hipStream_t st = (hipStream_t)stream;
+  if (pl.ksplit > 1) {
+    k.C = (float*)ws, k.c_pitch = Nn, k.c_split = M * Nn;
+    if (int e = launch<MODE_WGRAD>(k, pl, st)) return e;
+    const int nb = (int)std::min<long>((M * Nn + 255) / 256, 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, (const float*)ws, pl.ksplit, M * Nn, (int)M, (int)Nn, dw, (long)Nn,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0l, 0);
+    if (int e = pm_check_launch("splitk_reduce")) return e;
+  } else {
+    k.C = dw, k.c_pitch = Nn, k.c_split = 0;
+    if (int e = launch<MODE_WGRAD>(k, pl, st)) return e;
+  }
+  if (dbias) {
+    const long P = pm_pixels(dy);
+    const int nb = pm_cdiv(P, 2048);
+    float* part = (float*)((char*)ws + pm_align_up(pl.ws_bytes, 256));
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb, pm_cdiv(dy->c, 64)), dim3(256), 0, st, (const float*)dy->ptr, (long)dy->pitch, P, dy->c, 2048, part);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(pm_cdiv(dy->c, 64)), dim3(64), 0, st, (const float*)part, nb, dy->c, dbias);
+    return pm_check_launch("conv_bias_grad");
+  }
+  return PM_OK;
+}

@@ -1,0 +1,411 @@
+// K7/K8: the categorical memory of "Pin the Memory" (/root/reference/network/memory.py) -- HBM-bound row kernels.
+//   read   (memory.py:317-336 + get_score :167-189): qhat = x/max(|x|,1e-12); S = qhat.M^T; P = softmax_slots(S [+gumbel]);
+//          R = P.M; writes [qhat | R] (the 2d-channel input of memory.output), S and P. One wave per query row
+//          (d = 256 = 64 lanes x float4), the 19x256 memory lives in LDS, per-slot dot products reduced with wave shuffles.
+//   write  (memory.py:206-239): 4-tap bilinear(align_corners) soft labels straight from the int64 mask (never the
+//          755 MB one-hot), class-masked accumulation of nominator[20][256] / denominator[20] in per-wave LDS slabs,
+//          fixed-order two-stage reduce; momentum update + renormalise with a device-side `den != 0` predicate
+//          (the reference syncs the host 19 times per step, memory.py:234-237).
+// All reductions are deterministic (no atomics).
+#include "pm_common.h"
+
+namespace {
+
+constexpr int D = 256;     // feature dim (mem_dim); one wave = one row of 64 float4
+constexpr int MAXM = 32;   // max slots (+1 for the ignore class in write)
+constexpr float EPS = 1e-12f;
+
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// read forward
+// ---------------------------------------------------------------------------------------------------------------
+template <int M_>
+__global__ __launch_bounds__(256) void mem_read_fwd_kernel(const float* __restrict__ x, long xp, long rows, const float* __restrict__ mem, int m_rt,
+                                                           const float* __restrict__ noise, float* __restrict__ qr, long qp, float* __restrict__ score,
+                                                           float* __restrict__ pm) {
+  const int M = M_ > 0 ? M_ : m_rt;
+  __shared__ __align__(16) float smem[MAXM * D];
+  for (int i = threadIdx.x; i < M * D / 4; i += 256) reinterpret_cast<float4*>(smem)[i] = reinterpret_cast<const float4*>(mem)[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * 4) {
+    const float4 v = PM_LD4(x + r * xp + lane * 4);
+    const float nrm = fmaxf(sqrtf(pm_wave_sum(dot4(v, v))), EPS);
+    const float4 q = make_float4(v.x / nrm, v.y / nrm, v.z / nrm, v.w / nrm);
+    float s[M_ > 0 ? M_ : MAXM];
+#pragma unroll
+    for (int j = 0; j < (M_ > 0 ? M_ : MAXM); ++j)
+      if (j < M) s[j] = pm_wave_sum(dot4(q, reinterpret_cast<const float4*>(smem + j * D)[lane]));
+    if (lane < M) {
+      float mine = 0.f;
+#pragma unroll
+      for (int j = 0; j < (M_ > 0 ? M_ : MAXM); ++j)
+        if (j == lane) mine = s[j];
+      score[r * M + lane] = mine;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < (M_ > 0 ? M_ : MAXM); ++j)
+      if (j < M) {
+        if (noise) s[j] += noise[r * M + j];
+        mx = fmaxf(mx, s[j]);
+      }
+    float se = 0.f;
+#pragma unroll
+    for (int j = 0; j < (M_ > 0 ? M_ : MAXM); ++j)
+      if (j < M) s[j] = expf(s[j] - mx), se += s[j];
+    float4 agg = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < (M_ > 0 ? M_ : MAXM); ++j)
+      if (j < M) {
+        s[j] = s[j] / se;
+        const float4 mv = reinterpret_cast<const float4*>(smem + j * D)[lane];
+        agg.x += s[j] * mv.x, agg.y += s[j] * mv.y, agg.z += s[j] * mv.z, agg.w += s[j] * mv.w;
+      }
+    if (lane < M) {
+      float mine = 0.f;
+#pragma unroll
+      for (int j = 0; j < (M_ > 0 ? M_ : MAXM); ++j)
+        if (j == lane) mine = s[j];
+      pm[r * M + lane] = mine;
+    }
+    PM_ST4(qr + r * qp + lane * 4, q);
+    PM_ST4(qr + r * qp + D + lane * 4, agg);
+  }
+}
+
+// softmax over ALL rows per slot column (memory.py:186); one block per column, three sweeps over an L2-resident [N][m]
+__global__ __launch_bounds__(256) void mem_colsoftmax_kernel(const float* __restrict__ score, const float* __restrict__ noise, long rows, int M,
+                                                             float* __restrict__ out) {
+  __shared__ float red[4];
+  const int j = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float mx = -INFINITY;
+  for (long r = threadIdx.x; r < rows; r += 256) mx = fmaxf(mx, score[r * M + j] + (noise ? noise[r * M + j] : 0.f));
+  mx = pm_wave_max(mx);
+  if (lane == 0) red[wv] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float se = 0.f;
+  for (long r = threadIdx.x; r < rows; r += 256) se += expf(score[r * M + j] + (noise ? noise[r * M + j] : 0.f) - mx);
+  se = pm_wave_sum(se);
+  if (lane == 0) red[wv] = se;
+  __syncthreads();
+  se = (red[0] + red[1]) + (red[2] + red[3]);
+  for (long r = threadIdx.x; r < rows; r += 256) out[r * M + j] = expf(score[r * M + j] + (noise ? noise[r * M + j] : 0.f) - mx) / se;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// read backward: dx (and optionally per-block partials of dmem)
+// ---------------------------------------------------------------------------------------------------------------
+template <int M_, bool DMEM>
+__global__ __launch_bounds__(256) void mem_read_bwd_kernel(const float* __restrict__ x, long xp, long rows, const float* __restrict__ mem, int m_rt,
+                                                           const float* __restrict__ pm, const float* __restrict__ dqr, long dqp,
+                                                           const float* __restrict__ dsx, float* __restrict__ dx, long dxp, float* __restrict__ dmem_part) {
+  const int M = M_ > 0 ? M_ : m_rt;
+  __shared__ __align__(16) float smem[MAXM * D];
+  for (int i = threadIdx.x; i < M * D / 4; i += 256) reinterpret_cast<float4*>(smem)[i] = reinterpret_cast<const float4*>(mem)[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float4 dm[DMEM ? (M_ > 0 ? M_ : MAXM) : 1];
+#pragma unroll
+  for (int j = 0; j < (DMEM ? (M_ > 0 ? M_ : MAXM) : 1); ++j) dm[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long r = (long)blockIdx.x * 4 + wv; r < rows; r += (long)gridDim.x * 4) {
+    const float4 v = PM_LD4(x + r * xp + lane * 4);
+    const float n0 = sqrtf(pm_wave_sum(dot4(v, v)));
+    const float nrm = fmaxf(n0, EPS);
+    const float4 q = make_float4(v.x / nrm, v.y / nrm, v.z / nrm, v.w / nrm);
+    float4 dq = PM_LD4(dqr + r * dqp + lane * 4);
+    const float4 dr = PM_LD4(dqr + r * dqp + D + lane * 4);
+    float p[M_ > 0 ? M_ : MAXM], dp[M_ > 0 ? M_ : MAXM];
+    float pdp = 0.f;
+#pragma unroll
+    for (int j = 0; j < (M_ > 0 ? M_ : MAXM); ++j)
+      if (j < M) {
+        p[j] = pm[r * M + j];
+        dp[j] = pm_wave_sum(dot4(dr, reinterpret_cast<const float4*>(smem + j * D)[lane]));
+        pdp += p[j] * dp[j];
+      }
+#pragma unroll
+    for (int j = 0; j < (M_ > 0 ? M_ : MAXM); ++j)
+      if (j < M) {
+        const float ds = p[j] * (dp[j] - pdp) + (dsx ? dsx[r * M + j] : 0.f);
+        const float4 mv = reinterpret_cast<const float4*>(smem + j * D)[lane];
+        dq.x += ds * mv.x, dq.y += ds * mv.y, dq.z += ds * mv.z, dq.w += ds * mv.w;
+        if (DMEM) {
+          dm[j].x += ds * q.x + p[j] * dr.x, dm[j].y += ds * q.y + p[j] * dr.y;
+          dm[j].z += ds * q.z + p[j] * dr.z, dm[j].w += ds * q.w + p[j] * dr.w;
+        }
+      }
+    // through qhat = x / max(|x|, eps)
+    float4 o;
+    if (n0 >= EPS) {
+      const float qd = pm_wave_sum(dot4(q, dq));
+      o = make_float4((dq.x - q.x * qd) / nrm, (dq.y - q.y * qd) / nrm, (dq.z - q.z * qd) / nrm, (dq.w - q.w * qd) / nrm);
+    } else {
+      o = make_float4(dq.x / nrm, dq.y / nrm, dq.z / nrm, dq.w / nrm);
+    }
+    PM_ST4(dx + r * dxp + lane * 4, o);
+  }
+  if (DMEM) {  // cross-wave reduce through LDS (memory copy no longer needed), then one partial slab per block
+    __syncthreads();
+    float* red = smem;  // reuse: [4 waves] would need 4*M*D floats > MAXM*D; reduce slot by slot instead
+#pragma unroll
+    for (int j = 0; j < (M_ > 0 ? M_ : MAXM); ++j)
+      if (j < M) {
+        reinterpret_cast<float4*>(red + wv * D)[lane] = dm[j];
+        __syncthreads();
+        if (wv == 0) {
+          float4 a = reinterpret_cast<float4*>(red)[lane], b = reinterpret_cast<float4*>(red + D)[lane];
+          float4 c = reinterpret_cast<float4*>(red + 2 * D)[lane], d = reinterpret_cast<float4*>(red + 3 * D)[lane];
+          float4 s = make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+          PM_ST4(dmem_part + ((long)blockIdx.x * M + j) * D + lane * 4, s);
+        }
+        __syncthreads();
+      }
+  }
+}
+
+__global__ void reduce_partials_kernel(const float* __restrict__ part, int nb, long n, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int b = 0; b < nb; ++b) s += part[(long)b * n + i];
+  out[i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// write: accumulate nominator / denominator
+// ---------------------------------------------------------------------------------------------------------------
+struct Taps {
+  int cls[4];
+  float w[4];
+};
+__device__ __forceinline__ Taps soft_label_taps(const int64_t* __restrict__ lab, int b, int y, int x, int H, int W, int h, int w, float sy, float sx, int m) {
+  const pm_lerp ly = pm_ac_lerp(sy, y, H), lx = pm_ac_lerp(sx, x, W);  // downsample: source grid is the H x W mask
+  (void)h, (void)w;
+  Taps t;
+  const int64_t* base = lab + (long)b * H * W;
+  const int ys[2] = {ly.i0, ly.i1}, xs[2] = {lx.i0, lx.i1};
+  const float wy[2] = {ly.w0, ly.w1}, wx[2] = {lx.w0, lx.w1};
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int64_t c = base[(long)ys[i] * W + xs[j]];
+      if (c == 255) c = m;                       // memory.py:220
+      t.cls[i * 2 + j] = (c >= 0 && c <= m) ? (int)c : -1;
+      t.w[i * 2 + j] = wy[i] * wx[j];
+    }
+  return t;
+}
+
+constexpr int ACC_W = 4;   // waves per block
+__global__ __launch_bounds__(256) void mem_write_accum_kernel(const float* __restrict__ z, long zp, int n, int h, int w, const int64_t* __restrict__ lab,
+                                                              int H, int W, int m, int normalize, float sy, float sx, float* __restrict__ part) {
+  extern __shared__ __align__(16) float sacc[];   // [ACC_W][(m+1)*D + MAXM]
+  const int slab = (m + 1) * D + MAXM;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* mine = sacc + wv * slab;
+  for (int i = lane; i < slab; i += 64) mine[i] = 0.f;
+  const long rows = (long)n * h * w;
+  for (long r = (long)blockIdx.x * ACC_W + wv; r < rows; r += (long)gridDim.x * ACC_W) {
+    const int x = (int)(r % w), y = (int)((r / w) % h), b = (int)(r / ((long)w * h));
+    float4 v = PM_LD4(z + r * zp + lane * 4);
+    if (normalize) {
+      const float nrm = fmaxf(sqrtf(pm_wave_sum(dot4(v, v))), EPS);
+      v = make_float4(v.x / nrm, v.y / nrm, v.z / nrm, v.w / nrm);
+    }
+    const Taps t = soft_label_taps(lab, b, y, x, H, W, h, w, sy, sx, m);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (t.cls[k] < 0 || t.w[k] == 0.f) continue;   // wave-uniform
+      float4* a = reinterpret_cast<float4*>(mine + t.cls[k] * D) + lane;
+      float4 c = *a;
+      c.x += t.w[k] * v.x, c.y += t.w[k] * v.y, c.z += t.w[k] * v.z, c.w += t.w[k] * v.w;
+      *a = c;
+      if (lane == 0) mine[(m + 1) * D + t.cls[k]] += t.w[k];
+    }
+  }
+  __syncthreads();
+  const int nout = (m + 1) * D + (m + 1);
+  for (int i = threadIdx.x; i < nout; i += 256) {
+    const int src = i < (m + 1) * D ? i : (m + 1) * D + (i - (m + 1) * D);
+    part[(long)blockIdx.x * nout + i] = (sacc[src] + sacc[slab + src]) + (sacc[2 * slab + src] + sacc[3 * slab + src]);
+  }
+}
+
+__global__ __launch_bounds__(256) void mem_write_accum_bwd_kernel(const float* __restrict__ z, long zp, int n, int h, int w, const int64_t* __restrict__ lab,
+                                                                  int H, int W, int m, int normalize, float sy, float sx, const float* __restrict__ dnom,
+                                                                  float* __restrict__ dz, long dzp) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long rows = (long)n * h * w;
+  for (long r = (long)blockIdx.x * 4 + wv; r < rows; r += (long)gridDim.x * 4) {
+    const int x = (int)(r % w), y = (int)((r / w) % h), b = (int)(r / ((long)w * h));
+    const Taps t = soft_label_taps(lab, b, y, x, H, W, h, w, sy, sx, m);
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (t.cls[k] < 0 || t.w[k] == 0.f) continue;
+      const float4 d = PM_LD4(dnom + (long)t.cls[k] * D + lane * 4);
+      g.x += t.w[k] * d.x, g.y += t.w[k] * d.y, g.z += t.w[k] * d.z, g.w += t.w[k] * d.w;
+    }
+    if (normalize) {
+      const float4 v = PM_LD4(z + r * zp + lane * 4);
+      const float n0 = sqrtf(pm_wave_sum(dot4(v, v)));
+      const float nrm = fmaxf(n0, EPS);
+      if (n0 >= EPS) {
+        const float4 q = make_float4(v.x / nrm, v.y / nrm, v.z / nrm, v.w / nrm);
+        const float qd = pm_wave_sum(dot4(q, g));
+        g = make_float4((g.x - q.x * qd) / nrm, (g.y - q.y * qd) / nrm, (g.z - q.z * qd) / nrm, (g.w - q.w * qd) / nrm);
+      } else {
+        g = make_float4(g.x / nrm, g.y / nrm, g.z / nrm, g.w / nrm);
+      }
+    }
+    PM_ST4(dz + r * dzp + lane * 4, g);
+  }
+}
+
+// update: one block (256 threads = D channels) per slot
+__global__ __launch_bounds__(256) void mem_write_update_kernel(const float* __restrict__ mem, const float* __restrict__ nomden, int m, float mu,
+                                                               float* __restrict__ out, float* __restrict__ u_out) {
+  __shared__ float red[4];
+  const int j = blockIdx.x, c = threadIdx.x;
+  const float den = nomden[(m + 1) * D + j];
+  const float old = mem[j * D + c];
+  const float u = den != 0.f ? mu * old + (1.f - mu) * nomden[j * D + c] / den : old;
+  float ss = pm_wave_sum(u * u);
+  if ((c & 63) == 0) red[c >> 6] = ss;
+  __syncthreads();
+  const float nrm = fmaxf(sqrtf((red[0] + red[1]) + (red[2] + red[3])), EPS);
+  out[j * D + c] = u / nrm;
+  if (u_out) u_out[j * D + c] = u;
+}
+
+__global__ __launch_bounds__(256) void mem_write_update_bwd_kernel(const float* __restrict__ u, const float* __restrict__ nomden, int m, float mu,
+                                                                   const float* __restrict__ dout, float* __restrict__ dnom, float* __restrict__ dmem_in) {
+  __shared__ float red[2][4];
+  const int j = blockIdx.x, c = threadIdx.x;
+  if (j == m) {  // ignore-class row never reaches the memory
+    dnom[j * D + c] = 0.f;
+    return;
+  }
+  const float uv = u[j * D + c], g = dout[j * D + c];
+  const float ss = pm_wave_sum(uv * uv), ug = pm_wave_sum(uv * g);
+  if ((c & 63) == 0) red[0][c >> 6] = ss, red[1][c >> 6] = ug;
+  __syncthreads();
+  const float n0 = sqrtf((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+  const float dot = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  const float nrm = fmaxf(n0, EPS);
+  const float du = n0 >= EPS ? (g - (uv / nrm) * (dot / nrm)) / nrm : g / nrm;
+  const float den = nomden[(m + 1) * D + j];
+  dnom[j * D + c] = den != 0.f ? du * (1.f - mu) / den : 0.f;
+  if (dmem_in) dmem_in[j * D + c] = den != 0.f ? du * mu : du;
+}
+
+inline int row_blocks(long rows) { return (int)std::min<long>((rows + 3) / 4, 256 * 8); }
+inline int accum_blocks(long rows) { return (int)std::min<long>((rows + 63) / 64, 128); }
+
+}  // namespace
+
+extern "C" int pm_mem_read_fwd(const pm_tensor* x, const float* mem, int m, const float* noise, const pm_tensor* qr, float* score, float* p_mem,
+                               void* stream) {
+  PM_REQUIRE(x && qr && mem && score && p_mem && x->ptr && qr->ptr, PM_EINVAL, "mem_read_fwd: null");
+  PM_REQUIRE(x->c == D && qr->c == 2 * D && pm_vec_ok(x) && pm_vec_ok(qr) && pm_aligned16(mem), PM_EUNSUPPORTED, "mem_read_fwd: needs d == %d, aligned views", D);
+  PM_REQUIRE(m >= 1 && m <= MAXM && pm_pixels(x) == pm_pixels(qr), PM_EINVAL, "mem_read_fwd: bad slots/rows");
+  const long rows = pm_pixels(x);
+  hipStream_t st = (hipStream_t)stream;
+  if (m == 19)
+    hipLaunchKernelGGL(mem_read_fwd_kernel<19>, dim3(row_blocks(rows)), dim3(256), 0, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, noise,
+                       (float*)qr->ptr, (long)qr->pitch, score, p_mem);
+  else
+    hipLaunchKernelGGL(mem_read_fwd_kernel<0>, dim3(row_blocks(rows)), dim3(256), 0, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, noise,
+                       (float*)qr->ptr, (long)qr->pitch, score, p_mem);
+  return pm_check_launch("mem_read_fwd");
+}
+
+extern "C" size_t pm_mem_colsoftmax_workspace(int64_t, int) { return 0; }
+extern "C" int pm_mem_colsoftmax(const float* score, const float* noise, int64_t rows, int m, float* p_query, void*, size_t, void* stream) {
+  PM_REQUIRE(score && p_query && rows > 0 && m >= 1, PM_EINVAL, "mem_colsoftmax: bad args");
+  hipLaunchKernelGGL(mem_colsoftmax_kernel, dim3(m), dim3(256), 0, (hipStream_t)stream, score, noise, (long)rows, m, p_query);
+  return pm_check_launch("mem_colsoftmax");
+}
+
+extern "C" size_t pm_mem_read_bwd_workspace(int64_t rows, int m, int d) { return pm_align_up((size_t)row_blocks(rows) * m * d * sizeof(float), 256); }
+extern "C" int pm_mem_read_bwd(const pm_tensor* x, const float* mem, int m, const float* p_mem, const pm_tensor* dqr, const float* dsx,
+                               const pm_tensor* dx, float* dmem, void* ws, size_t ws_bytes, void* stream) {
+  PM_REQUIRE(x && dqr && dx && mem && p_mem && x->ptr && dqr->ptr && dx->ptr, PM_EINVAL, "mem_read_bwd: null");
+  PM_REQUIRE(x->c == D && dqr->c == 2 * D && dx->c == D && pm_vec_ok(x) && pm_vec_ok(dqr) && pm_vec_ok(dx) && pm_aligned16(mem), PM_EUNSUPPORTED,
+             "mem_read_bwd: needs d == %d, aligned views", D);
+  PM_REQUIRE(m >= 1 && m <= MAXM, PM_EINVAL, "mem_read_bwd: bad slots");
+  const long rows = pm_pixels(x);
+  const int nb = row_blocks(rows);
+  hipStream_t st = (hipStream_t)stream;
+  if (dmem) {
+    PM_REQUIRE(ws && ws_bytes >= pm_mem_read_bwd_workspace(rows, m, D), PM_EWORKSPACE, "mem_read_bwd: workspace too small");
+    if (m == 19)
+      hipLaunchKernelGGL((mem_read_bwd_kernel<19, true>), dim3(nb), dim3(256), 0, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, p_mem,
+                         (const float*)dqr->ptr, (long)dqr->pitch, dsx, (float*)dx->ptr, (long)dx->pitch, (float*)ws);
+    else
+      hipLaunchKernelGGL((mem_read_bwd_kernel<0, true>), dim3(nb), dim3(256), 0, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, p_mem,
+                         (const float*)dqr->ptr, (long)dqr->pitch, dsx, (float*)dx->ptr, (long)dx->pitch, (float*)ws);
+    const long n = (long)m * D;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(pm_cdiv(n, 256)), dim3(256), 0, st, (const float*)ws, nb, n, dmem);
+  } else {
+    if (m == 19)
+      hipLaunchKernelGGL((mem_read_bwd_kernel<19, false>), dim3(nb), dim3(256), 0, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, p_mem,
+                         (const float*)dqr->ptr, (long)dqr->pitch, dsx, (float*)dx->ptr, (long)dx->pitch, (float*)nullptr);
+    else
+      hipLaunchKernelGGL((mem_read_bwd_kernel<0, false>), dim3(nb), dim3(256), 0, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, p_mem,
+                         (const float*)dqr->ptr, (long)dqr->pitch, dsx, (float*)dx->ptr, (long)dx->pitch, (float*)nullptr);
+  }
+  return pm_check_launch("mem_read_bwd");
+}
+
+extern "C" size_t pm_mem_write_accum_workspace(const pm_tensor* z, int m) {
+  return pm_align_up((size_t)accum_blocks(pm_pixels(z)) * ((m + 1) * (D + 1)) * sizeof(float), 256);
+}
+extern "C" int pm_mem_write_accum(const pm_tensor* z, const int64_t* labels, int H, int W, int m, int normalize, float* nomden, void* ws, size_t ws_bytes,
+                                  void* stream) {
+  PM_REQUIRE(z && z->ptr && labels && nomden, PM_EINVAL, "mem_write_accum: null");
+  PM_REQUIRE(z->c == D && pm_vec_ok(z) && m >= 1 && m + 1 <= MAXM, PM_EUNSUPPORTED, "mem_write_accum: needs d == %d and <= %d slots", D, MAXM - 1);
+  PM_REQUIRE(ws && ws_bytes >= pm_mem_write_accum_workspace(z, m), PM_EWORKSPACE, "mem_write_accum: workspace too small");
+  const long rows = pm_pixels(z);
+  const int nb = accum_blocks(rows);
+  const size_t lds = (size_t)ACC_W * ((m + 1) * D + MAXM) * sizeof(float);
+  static const bool attr = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mem_write_accum_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return true;
+  }();
+  (void)attr;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(mem_write_accum_kernel, dim3(nb), dim3(256), lds, st, (const float*)z->ptr, (long)z->pitch, z->n, z->h, z->w, labels, H, W, m, normalize,
+                     pm_ac_scale(H, z->h), pm_ac_scale(W, z->w), (float*)ws);
+  const long n = (long)(m + 1) * (D + 1);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(pm_cdiv(n, 256)), dim3(256), 0, st, (const float*)ws, nb, n, nomden);
+  return pm_check_launch("mem_write_accum");
+}
+
+extern "C" int pm_mem_write_accum_bwd(const pm_tensor* z, const int64_t* labels, int H, int W, int m, int normalize, const float* dnom,
+                                      const pm_tensor* dz, void* stream) {
+  PM_REQUIRE(z && dz && z->ptr && dz->ptr && labels && dnom && pm_aligned16(dnom), PM_EINVAL, "mem_write_accum_bwd: null/unaligned");
+  PM_REQUIRE(z->c == D && dz->c == D && pm_vec_ok(z) && pm_vec_ok(dz) && m >= 1 && m + 1 <= MAXM, PM_EUNSUPPORTED, "mem_write_accum_bwd: needs d == %d", D);
+  const long rows = pm_pixels(z);
+  hipLaunchKernelGGL(mem_write_accum_bwd_kernel, dim3(row_blocks(rows)), dim3(256), 0, (hipStream_t)stream, (const float*)z->ptr, (long)z->pitch, z->n, z->h,
+                     z->w, labels, H, W, m, normalize, pm_ac_scale(H, z->h), pm_ac_scale(W, z->w), dnom, (float*)dz->ptr, (long)dz->pitch);
+  return pm_check_launch("mem_write_accum_bwd");
+}
+
+extern "C" int pm_mem_write_update(const float* mem, const float* nomden, int m, int d, float momentum, float* mem_out, float* u_out, void* stream) {
+  PM_REQUIRE(mem && nomden && mem_out && d == D && m >= 1 && m + 1 <= MAXM, PM_EINVAL, "mem_write_update: bad args (d must be %d)", D);
+  hipLaunchKernelGGL(mem_write_update_kernel, dim3(m), dim3(256), 0, (hipStream_t)stream, mem, nomden, m, momentum, mem_out, u_out);
+  return pm_check_launch("mem_write_update");
+}
+
+extern "C" int pm_mem_write_update_bwd(const float* u, const float* nomden, int m, int d, float momentum, const float* dmem_out, float* dnom, float* dmem_in,
+                                       void* stream) {
+  PM_REQUIRE(u && nomden && dmem_out && dnom && d == D && m >= 1 && m + 1 <= MAXM, PM_EINVAL, "mem_write_update_bwd: bad args (d must be %d)", D);
+  hipLaunchKernelGGL(mem_write_update_bwd_kernel, dim3(m + 1), dim3(256), 0, (hipStream_t)stream, u, nomden, m, momentum, dmem_out, dnom, dmem_in);
+  return pm_check_launch("mem_write_update_bwd");
+}

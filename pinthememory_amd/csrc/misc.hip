@@ -1,0 +1,170 @@
+// Error reporting, elementwise helpers, layout edges and the flat-arena SGD step.
+#include <algorithm>
+
+#include "pm_common.h"
+
+static thread_local char g_err[512] = "";
+
+void pm_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* pm_last_error(void) { return g_err; }
+extern "C" int pm_version(void) { return 100; }
+
+#define LD4 PM_LD4
+#define ST4 PM_ST4
+#define ew_launch pm_ew_launch
+#define same_shape pm_same_shape
+#define vec4 pm_vec4
+
+extern "C" int pm_relu_bwd(const pm_tensor* dy, const pm_tensor* y, const pm_tensor* dx, void* stream) {
+  PM_REQUIRE(dy && y && dx && same_shape(dy, y) && same_shape(dy, dx), PM_EINVAL, "relu_bwd: shape mismatch");
+  const float *pdy = (const float*)dy->ptr, *py = (const float*)y->ptr;
+  float* pdx = (float*)dx->ptr;
+  const long a = dy->pitch, b = y->pitch, c = dx->pitch;
+  const bool v = vec4(dy) && vec4(y) && vec4(dx);
+  if (v)
+    return ew_launch(true, pm_pixels(dy), dy->c, (hipStream_t)stream, "relu_bwd", [=] __device__(long p, int ch) {
+      float4 g = LD4(pdy + p * a + ch), o = LD4(py + p * b + ch);
+      g.x = o.x > 0.f ? g.x : 0.f, g.y = o.y > 0.f ? g.y : 0.f, g.z = o.z > 0.f ? g.z : 0.f, g.w = o.w > 0.f ? g.w : 0.f;
+      ST4(pdx + p * c + ch, g);
+    });
+  return ew_launch(false, pm_pixels(dy), dy->c, (hipStream_t)stream, "relu_bwd",
+                   [=] __device__(long p, int ch) { pdx[p * c + ch] = py[p * b + ch] > 0.f ? pdy[p * a + ch] : 0.f; });
+}
+
+extern "C" int pm_add(const pm_tensor* x, const pm_tensor* y, const pm_tensor* o, void* stream) {
+  PM_REQUIRE(x && y && o && same_shape(x, y) && same_shape(x, o), PM_EINVAL, "add: shape mismatch");
+  const float *px = (const float*)x->ptr, *py = (const float*)y->ptr;
+  float* po = (float*)o->ptr;
+  const long a = x->pitch, b = y->pitch, c = o->pitch;
+  if (vec4(x) && vec4(y) && vec4(o))
+    return ew_launch(true, pm_pixels(x), x->c, (hipStream_t)stream, "add", [=] __device__(long p, int ch) {
+      float4 u = LD4(px + p * a + ch), w = LD4(py + p * b + ch);
+      ST4(po + p * c + ch, make_float4(u.x + w.x, u.y + w.y, u.z + w.z, u.w + w.w));
+    });
+  return ew_launch(false, pm_pixels(x), x->c, (hipStream_t)stream, "add",
+                   [=] __device__(long p, int ch) { po[p * c + ch] = px[p * a + ch] + py[p * b + ch]; });
+}
+
+extern "C" int pm_copy(const pm_tensor* x, const pm_tensor* o, void* stream) {
+  PM_REQUIRE(x && o && same_shape(x, o), PM_EINVAL, "copy: shape mismatch");
+  const float* px = (const float*)x->ptr;
+  float* po = (float*)o->ptr;
+  const long a = x->pitch, c = o->pitch;
+  if (vec4(x) && vec4(o))
+    return ew_launch(true, pm_pixels(x), x->c, (hipStream_t)stream, "copy",
+                     [=] __device__(long p, int ch) { ST4(po + p * c + ch, LD4(px + p * a + ch)); });
+  return ew_launch(false, pm_pixels(x), x->c, (hipStream_t)stream, "copy", [=] __device__(long p, int ch) { po[p * c + ch] = px[p * a + ch]; });
+}
+
+// y = relu?(x*scale[c] + shift[c] + residual?)  -- eval-mode BN fold applied to an existing tensor
+extern "C" int pm_scale_shift_act(const pm_tensor* x, const float* scale, const float* shift, const pm_tensor* res, int relu,
+                                  const pm_tensor* o, void* stream) {
+  PM_REQUIRE(x && o && scale && shift && same_shape(x, o) && (!res || same_shape(x, res)), PM_EINVAL, "scale_shift_act: bad args");
+  const float *px = (const float*)x->ptr, *pr = res ? (const float*)res->ptr : nullptr;
+  float* po = (float*)o->ptr;
+  const long a = x->pitch, b = res ? res->pitch : 0, c = o->pitch;
+  return ew_launch(false, pm_pixels(x), x->c, (hipStream_t)stream, "scale_shift_act", [=] __device__(long p, int ch) {
+    float v = px[p * a + ch] * scale[ch] + shift[ch];
+    if (pr) v += pr[p * b + ch];
+    po[p * c + ch] = relu ? fmaxf(v, 0.f) : v;
+  });
+}
+
+// ---- layout edges ----------------------------------------------------------------------------------------------
+namespace {
+// 32x32 LDS-tiled transpose between [C][P] planes and [P][pitch] rows (per image), coalesced on both sides.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, int csrc, long P, float* __restrict__ y, int c, long pitch) {
+  __shared__ float tile[32][33];
+  const int img = blockIdx.z;
+  const long p0 = (long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    const int ch = c0 + j;
+    const long p = p0 + tx;
+    tile[j][tx] = (ch < csrc && p < P) ? x[((long)img * csrc + ch) * P + p] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const long p = p0 + j;
+    const int ch = c0 + tx;
+    if (p < P && ch < c) y[((long)img * P + p) * pitch + ch] = tile[tx][j];
+  }
+}
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, int c, long pitch, long P, float* __restrict__ y) {
+  __shared__ float tile[32][33];
+  const int img = blockIdx.z;
+  const long p0 = (long)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    const long p = p0 + j;
+    const int ch = c0 + tx;
+    tile[j][tx] = (p < P && ch < c) ? x[((long)img * P + p) * pitch + ch] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int ch = c0 + j;
+    const long p = p0 + tx;
+    if (ch < c && p < P) y[((long)img * c + ch) * P + p] = tile[tx][j];
+  }
+}
+__global__ void label_nearest_kernel(const int64_t* __restrict__ lab, int n, int H, int W, int64_t* __restrict__ out, int h, int w, float sy, float sx) {
+  const long total = (long)n * h * w;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % w), y = (int)((i / w) % h), b = (int)(i / ((long)w * h));
+    // ATen nearest: src = min(floor(dst * scale), in-1), scale = in/out in float
+    int yy = min((int)floorf((float)y * sy), H - 1), xx = min((int)floorf((float)x * sx), W - 1);
+    out[i] = lab[((long)b * H + yy) * W + xx];
+  }
+}
+}  // namespace
+
+extern "C" int pm_nchw_to_nhwc(const float* x, int c_src, const pm_tensor* y, void* stream) {
+  PM_REQUIRE(x && y && y->ptr && c_src <= y->c, PM_EINVAL, "nchw_to_nhwc: bad args");
+  const long P = (long)y->h * y->w;
+  dim3 grid(pm_cdiv(P, 32), pm_cdiv(y->c, 32), y->n);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, c_src, P, (float*)y->ptr, y->c, (long)y->pitch);
+  return pm_check_launch("nchw_to_nhwc");
+}
+extern "C" int pm_nhwc_to_nchw(const pm_tensor* x, float* y, void* stream) {
+  PM_REQUIRE(x && y && x->ptr, PM_EINVAL, "nhwc_to_nchw: bad args");
+  const long P = (long)x->h * x->w;
+  dim3 grid(pm_cdiv(P, 32), pm_cdiv(x->c, 32), x->n);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr, x->c, (long)x->pitch, P, y);
+  return pm_check_launch("nhwc_to_nchw");
+}
+extern "C" int pm_label_nearest(const int64_t* lab, int n, int H, int W, int64_t* out, int h, int w, void* stream) {
+  PM_REQUIRE(lab && out && h > 0 && w > 0, PM_EINVAL, "label_nearest: bad args");
+  const long total = (long)n * h * w;
+  hipLaunchKernelGGL(label_nearest_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream, lab, n, H, W, out, h, w,
+                     (float)H / (float)h, (float)W / (float)w);
+  return pm_check_launch("label_nearest");
+}
+
+// ---- SGD with momentum over a flat arena (torch.optim.SGD semantics, optimizer.py:21-25) --------------------------
+namespace {
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, long n, float lr, float mom,
+                                                  float wd, int first) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float w = p[i];
+    const float d = g[i] + wd * w;
+    const float b = first ? d : mom * m[i] + d;
+    m[i] = b;
+    p[i] = w - lr * b;
+  }
+}
+}  // namespace
+extern "C" int pm_sgd_momentum(float* param, const float* grad, float* mbuf, int64_t n, float lr, float momentum, float wd, int first_step,
+                               void* stream) {
+  PM_REQUIRE(param && grad && mbuf && n >= 0, PM_EINVAL, "sgd: bad args");
+  if (n == 0) return PM_OK;
+  hipLaunchKernelGGL(sgd_kernel, dim3((int)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)stream, param, grad, mbuf, (long)n, lr,
+                     momentum, wd, first_step);
+  return pm_check_launch("sgd_momentum");
+}

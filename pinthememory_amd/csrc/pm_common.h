@@ -1,0 +1,98 @@
+// Shared helpers for libpinmem_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/pinmem_hip.h"
+
+void pm_set_error(const char* fmt, ...);
+
+#define PM_REQUIRE(cond, code, ...)      \
+  do {                                   \
+    if (!(cond)) {                       \
+      pm_set_error(__VA_ARGS__);         \
+      return (code);                     \
+    }                                    \
+  } while (0)
+
+static inline int pm_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    pm_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return PM_ELAUNCH;
+  }
+  return PM_OK;
+}
+
+static inline bool pm_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int64_t pm_pixels(const pm_tensor* t) { return (int64_t)t->n * t->h * t->w; }
+static inline int pm_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline size_t pm_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Vectorisable NHWC view: base 16B-aligned, pitch % 4 == 0.
+static inline bool pm_vec_ok(const pm_tensor* t) { return pm_aligned16(t->ptr) && (t->pitch % 4) == 0; }
+
+// ---- device helpers -------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pm_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float pm_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ATen's align_corners=True source-index math, in fp32 exactly as area_pixel_compute_scale /
+// area_pixel_compute_source_index do it (scale = (in-1)/(out-1) in float, src = scale*dst).
+struct pm_lerp {
+  int i0, i1;
+  float w0, w1;
+};
+__host__ __device__ __forceinline__ float pm_ac_scale(int in, int out) {
+  return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+}
+__device__ __forceinline__ pm_lerp pm_ac_lerp(float scale, int dst, int in) {
+  float src = scale * (float)dst;
+  int i0 = (int)src;                       // src >= 0 -> truncation == floor
+  if (i0 > in - 1) i0 = in - 1;
+  int i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  float l1 = src - (float)i0;
+  if (l1 < 0.f) l1 = 0.f;
+  if (l1 > 1.f) l1 = 1.f;
+  pm_lerp r;
+  r.i0 = i0;
+  r.i1 = i1;
+  r.w1 = l1;
+  r.w0 = 1.f - l1;
+  return r;
+}
+
+// ---- generic NHWC elementwise driver: thread -> (pixel, 4 channels) ----------------------------------------------
+// VEC=true needs 16B-aligned views with c % 4 == 0 (pm_vec4). f(pixel, channel) is a __device__ lambda.
+template <bool VEC, typename F>
+__global__ __launch_bounds__(256) void pm_ew_kernel(long pixels, int c, F f) {
+  const int cg = VEC ? c / 4 : c;
+  const long total = pixels * cg;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long p = i / cg;
+    const int ch = (int)(i - p * cg) * (VEC ? 4 : 1);
+    f(p, ch);
+  }
+}
+static inline int pm_ew_grid(long work) { return (int)std::min<long>((work + 255) / 256, 256 * 16); }
+template <typename F>
+static inline int pm_ew_launch(bool vec, long pixels, int c, hipStream_t st, const char* name, F f) {
+  if (pixels * c == 0) return PM_OK;
+  if (vec) hipLaunchKernelGGL((pm_ew_kernel<true, F>), dim3(pm_ew_grid(pixels * c / 4)), dim3(256), 0, st, pixels, c, f);
+  else hipLaunchKernelGGL((pm_ew_kernel<false, F>), dim3(pm_ew_grid(pixels * c)), dim3(256), 0, st, pixels, c, f);
+  return pm_check_launch(name);
+}
+static inline bool pm_same_shape(const pm_tensor* a, const pm_tensor* b) { return a->n == b->n && a->h == b->h && a->w == b->w && a->c == b->c; }
+static inline bool pm_vec4(const pm_tensor* t) { return pm_vec_ok(t) && t->c % 4 == 0; }
+#define PM_LD4(ptr) (*reinterpret_cast<const float4*>(ptr))
+#define PM_ST4(ptr, v) (*reinterpret_cast<float4*>(ptr) = (v))

@@ -1,0 +1,248 @@
+// K3/K5: max-pool 3x3 s2 p1, global average pool, bilinear resize (align_corners=True) -- NHWC fp32, HBM-bound.
+// Replaces nn.MaxPool2d(3,2,1) (/root/reference/network/Resnet.py:432), nn.AdaptiveAvgPool2d(1) (deepv3plus.py:85)
+// and mynn.Upsample (mynn.py:57-62). Backward passes are gathers (no atomics): deterministic.
+#include "pm_common.h"
+
+namespace {
+
+// ---------------- max pool ------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, long xp, int H, int W, float* __restrict__ y, long yp, int Ho,
+                                                          int Wo, int C, long total, uint8_t* __restrict__ arg) {
+  constexpr int V = VEC ? 4 : 1;
+  const int cg = C / V;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long op = i / cg;
+    const int ch = (int)(i - op * cg) * V;
+    const int ox = (int)(op % Wo), oy = (int)((op / Wo) % Ho), n = (int)(op / ((long)Wo * Ho));
+    float best[V];
+    uint8_t bi[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) best[v] = -INFINITY, bi[v] = 0;
+    bool first = true;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 - 1 + ky;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 - 1 + kx;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const float* p = x + ((long)(n * H + iy) * W + ix) * xp + ch;
+        float v[V];
+        if constexpr (VEC) {
+          const float4 q = PM_LD4(p);
+          v[0] = q.x;
+          if (V > 1) v[1 % V] = q.y, v[2 % V] = q.z, v[3 % V] = q.w;
+        } else {
+          v[0] = *p;
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+          if (first || v[e] > best[e] || v[e] != v[e]) best[e] = v[e], bi[e] = (uint8_t)(ky * 3 + kx);
+        first = false;
+      }
+    }
+    float* o = y + op * yp + ch;
+    uint8_t* a = arg + op * C + ch;
+#pragma unroll
+    for (int e = 0; e < V; ++e) o[e] = best[e], a[e] = bi[e];
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, long dp, int Ho, int Wo, const uint8_t* __restrict__ arg,
+                                                          float* __restrict__ dx, long xp, int H, int W, int C, long total) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long ip = i / C;
+    const int ch = (int)(i - ip * C);
+    const int ix = (int)(ip % W), iy = (int)((ip / W) % H), n = (int)(ip / ((long)W * H));
+    float g = 0.f;
+    const int oy_hi = min((iy + 1) >> 1, Ho - 1), ox_hi = min((ix + 1) >> 1, Wo - 1);
+    for (int oy = max(iy >> 1, 0); oy <= oy_hi; ++oy) {
+      const int ky = iy + 1 - 2 * oy;
+      if (ky < 0 || ky > 2) continue;
+      for (int ox = max(ix >> 1, 0); ox <= ox_hi; ++ox) {
+        const int kx = ix + 1 - 2 * ox;
+        if (kx < 0 || kx > 2) continue;
+        const long op = (long)(n * Ho + oy) * Wo + ox;
+        if (arg[op * C + ch] == (uint8_t)(ky * 3 + kx)) g += dy[op * dp + ch];
+      }
+    }
+    dx[ip * xp + ch] = g;
+  }
+}
+
+// ---------------- global average pool ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ x, long xp, long HW, int C, float* __restrict__ y, long yp) {
+  __shared__ float sm[16][64];
+  const int g = threadIdx.x & 15, r = threadIdx.x >> 4;
+  const int c = blockIdx.y * 64 + g * 4, n = blockIdx.x;
+  float s[4] = {0, 0, 0, 0};
+  if (c < C)
+    for (long p = r; p < HW; p += 16) {
+      const float4 v = PM_LD4(x + ((long)n * HW + p) * xp + c);
+      s[0] += v.x, s[1] += v.y, s[2] += v.z, s[3] += v.w;
+    }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sm[r][g * 4 + j] = s[j];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += sm[i][threadIdx.x];
+    const int ch = blockIdx.y * 64 + threadIdx.x;
+    if (ch < C) y[(long)n * yp + ch] = t / (float)HW;
+  }
+}
+
+// ---------------- bilinear, align_corners=True -------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void resize_fwd_kernel(const float* __restrict__ x, long xp, int h, int w, float* __restrict__ y, long yp, int H, int W,
+                                                         int C, long total, float sy, float sx) {
+  constexpr int V = VEC ? 4 : 1;
+  const int cg = C / V;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long op = i / cg;
+    const int ch = (int)(i - op * cg) * V;
+    const int X = (int)(op % W), Y = (int)((op / W) % H), n = (int)(op / ((long)W * H));
+    const pm_lerp ly = pm_ac_lerp(sy, Y, h), lx = pm_ac_lerp(sx, X, w);
+    const float* r0 = x + ((long)(n * h + ly.i0) * w) * xp + ch;
+    const float* r1 = x + ((long)(n * h + ly.i1) * w) * xp + ch;
+    if constexpr (VEC) {
+      const float4 a = PM_LD4(r0 + lx.i0 * xp), b = PM_LD4(r0 + lx.i1 * xp), c = PM_LD4(r1 + lx.i0 * xp), d = PM_LD4(r1 + lx.i1 * xp);
+      float4 o;
+      o.x = ly.w0 * (lx.w0 * a.x + lx.w1 * b.x) + ly.w1 * (lx.w0 * c.x + lx.w1 * d.x);
+      o.y = ly.w0 * (lx.w0 * a.y + lx.w1 * b.y) + ly.w1 * (lx.w0 * c.y + lx.w1 * d.y);
+      o.z = ly.w0 * (lx.w0 * a.z + lx.w1 * b.z) + ly.w1 * (lx.w0 * c.z + lx.w1 * d.z);
+      o.w = ly.w0 * (lx.w0 * a.w + lx.w1 * b.w) + ly.w1 * (lx.w0 * c.w + lx.w1 * d.w);
+      PM_ST4(y + op * yp + ch, o);
+    } else {
+      y[op * yp + ch] = ly.w0 * (lx.w0 * r0[lx.i0 * xp] + lx.w1 * r0[lx.i1 * xp]) + ly.w1 * (lx.w0 * r1[lx.i0 * xp] + lx.w1 * r1[lx.i1 * xp]);
+    }
+  }
+}
+
+// Output rows whose taps may touch input row `i`: conservative [lo, hi] from the inverse map, each verified exactly.
+__device__ __forceinline__ void support(float scale, int i, int out, int& lo, int& hi) {
+  if (scale <= 0.f) {
+    lo = 0, hi = out - 1;
+    return;
+  }
+  const float inv = 1.f / scale;
+  lo = max(0, (int)floorf(((float)i - 1.f) * inv) - 1);
+  hi = min(out - 1, (int)ceilf(((float)i + 1.f) * inv) + 1);
+}
+__device__ __forceinline__ float tap_weight(const pm_lerp& l, int i) { return (l.i0 == i ? l.w0 : 0.f) + (l.i1 == i ? l.w1 : 0.f); }
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict__ dy, long dp, int H, int W, float* __restrict__ dx, long xp, int h, int w,
+                                                         int C, long total, float sy, float sx, int accumulate) {
+  constexpr int V = VEC ? 4 : 1;
+  const int cg = C / V;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long ip = i / cg;
+    const int ch = (int)(i - ip * cg) * V;
+    const int x = (int)(ip % w), y = (int)((ip / w) % h), n = (int)(ip / ((long)w * h));
+    int ylo, yhi, xlo, xhi;
+    support(sy, y, H, ylo, yhi);
+    support(sx, x, W, xlo, xhi);
+    float g[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) g[e] = 0.f;
+    for (int Y = ylo; Y <= yhi; ++Y) {
+      const float wy = tap_weight(pm_ac_lerp(sy, Y, h), y);
+      if (wy == 0.f) continue;
+      for (int X = xlo; X <= xhi; ++X) {
+        const float wx = tap_weight(pm_ac_lerp(sx, X, w), x);
+        if (wx == 0.f) continue;
+        const float* p = dy + ((long)(n * H + Y) * W + X) * dp + ch;
+        const float ww = wy * wx;
+        if constexpr (VEC) {
+          const float4 q = PM_LD4(p);
+          g[0] += ww * q.x;
+          if (V > 1) g[1 % V] += ww * q.y, g[2 % V] += ww * q.z, g[3 % V] += ww * q.w;
+        } else {
+          g[0] += ww * *p;
+        }
+      }
+    }
+    float* o = dx + ip * xp + ch;
+#pragma unroll
+    for (int e = 0; e < V; ++e) o[e] = accumulate ? o[e] + g[e] : g[e];
+  }
+}
+
+inline int grid_for(long work) { return (int)std::min<long>((work + 255) / 256, 256 * 32); }
+
+}  // namespace
+
+extern "C" int pm_maxpool3x3s2_fwd(const pm_tensor* x, const pm_tensor* y, uint8_t* argmax, void* stream) {
+  PM_REQUIRE(x && y && argmax && x->ptr && y->ptr, PM_EINVAL, "maxpool_fwd: null");
+  PM_REQUIRE(y->h == (x->h + 2 - 3) / 2 + 1 && y->w == (x->w + 2 - 3) / 2 + 1 && x->n == y->n && x->c == y->c, PM_EINVAL, "maxpool_fwd: shape mismatch");
+  const bool v = pm_vec4(x) && pm_vec4(y);
+  const long total = pm_pixels(y) * (v ? y->c / 4 : y->c);
+  if (v)
+    hipLaunchKernelGGL(maxpool_fwd_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr, (long)x->pitch, x->h, x->w,
+                       (float*)y->ptr, (long)y->pitch, y->h, y->w, y->c, total, argmax);
+  else
+    hipLaunchKernelGGL(maxpool_fwd_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr, (long)x->pitch, x->h, x->w,
+                       (float*)y->ptr, (long)y->pitch, y->h, y->w, y->c, total, argmax);
+  return pm_check_launch("maxpool_fwd");
+}
+
+extern "C" int pm_maxpool3x3s2_bwd(const pm_tensor* dy, const uint8_t* argmax, const pm_tensor* dx, void* stream) {
+  PM_REQUIRE(dy && dx && argmax && dy->ptr && dx->ptr && dy->n == dx->n && dy->c == dx->c, PM_EINVAL, "maxpool_bwd: bad args");
+  const long total = pm_pixels(dx) * dx->c;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)dy->ptr, (long)dy->pitch, dy->h, dy->w, argmax,
+                     (float*)dx->ptr, (long)dx->pitch, dx->h, dx->w, dx->c, total);
+  return pm_check_launch("maxpool_bwd");
+}
+
+extern "C" int pm_global_avgpool_fwd(const pm_tensor* x, const pm_tensor* y, void* stream) {
+  PM_REQUIRE(x && y && pm_vec4(x) && y->ptr && y->h == 1 && y->w == 1 && y->n == x->n && y->c == x->c, PM_EINVAL, "global_avgpool_fwd: bad args");
+  hipLaunchKernelGGL(gap_fwd_kernel, dim3(x->n, pm_cdiv(x->c, 64)), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr, (long)x->pitch,
+                     (long)x->h * x->w, x->c, (float*)y->ptr, (long)y->pitch);
+  return pm_check_launch("global_avgpool_fwd");
+}
+
+extern "C" int pm_global_avgpool_bwd(const pm_tensor* dy, const pm_tensor* dx, int accumulate, void* stream) {
+  PM_REQUIRE(dy && dx && dy->ptr && pm_vec4(dx) && dy->h == 1 && dy->w == 1 && dy->n == dx->n && dy->c == dx->c, PM_EINVAL, "global_avgpool_bwd: bad args");
+  const float* pd = (const float*)dy->ptr;
+  float* px = (float*)dx->ptr;
+  const long dp = dy->pitch, xp = dx->pitch, HW = (long)dx->h * dx->w;
+  const float inv = 1.f / (float)HW;
+  return pm_ew_launch(true, pm_pixels(dx), dx->c, (hipStream_t)stream, "global_avgpool_bwd", [=] __device__(long p, int ch) {
+    const long n = p / HW;
+    float4 o = accumulate ? PM_LD4(px + p * xp + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+    o.x += pd[n * dp + ch] * inv, o.y += pd[n * dp + ch + 1] * inv, o.z += pd[n * dp + ch + 2] * inv, o.w += pd[n * dp + ch + 3] * inv;
+    PM_ST4(px + p * xp + ch, o);
+  });
+}
+
+extern "C" int pm_resize_bilinear_fwd(const pm_tensor* x, const pm_tensor* y, void* stream) {
+  PM_REQUIRE(x && y && x->ptr && y->ptr && x->n == y->n && x->c == y->c, PM_EINVAL, "resize_fwd: bad args");
+  const bool v = pm_vec4(x) && pm_vec4(y);
+  const long total = pm_pixels(y) * (v ? y->c / 4 : y->c);
+  const float sy = pm_ac_scale(x->h, y->h), sx = pm_ac_scale(x->w, y->w);
+  if (v)
+    hipLaunchKernelGGL(resize_fwd_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr, (long)x->pitch, x->h, x->w,
+                       (float*)y->ptr, (long)y->pitch, y->h, y->w, y->c, total, sy, sx);
+  else
+    hipLaunchKernelGGL(resize_fwd_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr, (long)x->pitch, x->h, x->w,
+                       (float*)y->ptr, (long)y->pitch, y->h, y->w, y->c, total, sy, sx);
+  return pm_check_launch("resize_fwd");
+}
+
+extern "C" int pm_resize_bilinear_bwd(const pm_tensor* dy, const pm_tensor* dx, int accumulate, void* stream) {
+  PM_REQUIRE(dy && dx && dy->ptr && dx->ptr && dy->n == dx->n && dy->c == dx->c, PM_EINVAL, "resize_bwd: bad args");
+  const bool v = pm_vec4(dy) && pm_vec4(dx);
+  const long total = pm_pixels(dx) * (v ? dx->c / 4 : dx->c);
+  const float sy = pm_ac_scale(dx->h, dy->h), sx = pm_ac_scale(dx->w, dy->w);
+  if (v)
+    hipLaunchKernelGGL(resize_bwd_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)dy->ptr, (long)dy->pitch, dy->h, dy->w,
+                       (float*)dx->ptr, (long)dx->pitch, dx->h, dx->w, dx->c, total, sy, sx, accumulate);
+  else
+    hipLaunchKernelGGL(resize_bwd_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)dy->ptr, (long)dy->pitch, dy->h, dy->w,
+                       (float*)dx->ptr, (long)dx->pitch, dx->h, dx->w, dx->c, total, sy, sx, accumulate);
+  return pm_check_launch("resize_bwd");
+}

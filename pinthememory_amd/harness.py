@@ -1,0 +1,145 @@
+"""Callers either side of the hot path, on the GPU: the aggregation train step, memory initialisation, sliding-window
+evaluation and mIoU -- the build's counterparts of /root/reference/train.py:284-374 (+ calculate_loss :213-244),
+train.py:1000-1042, eval.py:148-274,340-405 and utils/misc.py:65-73."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import dist as D
+from .hip import kernels as K
+from .hip import ops
+
+LOSS_W = dict(aux=0.4, read=0.02, div=0.4, cls=0.2)    # train.py:1213-1215 defaults
+
+
+def make_optimizer(net, lr=0.01, momentum=0.9, poly_exp=9):
+    """optimizer.py:11-32: SGD over all named parameters, weight decay hard-coded 5e-4, lr * exp(-poly_exp*it/120000)."""
+    opt = torch.optim.SGD([p for _, p in net.named_parameters()], lr=lr, weight_decay=5e-4, momentum=momentum, nesterov=False)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda it: math.exp(-1 * poly_exp * it / 120000))
+    return opt, sched
+
+
+def total_loss(outputs, w=LOSS_W):
+    main, aux, readloss, writeloss = outputs[0], outputs[1], outputs[-2], outputs[-3]
+    return main + w['aux'] * aux + w['read'] * readloss + w['div'] * writeloss[0] + w['cls'] * writeloss[1]
+
+
+def memory_only_forward(net, x, gts):
+    """What the reference's second forward (train.py:330-335) is for: eval-mode features -> memory.write(); the decoder
+    and losses it also computes are discarded there, so skipping them leaves every result identical."""
+    m = net.module if hasattr(net, 'module') else net
+    _, _, feat = m._trunk(x)
+    feat = m.aspp(feat)
+    if hasattr(m, 'bot_aspp'):
+        from .network.deepv3plus import run_cbr
+        feat = run_cbr(m.bot_aspp, feat)
+    m.memory._mem(feat)
+    m.memory.m_items = m.memory.m_items.detach()
+    m.memory.write(feat, gts, True)
+
+
+def agg_train_step(net, opt, x, gts, aux_gts=None, sched=None, buckets=None, truncate_second_forward=False):
+    """One iteration of train_memory_agg. `buckets` (dist.GradBuckets) replaces DDP's reducer for N > 1."""
+    aux_gts = gts if aux_gts is None else aux_gts
+    m = net.module if hasattr(net, 'module') else net
+    net.train()
+    mem_t = m.memory.m_items.clone().detach()
+    if buckets is not None:
+        buckets.zero()
+    else:
+        opt.zero_grad()
+    outputs = net(x, gts=gts, aux_gts=aux_gts, memory_writing=True, writing_detach=False)
+    loss = total_loss(outputs)
+    loss.backward()
+    if buckets is not None:
+        buckets.finish()
+    opt.step()
+    with torch.no_grad():
+        net.eval()
+        m.memory.m_items = mem_t
+        if truncate_second_forward:
+            memory_only_forward(net, x, gts)
+        else:
+            net(x, gts=gts, aux_gts=aux_gts, memory_writing=True)
+        net.train()
+    if sched is not None:
+        sched.step()
+    return dict(loss1=outputs[0].detach(), loss2=outputs[1].detach(), readloss=outputs[-2].detach(), div=outputs[-3][0].detach(),
+                cls=outputs[-3][1].detach(), total=loss.detach())
+
+
+def memory_initialize(net, batches, epochs=2):
+    """Class-prototype initialisation: sum of normalised bot_aspp features per soft class / count (no writenet).
+    The reference builds a one-hot + F.interpolate per batch (train.py:1020-1030); here it is the write kernel's
+    4-tap gather with normalize=1, summed across batches (and ranks) before the division."""
+    m = net.module if hasattr(net, 'module') else net
+    mem = m.memory
+    net.eval()
+    acc = None
+    with torch.no_grad():
+        for _ in range(epochs):
+            for x, gt in batches:
+                feat = net(x, gts=gt, aux_gts=gt)[-1]
+                nomden = K.mem_write_accum(ops.nhwc(feat), gt.contiguous(), mem.memory_size, normalize=True)
+                acc = nomden if acc is None else acc + nomden
+        acc = D.all_reduce_sum(acc)
+        s, d = mem.memory_size, mem.feature_dim
+        basket = acc[:(s + 1) * d].view(s + 1, d)[:s]
+        count = acc[(s + 1) * d:][:s].clone().unsqueeze(1)
+        count[count == 0] = 1
+        mem.m_items = F.normalize(basket / count, dim=1)
+    net.train()
+    return mem.m_items
+
+
+def sliding_tiles(h, w, crop, overlap=1.0 / 3, scale=1.0):
+    """eval.py:158-182: [(x1,y1,x2,y2)] in the reference's order."""
+    tile = int(crop * max(scale, 1.0))
+    stride = math.ceil(tile * (1 - overlap))
+    rows = int(math.ceil((w - tile) / stride) + 1)
+    cols = int(math.ceil((h - tile) / stride) + 1)
+    out = []
+    for r in range(rows):
+        for c in range(cols):
+            x2, y2 = min(int(r * stride) + tile, w), min(int(c * stride) + tile, h)
+            out.append((max(int(x2 - tile), 0), max(int(y2 - tile), 0), x2, y2))
+    return out
+
+
+def sliding_logits(net, img, crop, overlap=1.0 / 3, flips=(False, True), batch_tiles=True):
+    """Single-scale sliding-window logits for one CHW image, stitched on the GPU in float64 (the reference stitches
+    per class in numpy threads, eval.py:210-274). Logits (not probabilities) are averaged (eval.py:380-392); the count
+    divides by the true per-pixel tile count (the reference's count array is mis-indexed but class-uniform)."""
+    c, h, w = img.shape
+    tiles = sliding_tiles(h, w, crop, overlap)
+    net.eval()
+    acc = None
+    with torch.no_grad():
+        for flip in flips:
+            src = torch.flip(img, dims=[2]) if flip else img
+            crops = torch.stack([src[:, y1:y2, x1:x2] for (x1, y1, x2, y2) in tiles])
+            outs = net(crops)[0] if batch_tiles else torch.cat([net(cr[None])[0] for cr in crops])   # eval.py:379-390 (--faster batches)
+            full = torch.zeros(outs.shape[1], h, w, dtype=torch.float64, device=img.device)
+            cnt = torch.zeros(1, h, w, dtype=torch.float64, device=img.device)
+            for i, (x1, y1, x2, y2) in enumerate(tiles):
+                full[:, y1:y2, x1:x2] += outs[i].double()
+                cnt[:, y1:y2, x1:x2] += 1
+            full = full / cnt
+            if flip:
+                full = torch.flip(full, dims=[2])
+            acc = full if acc is None else acc + full
+    return acc / len(flips)
+
+
+def fast_hist(pred, gt, n=19):
+    """utils/misc.py:65-70 as one device bincount."""
+    pred, gt = pred.reshape(-1), gt.reshape(-1)
+    k = (gt >= 0) & (gt < n)
+    return torch.bincount(n * gt[k].long() + pred[k].long(), minlength=n * n).view(n, n)
+
+
+def miou(hist):
+    hist = hist.double()
+    iu = torch.diag(hist) / (hist.sum(1) + hist.sum(0) - torch.diag(hist))
+    return float(torch.nanmean(iu)), iu

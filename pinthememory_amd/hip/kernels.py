@@ -1,0 +1,320 @@
+"""Raw (non-autograd) launches of the HIP kernels on torch-owned NHWC fp32 tensors.
+Every function enqueues on torch's current stream and returns torch tensors; no CPU fallback exists."""
+from ctypes import byref
+
+import torch
+
+from . import lib as L
+from .lib import PmConvEpilogue, PmConvParams, check, ptr, stream, tdesc, workspace
+
+
+def _lib():
+    return L.load()
+
+
+def new(shape, like, pitch_pad=False):
+    """Fresh NHWC tensor. Channel counts that are not a multiple of 4 (the 19 logits) get a padded pitch so rows stay 16B aligned."""
+    n, h, w, c = shape
+    if c % 4 and pitch_pad:
+        cp = (c + 3) // 4 * 4
+        return torch.zeros((n, h, w, cp), dtype=torch.float32, device=like.device)[..., :c]
+    return torch.empty((n, h, w, c), dtype=torch.float32, device=like.device)
+
+
+def conv_out_hw(h, w, k, stride, pad, dil):
+    return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1, (w + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def krsc(w):
+    """[Cout,Cin,kh,kw] parameter -> contiguous KRSC memory (a free view when the parameter is channels_last)."""
+    v = w.permute(0, 2, 3, 1)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, residual=None, relu=False, out=None):
+    cout, kh, kw, cin = w_krsc.shape
+    n, h, w_, c = x.shape
+    assert c == cin, 'conv: Cin mismatch %d vs %d' % (c, cin)
+    ho, wo = conv_out_hw(h, w_, kh, stride, pad, dil)
+    y = out if out is not None else new((n, ho, wo, cout), x, pitch_pad=True)
+    xd, yd = tdesc(x), tdesc(y)
+    p = PmConvParams(kh, kw, stride, pad, dil)
+    lib = _lib()
+    nb = lib.pm_conv_workspace(byref(xd), byref(yd), byref(p), 0)
+    ws = workspace(nb, x.device) if nb else None
+    ep = None
+    if bias is not None or scale is not None or residual is not None or relu:
+        rd = tdesc(residual) if residual is not None else None
+        ep = PmConvEpilogue(ptr(bias), ptr(scale), ptr(shift), rd.ptr if rd else None, rd.pitch if rd else 0, 1 if relu else 0)
+    check(lib.pm_conv_fwd(byref(xd), w_krsc.data_ptr(), byref(yd), byref(p), byref(ep) if ep else None, ptr(ws), nb, stream()), 'pm_conv_fwd')
+    return y
+
+
+def conv_bwd_data(dy, w_krsc, x_shape, stride, pad, dil, add=None):
+    cout, kh, kw, cin = w_krsc.shape
+    dx = new(x_shape, dy)
+    dyd, dxd = tdesc(dy), tdesc(dx)
+    p = PmConvParams(kh, kw, stride, pad, dil)
+    lib = _lib()
+    nb = lib.pm_conv_workspace(byref(dxd), byref(dyd), byref(p), 1)
+    ws = workspace(nb, dy.device) if nb else None
+    ad = tdesc(add) if add is not None else None
+    check(lib.pm_conv_bwd_data(byref(dyd), w_krsc.data_ptr(), byref(dxd), byref(p), byref(ad) if ad else None, ptr(ws), nb, stream()), 'pm_conv_bwd_data')
+    return dx
+
+
+def conv_bwd_weight(x, dy, w_shape_krsc, stride, pad, dil, want_bias=False):
+    cout, kh, kw, cin = w_shape_krsc
+    dw = torch.empty(w_shape_krsc, dtype=torch.float32, device=x.device)
+    db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_bias else None
+    xd, dyd = tdesc(x), tdesc(dy)
+    p = PmConvParams(kh, kw, stride, pad, dil)
+    lib = _lib()
+    nb = lib.pm_conv_workspace(byref(xd), byref(dyd), byref(p), 2)
+    ws = workspace(nb, x.device)
+    check(lib.pm_conv_bwd_weight(byref(xd), byref(dyd), dw.data_ptr(), ptr(db), byref(p), ptr(ws), nb, stream()), 'pm_conv_bwd_weight')
+    return dw, db
+
+
+# ---- batch norm --------------------------------------------------------------------------------------------------
+def bn_stats(x):
+    """-> moments float[3C] = mean | M2 | count (local to this rank)."""
+    c = x.shape[3]
+    mom = torch.empty(3 * c, dtype=torch.float32, device=x.device)
+    xd = tdesc(x)
+    lib = _lib()
+    nb = lib.pm_bn_workspace(byref(xd))
+    ws = workspace(nb, x.device)
+    check(lib.pm_bn_stats(byref(xd), mom.data_ptr(), ptr(ws), nb, stream()), 'pm_bn_stats')
+    return mom
+
+
+def bn_finalize(moments, c, eps, running_mean=None, running_var=None, momentum=0.1):
+    mean = torch.empty(c, dtype=torch.float32, device=moments.device)
+    invstd = torch.empty_like(mean)
+    check(_lib().pm_bn_finalize(moments.data_ptr(), c, eps, mean.data_ptr(), invstd.data_ptr(), ptr(running_mean), ptr(running_var), momentum, stream()),
+          'pm_bn_finalize')
+    return mean, invstd
+
+
+def bn_fold(gamma, beta, running_mean, running_var, eps, conv_bias=None):
+    c = gamma.numel()
+    scale = torch.empty(c, dtype=torch.float32, device=gamma.device)
+    shift = torch.empty_like(scale)
+    check(_lib().pm_bn_fold(gamma.data_ptr(), beta.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(), ptr(conv_bias), c, eps, scale.data_ptr(),
+                            shift.data_ptr(), stream()), 'pm_bn_fold')
+    return scale, shift
+
+
+def bn_apply(x, mean, invstd, gamma, beta, residual=None, relu=False, out=None):
+    y = out if out is not None else torch.empty_like(x, memory_format=torch.contiguous_format)
+    rd = tdesc(residual) if residual is not None else None
+    check(_lib().pm_bn_apply(byref(tdesc(x)), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), byref(rd) if rd else None,
+                             1 if relu else 0, byref(tdesc(y)), stream()), 'pm_bn_apply')
+    return y
+
+
+def bn_bwd_reduce(dy, y, x, mean, invstd, relu):
+    c = x.shape[3]
+    sums = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+    xd = tdesc(x)
+    lib = _lib()
+    nb = lib.pm_bn_workspace(byref(xd))
+    ws = workspace(nb, x.device)
+    yd = tdesc(y) if relu else None
+    check(lib.pm_bn_bwd_reduce(byref(tdesc(dy)), byref(yd) if yd else None, byref(xd), mean.data_ptr(), invstd.data_ptr(), 1 if relu else 0,
+                               sums.data_ptr(), ptr(ws), nb, stream()), 'pm_bn_bwd_reduce')
+    return sums
+
+
+def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, count, relu, want_dres):
+    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    dres = torch.empty(x.shape, dtype=torch.float32, device=x.device) if want_dres else None
+    yd = tdesc(y) if relu else None
+    dr = tdesc(dres) if want_dres else None
+    check(_lib().pm_bn_bwd_apply(byref(tdesc(dy)), byref(yd) if yd else None, byref(tdesc(x)), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                                 sums.data_ptr(), float(count), 1 if relu else 0, byref(tdesc(dx)), byref(dr) if dr else None, stream()), 'pm_bn_bwd_apply')
+    return dx, dres
+
+
+def relu_bwd(dy, y):
+    dx = torch.empty(y.shape, dtype=torch.float32, device=y.device)
+    check(_lib().pm_relu_bwd(byref(tdesc(dy)), byref(tdesc(y)), byref(tdesc(dx)), stream()), 'pm_relu_bwd')
+    return dx
+
+
+def add(a, b, out=None):
+    y = out if out is not None else torch.empty(a.shape, dtype=torch.float32, device=a.device)
+    check(_lib().pm_add(byref(tdesc(a)), byref(tdesc(b)), byref(tdesc(y)), stream()), 'pm_add')
+    return y
+
+
+def copy(src, dst):
+    check(_lib().pm_copy(byref(tdesc(src)), byref(tdesc(dst)), stream()), 'pm_copy')
+    return dst
+
+
+# ---- pooling / resize / layout -------------------------------------------------------------------------------------
+def maxpool_fwd(x):
+    n, h, w, c = x.shape
+    y = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), dtype=torch.float32, device=x.device)
+    arg = torch.empty(y.shape, dtype=torch.uint8, device=x.device)
+    check(_lib().pm_maxpool3x3s2_fwd(byref(tdesc(x)), byref(tdesc(y)), arg.data_ptr(), stream()), 'pm_maxpool3x3s2_fwd')
+    return y, arg
+
+
+def maxpool_bwd(dy, arg, x_shape):
+    dx = torch.empty(x_shape, dtype=torch.float32, device=dy.device)
+    check(_lib().pm_maxpool3x3s2_bwd(byref(tdesc(dy)), arg.data_ptr(), byref(tdesc(dx)), stream()), 'pm_maxpool3x3s2_bwd')
+    return dx
+
+
+def global_avgpool_fwd(x):
+    n, h, w, c = x.shape
+    y = torch.empty((n, 1, 1, c), dtype=torch.float32, device=x.device)
+    check(_lib().pm_global_avgpool_fwd(byref(tdesc(x)), byref(tdesc(y)), stream()), 'pm_global_avgpool_fwd')
+    return y
+
+
+def global_avgpool_bwd(dy, x_shape):
+    dx = torch.empty(x_shape, dtype=torch.float32, device=dy.device)
+    check(_lib().pm_global_avgpool_bwd(byref(tdesc(dy)), byref(tdesc(dx)), 0, stream()), 'pm_global_avgpool_bwd')
+    return dx
+
+
+def resize_fwd(x, size, out=None):
+    n, h, w, c = x.shape
+    y = out if out is not None else new((n, size[0], size[1], c), x, pitch_pad=True)
+    check(_lib().pm_resize_bilinear_fwd(byref(tdesc(x)), byref(tdesc(y)), stream()), 'pm_resize_bilinear_fwd')
+    return y
+
+
+def resize_bwd(dy, x_shape):
+    dx = new(x_shape, dy, pitch_pad=True)
+    check(_lib().pm_resize_bilinear_bwd(byref(tdesc(dy)), byref(tdesc(dx)), 0, stream()), 'pm_resize_bilinear_bwd')
+    return dx
+
+
+def nchw_to_nhwc(x, c_pad=None):
+    n, c, h, w = x.shape
+    x = x.contiguous()
+    y = torch.empty((n, h, w, c_pad or c), dtype=torch.float32, device=x.device)
+    check(_lib().pm_nchw_to_nhwc(x.data_ptr(), c, byref(tdesc(y)), stream()), 'pm_nchw_to_nhwc')
+    return y
+
+
+def nhwc_to_nchw(x):
+    n, h, w, c = x.shape
+    y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    check(_lib().pm_nhwc_to_nchw(byref(tdesc(x)), y.data_ptr(), stream()), 'pm_nhwc_to_nchw')
+    return y
+
+
+def label_nearest(lab, size):
+    n, H, W = lab.shape
+    lab = lab.contiguous()
+    out = torch.empty((n, size[0], size[1]), dtype=torch.int64, device=lab.device)
+    check(_lib().pm_label_nearest(lab.data_ptr(), n, H, W, out.data_ptr(), size[0], size[1], stream()), 'pm_label_nearest')
+    return out
+
+
+# ---- fused upsample + cross entropy -----------------------------------------------------------------------------
+def upsample_ce_fwd(logits, labels, inv_temp=1.0):
+    n, H, W = labels.shape
+    out = torch.empty(2, dtype=torch.float32, device=logits.device)
+    lib = _lib()
+    nb = lib.pm_upsample_ce_workspace(n, H, W)
+    ws = workspace(nb, logits.device)
+    check(lib.pm_upsample_ce_fwd(byref(tdesc(logits)), inv_temp, labels.data_ptr(), H, W, out.data_ptr(), ptr(ws), nb, stream()), 'pm_upsample_ce_fwd')
+    return out
+
+
+def upsample_ce_bwd(logits, labels, loss_out, gscale, inv_temp=1.0):
+    n, H, W = labels.shape
+    dl = new(tuple(logits.shape), logits, pitch_pad=(logits.stride(2) != logits.shape[3]))   # same pitch as the logits
+    check(_lib().pm_upsample_ce_bwd(byref(tdesc(logits)), inv_temp, labels.data_ptr(), H, W, loss_out.data_ptr(), ptr(gscale), byref(tdesc(dl)), stream()),
+          'pm_upsample_ce_bwd')
+    return dl
+
+
+# ---- memory ---------------------------------------------------------------------------------------------------------
+def mem_read_fwd(x, mem, noise=None):
+    n, h, w, d = x.shape
+    m = mem.shape[0]
+    qr = torch.empty((n, h, w, 2 * d), dtype=torch.float32, device=x.device)
+    score = torch.empty((n * h * w, m), dtype=torch.float32, device=x.device)
+    pmem = torch.empty_like(score)
+    check(_lib().pm_mem_read_fwd(byref(tdesc(x)), mem.data_ptr(), m, ptr(noise), byref(tdesc(qr)), score.data_ptr(), pmem.data_ptr(), stream()), 'pm_mem_read_fwd')
+    return qr, score, pmem
+
+
+def mem_colsoftmax(score, noise=None):
+    rows, m = score.shape
+    out = torch.empty_like(score)
+    check(_lib().pm_mem_colsoftmax(score.data_ptr(), ptr(noise), rows, m, out.data_ptr(), None, 0, stream()), 'pm_mem_colsoftmax')
+    return out
+
+
+def mem_read_bwd(x, mem, pmem, dqr, dscore_extra=None, want_dmem=False):
+    n, h, w, d = x.shape
+    m = mem.shape[0]
+    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    dmem = torch.empty_like(mem) if want_dmem else None
+    lib = _lib()
+    nb = lib.pm_mem_read_bwd_workspace(n * h * w, m, d) if want_dmem else 0
+    ws = workspace(nb, x.device) if nb else None
+    check(lib.pm_mem_read_bwd(byref(tdesc(x)), mem.data_ptr(), m, pmem.data_ptr(), byref(tdesc(dqr)), ptr(dscore_extra), byref(tdesc(dx)), ptr(dmem),
+                              ptr(ws), nb, stream()), 'pm_mem_read_bwd')
+    return dx, dmem
+
+
+def mem_write_accum(z, labels, m, normalize=True):
+    n, H, W = labels.shape
+    d = z.shape[3]
+    nomden = torch.empty((m + 1) * (d + 1), dtype=torch.float32, device=z.device)
+    zd = tdesc(z)
+    lib = _lib()
+    nb = lib.pm_mem_write_accum_workspace(byref(zd), m)
+    ws = workspace(nb, z.device)
+    check(lib.pm_mem_write_accum(byref(zd), labels.data_ptr(), H, W, m, 1 if normalize else 0, nomden.data_ptr(), ptr(ws), nb, stream()), 'pm_mem_write_accum')
+    return nomden
+
+
+def mem_write_accum_bwd(z, labels, m, dnom, normalize=True):
+    n, H, W = labels.shape
+    dz = torch.empty(z.shape, dtype=torch.float32, device=z.device)
+    check(_lib().pm_mem_write_accum_bwd(byref(tdesc(z)), labels.data_ptr(), H, W, m, 1 if normalize else 0, dnom.data_ptr(), byref(tdesc(dz)), stream()),
+          'pm_mem_write_accum_bwd')
+    return dz
+
+
+def mem_write_update(mem, nomden, momentum, want_u=False):
+    m, d = mem.shape
+    out = torch.empty_like(mem)
+    u = torch.empty_like(mem) if want_u else None
+    check(_lib().pm_mem_write_update(mem.data_ptr(), nomden.data_ptr(), m, d, momentum, out.data_ptr(), ptr(u), stream()), 'pm_mem_write_update')
+    return out, u
+
+
+def mem_write_update_bwd(u, nomden, momentum, dout):
+    m, d = u.shape
+    dnom = torch.empty((m + 1, d), dtype=torch.float32, device=u.device)
+    check(_lib().pm_mem_write_update_bwd(u.data_ptr(), nomden.data_ptr(), m, d, momentum, dout.data_ptr(), dnom.data_ptr(), None, stream()),
+          'pm_mem_write_update_bwd')
+    return dnom
+
+
+def sgd_momentum(param, grad, buf, lr, momentum, wd, first):
+    check(_lib().pm_sgd_momentum(param.data_ptr(), grad.data_ptr(), buf.data_ptr(), param.numel(), lr, momentum, wd, 1 if first else 0, stream()), 'pm_sgd_momentum')
+
+
+def profile_enable(on):
+    check(_lib().pm_profile_enable(1 if on else 0), 'pm_profile_enable')
+
+
+def profile_read(mode=-1, bn=0, clear=False):
+    """-> (total_ms, total_flops, launches) of the conv implicit-GEMM launches recorded since the last clear."""
+    import ctypes
+    ms, fl, n = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int64(0)
+    check(_lib().pm_profile_read(mode, bn, byref(ms), byref(fl), byref(n), 1 if clear else 0), 'pm_profile_read')
+    return ms.value, fl.value, n.value

@@ -1,0 +1,134 @@
+"""ctypes binding of libpinmem_hip.so (include/pinmem_hip.h). The product path has NO CPU fallback:
+if the library cannot be loaded, or a kernel returns an error, this raises."""
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_HERE, 'libpinmem_hip.so')
+
+
+class PmTensor(ctypes.Structure):
+    _fields_ = [('ptr', c_void_p), ('n', c_int32), ('h', c_int32), ('w', c_int32), ('c', c_int32), ('pitch', c_int64)]
+
+
+class PmConvParams(ctypes.Structure):
+    _fields_ = [('kh', c_int32), ('kw', c_int32), ('stride', c_int32), ('pad', c_int32), ('dil', c_int32)]
+
+
+class PmConvEpilogue(ctypes.Structure):
+    _fields_ = [('bias', c_void_p), ('scale', c_void_p), ('shift', c_void_p), ('residual', c_void_p),
+                ('residual_pitch', c_int64), ('relu', c_int32)]
+
+
+class PinmemError(RuntimeError):
+    pass
+
+
+_T, _P, _E = POINTER(PmTensor), POINTER(PmConvParams), POINTER(PmConvEpilogue)
+_vp, _sz, _i, _f, _i64 = c_void_p, c_size_t, c_int, c_float, c_int64
+
+# name -> (restype, argtypes); every symbol declared in include/pinmem_hip.h
+SIGNATURES = {
+    'pm_last_error': (c_char_p, []),
+    'pm_version': (c_int, []),
+    'pm_conv_workspace': (_sz, [_T, _T, _P, _i]),
+    'pm_conv_fwd': (_i, [_T, _vp, _T, _P, _E, _vp, _sz, _vp]),
+    'pm_conv_bwd_data': (_i, [_T, _vp, _T, _P, _T, _vp, _sz, _vp]),
+    'pm_conv_bwd_weight': (_i, [_T, _T, _vp, _vp, _P, _vp, _sz, _vp]),
+    'pm_profile_enable': (_i, [_i]),
+    'pm_profile_read': (_i, [_i, _i, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64), _i]),
+    'pm_bn_workspace': (_sz, [_T]),
+    'pm_bn_stats': (_i, [_T, _vp, _vp, _sz, _vp]),
+    'pm_bn_finalize': (_i, [_vp, _i, _f, _vp, _vp, _vp, _vp, _f, _vp]),
+    'pm_bn_fold': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp]),
+    'pm_bn_apply': (_i, [_T, _vp, _vp, _vp, _vp, _T, _i, _T, _vp]),
+    'pm_bn_bwd_reduce': (_i, [_T, _T, _T, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    'pm_bn_bwd_apply': (_i, [_T, _T, _T, _vp, _vp, _vp, _vp, _f, _i, _T, _T, _vp]),
+    'pm_relu_bwd': (_i, [_T, _T, _T, _vp]),
+    'pm_add': (_i, [_T, _T, _T, _vp]),
+    'pm_copy': (_i, [_T, _T, _vp]),
+    'pm_scale_shift_act': (_i, [_T, _vp, _vp, _T, _i, _T, _vp]),
+    'pm_maxpool3x3s2_fwd': (_i, [_T, _T, _vp, _vp]),
+    'pm_maxpool3x3s2_bwd': (_i, [_T, _vp, _T, _vp]),
+    'pm_global_avgpool_fwd': (_i, [_T, _T, _vp]),
+    'pm_global_avgpool_bwd': (_i, [_T, _T, _i, _vp]),
+    'pm_resize_bilinear_fwd': (_i, [_T, _T, _vp]),
+    'pm_resize_bilinear_bwd': (_i, [_T, _T, _i, _vp]),
+    'pm_nchw_to_nhwc': (_i, [_vp, _i, _T, _vp]),
+    'pm_nhwc_to_nchw': (_i, [_T, _vp, _vp]),
+    'pm_label_nearest': (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp]),
+    'pm_upsample_ce_workspace': (_sz, [_i, _i, _i]),
+    'pm_upsample_ce_fwd': (_i, [_T, _f, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    'pm_upsample_ce_bwd': (_i, [_T, _f, _vp, _i, _i, _vp, _vp, _T, _vp]),
+    'pm_mem_read_fwd': (_i, [_T, _vp, _i, _vp, _T, _vp, _vp, _vp]),
+    'pm_mem_colsoftmax_workspace': (_sz, [_i64, _i]),
+    'pm_mem_colsoftmax': (_i, [_vp, _vp, _i64, _i, _vp, _vp, _sz, _vp]),
+    'pm_mem_read_bwd_workspace': (_sz, [_i64, _i, _i]),
+    'pm_mem_read_bwd': (_i, [_T, _vp, _i, _vp, _T, _vp, _T, _vp, _vp, _sz, _vp]),
+    'pm_mem_write_accum_workspace': (_sz, [_T, _i]),
+    'pm_mem_write_accum': (_i, [_T, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    'pm_mem_write_accum_bwd': (_i, [_T, _vp, _i, _i, _i, _i, _vp, _T, _vp]),
+    'pm_mem_write_update': (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
+    'pm_mem_write_update_bwd': (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    'pm_sgd_momentum': (_i, [_vp, _vp, _vp, _i64, _f, _f, _f, _i, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library (building it with hipcc when it is absent or stale) and bind every symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        from .. import build as _build
+        _build.build()
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the header and the library drift apart
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(code, what=''):
+    if code != 0:
+        raise PinmemError('%s failed (%d): %s' % (what, code, load().pm_last_error().decode()))
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def tdesc(t):
+    """pm_tensor view of a torch tensor shaped [N,H,W,C] (channels innermost; may be a channel slice of a wider buffer)."""
+    assert t.dim() == 4 and t.dtype == torch.float32 and t.is_cuda, 'expected a CUDA fp32 NHWC tensor, got %s %s' % (tuple(t.shape), t.dtype)
+    n, h, w, c = t.shape
+    sn, sh, sw, sc = t.stride()
+    # size-1 dims carry arbitrary strides in torch: take the pixel pitch from the innermost spatial dim that is > 1
+    pitch = sw if w > 1 else (sh if h > 1 else (sn if n > 1 else c))
+    assert (sc == 1 or c == 1) and pitch >= c, 'channels must be innermost: shape %s stride %s' % (tuple(t.shape), t.stride())
+    assert (h == 1 or w == 1 or sh == w * pitch) and (n == 1 or h * w == 1 or sn == h * w * pitch), \
+        'not an NHWC view: shape %s stride %s' % (tuple(t.shape), t.stride())
+    return PmTensor(t.data_ptr(), n, h, w, c, pitch)
+
+
+_ws = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer per (device, stream); kernels on one stream are ordered, so reuse is safe."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,330 @@
+"""Autograd-wrapped HIP ops. Tensors crossing these functions are LOGICAL NCHW (the reference's shapes) whose
+memory is NHWC (`t.permute(0,2,3,1)` is a dense pixel-major view): every call site keeps the reference's shape
+arithmetic (`x.size()[2:]`, `dim=1` channel slices) while every kernel sees coalesced channel vectors.
+Weights enter as Function inputs (never cached pointers) so functional re-wiring of module._parameters works."""
+import torch
+
+from . import kernels as K
+from .. import dist as D
+
+
+def nhwc(t):
+    """Logical-NCHW tensor -> NHWC view usable by the kernels (zero-copy when the memory is already channels-last,
+    one transpose kernel when a caller hands over a true NCHW-contiguous tensor)."""
+    v = t.permute(0, 2, 3, 1)
+    n, h, w, c = v.shape
+    sn, sh, sw, sc = v.stride()
+    pitch = sw if w > 1 else (sh if h > 1 else (sn if n > 1 else c))
+    ok = (sc == 1 or c == 1) and pitch >= c and (h == 1 or w == 1 or sh == w * pitch) and (n == 1 or h * w == 1 or sn == h * w * pitch)
+    if ok and v.dtype == torch.float32:
+        return v
+    if h * w == 1:
+        return v.contiguous().float()
+    return K.nchw_to_nhwc(t.float())
+
+
+def nchw(v):
+    return v.permute(0, 3, 1, 2)
+
+
+def _grad_view(g):
+    """Incoming gradient (logical NCHW, arbitrary strides) -> NHWC view with 16B-aligned rows."""
+    v = nhwc(g)
+    if v.stride(2) % 4 or v.data_ptr() % 16:
+        v = v.contiguous()
+    return v
+
+
+class BNState:
+    """What the BN part of a fused op needs besides gamma/beta: the module's buffers and mode."""
+    __slots__ = ('running_mean', 'running_var', 'eps', 'momentum', 'training', 'group')
+
+    def __init__(self, bn):
+        self.running_mean, self.running_var = bn.running_mean, bn.running_var
+        self.eps = bn.eps
+        self.momentum = 0.1 if bn.momentum is None else bn.momentum
+        self.training = bn.training or bn.running_mean is None
+        # nn.SyncBatchNorm (train.py:95 convert_sync_batchnorm) -> exchange statistics over RCCL
+        self.group = D.bn_group(bn)
+        if bn.training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+
+
+class _ConvBnAct(torch.autograd.Function):
+    """conv -> BatchNorm(train: batch statistics | eval: folded into the conv epilogue) -> (+residual) -> ReLU.
+    Replaces e.g. Resnet.py:195-216 conv/bn/relu triples and every Sequential(Conv2d, Norm2d, ReLU) of deepv3plus.py."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, gamma, beta, residual, geom, bn, relu, out):
+        stride, pad, dil = geom
+        xv, wk = nhwc(x), K.krsc(w)
+        rv = nhwc(residual) if residual is not None else None
+        ov = nhwc(out) if out is not None else None
+        ctx.geom, ctx.relu, ctx.train = geom, relu, bn.training
+        if not bn.training:
+            scale, shift = K.bn_fold(gamma, beta, bn.running_mean, bn.running_var, bn.eps, bias)
+            o = K.conv_fwd(xv, wk, stride, pad, dil, scale=scale, shift=shift, residual=rv, relu=relu, out=ov)
+            return nchw(o)
+        y = K.conv_fwd(xv, wk, stride, pad, dil, bias=bias)
+        c = y.shape[3]
+        mom = K.bn_stats(y)
+        if bn.group is not None:
+            mom = D.merge_moments(mom, c, bn.group)
+        mean, invstd = K.bn_finalize(mom, c, bn.eps, bn.running_mean, bn.running_var, bn.momentum)
+        o = K.bn_apply(y, mean, invstd, gamma, beta, residual=rv, relu=relu, out=ov)
+        ctx.group, ctx.has_bias, ctx.has_res = bn.group, bias is not None, residual is not None
+        ctx.save_for_backward(xv, wk, y, o, mean, invstd, gamma)
+        return nchw(o)
+
+    @staticmethod
+    def backward(ctx, dout):
+        if not ctx.train:
+            raise NotImplementedError('backward through eval-mode (frozen-statistics) BatchNorm is not implemented in the HIP path')
+        xv, wk, y, o, mean, invstd, gamma = ctx.saved_tensors
+        stride, pad, dil = ctx.geom
+        dv = _grad_view(dout)
+        c = y.shape[3]
+        sums = K.bn_bwd_reduce(dv, o, y, mean, invstd, ctx.relu)
+        if ctx.group is not None:
+            sums = D.all_reduce_sum(sums, ctx.group)
+        count = float(y.shape[0] * y.shape[1] * y.shape[2]) * (D.group_size(ctx.group) if ctx.group is not None else 1)
+        dy, dres = K.bn_bwd_apply(dv, o, y, mean, invstd, gamma, sums, count, ctx.relu, ctx.has_res and ctx.needs_input_grad[5])
+        dx = nchw(K.conv_bwd_data(dy, wk, tuple(xv.shape), stride, pad, dil)) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dwk, db = K.conv_bwd_weight(xv, dy, tuple(wk.shape), stride, pad, dil, want_bias=ctx.has_bias)
+            dw = dwk.permute(0, 3, 1, 2)
+        return dx, dw, db, sums[c:], sums[:c], (nchw(dres) if dres is not None else None), None, None, None, None
+
+
+class _Conv(torch.autograd.Function):
+    """Plain convolution (+bias): final2 / dsn.4 (deepv3plus.py:416-417,424)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, geom):
+        stride, pad, dil = geom
+        xv, wk = nhwc(x), K.krsc(w)
+        y = K.conv_fwd(xv, wk, stride, pad, dil, bias=bias)
+        ctx.geom, ctx.has_bias = geom, bias is not None
+        ctx.save_for_backward(xv, wk)
+        return nchw(y)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xv, wk = ctx.saved_tensors
+        stride, pad, dil = ctx.geom
+        dv = _grad_view(dout)
+        dx = nchw(K.conv_bwd_data(dv, wk, tuple(xv.shape), stride, pad, dil)) if ctx.needs_input_grad[0] else None
+        dwk, db = K.conv_bwd_weight(xv, dv, tuple(wk.shape), stride, pad, dil, want_bias=ctx.has_bias)
+        return dx, dwk.permute(0, 3, 1, 2), db, None
+
+
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        xv = nhwc(x)
+        y, arg = K.maxpool_fwd(xv)
+        ctx.shape = tuple(xv.shape)
+        ctx.save_for_backward(arg)
+        return nchw(y)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (arg,) = ctx.saved_tensors
+        return nchw(K.maxpool_bwd(_grad_view(dout), arg, ctx.shape))
+
+
+class _GlobalAvgPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        xv = nhwc(x)
+        ctx.shape = tuple(xv.shape)
+        return nchw(K.global_avgpool_fwd(xv))
+
+    @staticmethod
+    def backward(ctx, dout):
+        return nchw(K.global_avgpool_bwd(_grad_view(dout), ctx.shape))
+
+
+class _Resize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, size, out):
+        xv = nhwc(x)
+        ctx.shape = tuple(xv.shape)
+        return nchw(K.resize_fwd(xv, (int(size[0]), int(size[1])), out=nhwc(out) if out is not None else None))
+
+    @staticmethod
+    def backward(ctx, dout):
+        return nchw(K.resize_bwd(_grad_view(dout), ctx.shape)), None, None
+
+
+class _Concat(torch.autograd.Function):
+    """The branches already wrote their channel slices of `buf`; this node only ties the graph together and
+    hands each branch its slice of the incoming gradient (no copy either way)."""
+
+    @staticmethod
+    def forward(ctx, buf, *parts):
+        ctx.widths = [p.shape[1] for p in parts]
+        return buf.view_as(buf)
+
+    @staticmethod
+    def backward(ctx, dout):
+        outs, off = [], 0
+        for wd in ctx.widths:
+            outs.append(dout[:, off:off + wd])
+            off += wd
+        return (None,) + tuple(outs)
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return nchw(K.add(nhwc(a), nhwc(b)))
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+class _UpsampleCE(torch.autograd.Function):
+    """mean CE(ignore 255) of bilinearly up-sampled logits vs full-resolution labels, logits never materialised."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, inv_temp):
+        lv = nhwc(logits)
+        labels = labels.contiguous()
+        out = K.upsample_ce_fwd(lv, labels, inv_temp)
+        ctx.inv_temp = inv_temp
+        ctx.save_for_backward(lv, labels, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lv, labels, out = ctx.saved_tensors
+        return nchw(K.upsample_ce_bwd(lv, labels, out, g.reshape(1).float().contiguous(), ctx.inv_temp)), None, None
+
+
+class _MemRead(torch.autograd.Function):
+    """memory.py:317-336. Returns (qr [B,2d,h,w], score [B,h,w,m], p_mem [B,h,w,m])."""
+
+    @staticmethod
+    def forward(ctx, x, mem, noise):
+        xv = nhwc(x)
+        mem = mem.contiguous()
+        qr, score, pmem = K.mem_read_fwd(xv, mem, noise)
+        n, h, w, _ = xv.shape
+        m = mem.shape[0]
+        ctx.save_for_backward(xv, mem, pmem)
+        score, pmem = score.view(n, h, w, m), pmem.view(n, h, w, m)
+        ctx.mark_non_differentiable(pmem)
+        return nchw(qr), score, pmem
+
+    @staticmethod
+    def backward(ctx, dqr, dscore, _dp):
+        xv, mem, pmem = ctx.saved_tensors
+        n, h, w, d = xv.shape
+        dq = _grad_view(dqr) if dqr is not None else torch.zeros((n, h, w, 2 * d), dtype=torch.float32, device=xv.device)
+        ds = dscore.contiguous() if dscore is not None else None
+        dx, dmem = K.mem_read_bwd(xv, mem, pmem, dq, ds, want_dmem=ctx.needs_input_grad[1])
+        return nchw(dx), dmem, None
+
+
+class _MemWriteAccum(torch.autograd.Function):
+    """memory.py:219-231 without the one-hot: flat [nominator (m+1,d) | denominator (m+1)]."""
+
+    @staticmethod
+    def forward(ctx, z, labels, m):
+        zv = nhwc(z)
+        labels = labels.contiguous()
+        ctx.m = m
+        ctx.save_for_backward(zv, labels)
+        return K.mem_write_accum(zv, labels, m, normalize=True)
+
+    @staticmethod
+    def backward(ctx, dnomden):
+        zv, labels = ctx.saved_tensors
+        m, d = ctx.m, zv.shape[3]
+        dnom = dnomden[:(m + 1) * d].contiguous()
+        return nchw(K.mem_write_accum_bwd(zv, labels, m, dnom, normalize=True)), None, None
+
+
+class _MemWriteUpdate(torch.autograd.Function):
+    """memory.py:233-239: momentum update of the slots whose class occurs, then row-normalise."""
+
+    @staticmethod
+    def forward(ctx, mem, nomden, momentum):
+        mem = mem.contiguous()
+        out, u = K.mem_write_update(mem, nomden, momentum, want_u=True)
+        ctx.momentum = momentum
+        ctx.save_for_backward(u, nomden)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        u, nomden = ctx.saved_tensors
+        m, d = u.shape
+        dnom = K.mem_write_update_bwd(u, nomden, ctx.momentum, dout.contiguous())
+        g = torch.zeros_like(nomden)
+        g[:(m + 1) * d] = dnom.reshape(-1)
+        return None, g, None
+
+
+# ---- functional front-ends (module holders in, logical-NCHW tensors out) ---------------------------------------------
+def _geom(conv):
+    assert conv.kernel_size[0] == conv.kernel_size[1] and conv.stride[0] == conv.stride[1] and conv.groups == 1
+    assert conv.padding[0] == conv.padding[1] and conv.dilation[0] == conv.dilation[1]
+    return conv.stride[0], conv.padding[0], conv.dilation[0]
+
+
+def conv_bn_act(x, conv, bn, relu=True, residual=None, out=None):
+    return _ConvBnAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, residual, _geom(conv), BNState(bn), relu, out)
+
+
+def conv(x, conv_mod):
+    return _Conv.apply(x, conv_mod.weight, conv_mod.bias, _geom(conv_mod))
+
+
+def conv_raw(x, weight, bias, geom):
+    return _Conv.apply(x, weight, bias, geom)
+
+
+def maxpool3x3s2(x):
+    return _MaxPool.apply(x)
+
+
+def global_avgpool(x):
+    return _GlobalAvgPool.apply(x)
+
+
+def resize(x, size, out=None):
+    return _Resize.apply(x, size, out)
+
+
+def concat_buffer(like, channels, hw):
+    """Logical-NCHW [B, sum(channels), h, w] buffer (NHWC memory) for branches to write into."""
+    buf = torch.empty((like.shape[0], hw[0], hw[1], sum(channels)), dtype=torch.float32, device=like.device)
+    return nchw(buf)
+
+
+def concat(buf, parts):
+    return _Concat.apply(buf, *parts)
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+def upsample_ce(logits, labels, inv_temp=1.0):
+    return _UpsampleCE.apply(logits, labels, float(inv_temp))
+
+
+def mem_read(x, mem, noise=None):
+    return _MemRead.apply(x, mem, noise)
+
+
+def mem_write_accum(z, labels, m):
+    return _MemWriteAccum.apply(z, labels, m)
+
+
+def mem_write_update(mem, nomden, momentum):
+    return _MemWriteUpdate.apply(mem, nomden, float(momentum))

@@ -1,0 +1,122 @@
+"""Categorical memory (read / write / losses) on the HIP kernels. Same class surface, parameter names, init and
+m_items handling as /root/reference/network/memory.py (Memory_sup :94-361, Writingnet :67-87)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import dist as D
+from ..hip import kernels as K
+from ..hip import ops
+
+
+def initialize_weights(*models):                      # memory.py:9-19
+    for model in models:
+        for m in model.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight.data, nonlinearity='relu')
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.fill_(1.)
+                m.bias.data.fill_(1e-4)
+            elif isinstance(m, nn.Linear):
+                m.weight.data.normal_(0.0, 0.0001)
+                m.bias.data.zero_()
+
+
+class Writingnet(nn.Module):
+    def __init__(self, input_feature_dim, feature_dim):
+        super().__init__()
+        assert input_feature_dim == feature_dim, "Should match when residual mode is on ({} != {})".format(input_feature_dim, feature_dim)
+        self.writefeat = nn.Sequential(nn.Conv2d(input_feature_dim, feature_dim, kernel_size=1, stride=1, bias=False),
+                                       nn.BatchNorm2d(feature_dim))
+        self.relu = nn.ReLU(inplace=True)
+        initialize_weights(self)
+
+    def forward(self, x):                             # relu(x + BN(conv1x1(x))), memory.py:83-87
+        return ops.conv_bn_act(x, self.writefeat[0], self.writefeat[1], relu=True, residual=x)
+
+
+class Memory_sup(nn.Module):
+    def __init__(self, memory_size, input_feature_dim, feature_dim, momentum, temperature, gumbel_read):
+        super().__init__()
+        self.memory_size = memory_size
+        self.feature_dim = feature_dim
+        self.momentum = momentum
+        self.initial_momentum = momentum
+        self.temperature = temperature
+        self.output = nn.Sequential(nn.Conv2d(feature_dim * 2, input_feature_dim, kernel_size=1, stride=1, bias=False),
+                                    nn.BatchNorm2d(input_feature_dim), nn.ReLU(inplace=True))
+        self.writenet = Writingnet(input_feature_dim, feature_dim)
+        self.mem_cls = torch.arange(memory_size)
+        self.clsfier = nn.Linear(in_features=feature_dim, out_features=memory_size, bias=True)
+        self.celoss = nn.CrossEntropyLoss(ignore_index=255)
+        self.gumbel_read = gumbel_read
+        self.writeTF = lambda x: x.clone()
+        self.m_items = F.normalize(torch.rand((memory_size, feature_dim), dtype=torch.float), dim=1)
+        initialize_weights(self)
+        self.noise_fn = None      # parity hook: callable(rows, slots, device) -> (noise_dim0, noise_dim1)
+
+    def _apply(self, fn, *args, **kwargs):
+        # m_items / mem_cls are plain attributes in the reference (hard .cuda() at memory.py:111,120); follow the module instead
+        super()._apply(fn, *args, **kwargs)
+        self.m_items = fn(self.m_items)
+        self.mem_cls = fn(self.mem_cls)
+        return self
+
+    def _mem(self, like):
+        if self.m_items.device != like.device:
+            self.m_items = self.m_items.to(like.device)
+            self.mem_cls = self.mem_cls.to(like.device)
+        return self.m_items
+
+    def _gumbel(self, rows, device):
+        if not self.gumbel_read:
+            return None, None
+        if self.noise_fn is not None:
+            return self.noise_fn(rows, self.memory_size, device)
+        # F.gumbel_softmax (memory.py:183-184): g = -log(Exp(1)), tau = 1; two independent draws
+        g0 = -torch.empty(rows, self.memory_size, device=device).exponential_().log()
+        g1 = -torch.empty(rows, self.memory_size, device=device).exponential_().log()
+        return g0, g1
+
+    def get_score(self, query, mask, mem):            # memory.py:167-189; query NHWC, normalised by the caller
+        bs, h, w, d = query.size()
+        g0, g1 = self._gumbel(bs * h * w, query.device)
+        _, score, pmem = ops.mem_read(query.permute(0, 3, 1, 2), mem, g1)
+        readloss = ops.upsample_ce(score.permute(0, 3, 1, 2), mask, 1.0 / self.temperature) if mask is not None else 0
+        pq = K.mem_colsoftmax(score.detach().reshape(bs * h * w, -1), g0)
+        return pq, pmem.reshape(bs * h * w, -1), readloss
+
+    def read(self, query, mask, memory_writing):      # memory.py:317-336
+        b, d, h, w = query.size()
+        mem = self._mem(query)
+        if memory_writing:
+            self.m_items = mem = mem.detach()
+        g0, g1 = self._gumbel(b * h * w, query.device)
+        qr, score, pmem = ops.mem_read(query, mem, g1)
+        readloss = ops.upsample_ce(score.permute(0, 3, 1, 2), mask, 1.0 / self.temperature) if mask is not None else 0
+        pq = K.mem_colsoftmax(score.detach().reshape(b * h * w, -1), g0).view(b, h, w, self.memory_size)
+        updated_query = ops.conv_bn_act(qr, self.output[0], self.output[1], relu=True)
+        return updated_query, pq, pmem, readloss
+
+    def write(self, input, mask, writing_detach=True):  # memory.py:206-257
+        mem = self._mem(input)
+        z = self.writenet(input)
+        nomden = ops.mem_write_accum(z, mask, self.memory_size)
+        if D.SYNC_MEMORY:
+            nomden = D.all_reduce_sum_autograd(nomden)
+        updated_memory = ops.mem_write_update(mem.detach(), nomden, self.momentum)
+        writing_loss = [self.diversityloss(updated_memory), self.classification_loss(updated_memory)]
+        self.m_items = updated_memory.detach() if writing_detach else updated_memory
+        return writing_loss
+
+    def classification_loss(self, mem):               # memory.py:259-262
+        return self.celoss(self.clsfier(mem), self.mem_cls)
+
+    def diversityloss(self, mem):                     # memory.py:264-272
+        cos_sim_pos = torch.matmul(mem, torch.t(mem)).clamp_min(0)    # == cos[cos < 0] = 0 without the host sync of a mask write
+        return (torch.sum(cos_sim_pos) - torch.trace(cos_sim_pos)) / (self.memory_size * (self.memory_size - 1))
+
+    def forward(self, query, mask=None, memory_writing=True, writing_detach=True):   # memory.py:191-204
+        updated_query, softmax_score_query, softmax_score_memory, readloss = self.read(query, mask, memory_writing)
+        writeloss = self.write(query, mask, writing_detach) if memory_writing else [0, 0]
+        return updated_query, softmax_score_query, softmax_score_memory, readloss, writeloss

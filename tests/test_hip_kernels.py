@@ -1,0 +1,280 @@
+"""GPU parity of each HIP kernel (called through the C ABI via ctypes) against stock torch fp32 ops on the CPU.
+Tolerances: fp32 accumulation-order differences only -> 2e-5 relative to the tensor's scale unless noted."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def K():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from pinthememory_amd.hip import kernels
+    return kernels
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+CONV_CASES = [
+    # n, cin, h, w, cout, k, stride, pad, dil, bias
+    (2, 64, 24, 20, 64, 1, 1, 0, 1, False),
+    (2, 64, 24, 20, 256, 1, 1, 0, 1, False),
+    (1, 32, 17, 19, 48, 3, 1, 1, 1, False),
+    (2, 128, 24, 24, 128, 3, 2, 1, 1, False),
+    (2, 256, 24, 24, 512, 1, 2, 0, 1, False),
+    (1, 64, 20, 20, 64, 3, 1, 2, 2, False),
+    (1, 128, 13, 13, 32, 3, 1, 6, 6, False),
+    (1, 64, 26, 26, 40, 3, 1, 12, 12, True),
+    (2, 4, 40, 36, 64, 7, 2, 3, 1, False),
+    (2, 256, 16, 16, 19, 1, 1, 0, 1, True),
+    (1, 304, 16, 16, 256, 3, 1, 1, 1, False),
+    (3, 2048, 4, 4, 256, 1, 1, 0, 1, False),
+    (2, 512, 1, 1, 256, 1, 1, 0, 1, False),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_fwd_bwd(K, case):
+    n, cin, h, w, cout, k, s, p, d, has_bias = case
+    x = rnd(n, cin, h, w, seed=1)
+    wt = rnd(cout, cin, k, k, seed=2, scale=(2.0 / (cin * k * k)) ** 0.5)
+    b = rnd(cout, seed=3) if has_bias else None
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if has_bias else None
+    y_ref = F.conv2d(xr, wr, br, stride=s, padding=p, dilation=d)
+    dy = rnd(*y_ref.shape, seed=4)
+    y_ref.backward(dy)
+
+    xg, wg = nhwc(x), wt.permute(0, 2, 3, 1).contiguous().cuda()
+    y = K.conv_fwd(xg, wg, s, p, d, bias=b.cuda() if has_bias else None)
+    assert rel(nchw(y), y_ref.detach()) < 2e-5
+    dyg = K.new(tuple(y.shape), y, pitch_pad=True)
+    dyg.copy_(nhwc(dy))
+    dx = K.conv_bwd_data(dyg, wg, tuple(xg.shape), s, p, d)
+    assert rel(nchw(dx), xr.grad) < 2e-5
+    dw, db = K.conv_bwd_weight(xg, dyg, tuple(wg.shape), s, p, d, want_bias=has_bias)
+    assert rel(dw.permute(0, 3, 1, 2), wr.grad) < 5e-5
+    if has_bias:
+        assert rel(db, br.grad) < 2e-5
+
+
+def test_conv_epilogue_and_slices(K):
+    """eval-mode fold (scale/shift), residual, relu, and writing into a channel slice of a wider concat buffer."""
+    x, wt = rnd(2, 64, 12, 12, seed=1), rnd(32, 64, 3, 3, seed=2, scale=0.05)
+    sc, sh, res = rnd(32, seed=3).abs() + 0.5, rnd(32, seed=4), rnd(2, 32, 12, 12, seed=5)
+    ref = torch.relu(F.conv2d(x, wt, padding=1) * sc[None, :, None, None] + sh[None, :, None, None] + res)
+    buf = torch.zeros(2, 12, 12, 96, device='cuda')
+    out = K.conv_fwd(nhwc(x), wt.permute(0, 2, 3, 1).contiguous().cuda(), 1, 1, 1, scale=sc.cuda(), shift=sh.cuda(), residual=nhwc(res), relu=True,
+                     out=buf[..., 32:64])
+    assert rel(nchw(out), ref) < 2e-5
+    assert buf[..., :32].abs().max().item() == 0 and buf[..., 64:].abs().max().item() == 0
+    # dgrad fused accumulate
+    dy, add = rnd(2, 32, 12, 12, seed=6), rnd(2, 64, 12, 12, seed=7)
+    xr = x.clone().requires_grad_(True)
+    F.conv2d(xr, wt, padding=1).backward(dy)
+    dx = K.conv_bwd_data(nhwc(dy), wt.permute(0, 2, 3, 1).contiguous().cuda(), (2, 12, 12, 64), 1, 1, 1, add=nhwc(add))
+    assert rel(nchw(dx), xr.grad + add) < 2e-5
+
+
+@pytest.mark.parametrize('shape,relu,res', [((4, 64, 20, 20), True, False), ((2, 256, 9, 11), True, True), ((3, 48, 16, 16), False, False),
+                                           ((8, 256, 1, 1), True, False)])
+def test_batchnorm_train(K, shape, relu, res):
+    n, c, h, w = shape
+    x = rnd(*shape, seed=1) * 2 + 3
+    r = rnd(*shape, seed=2) if res else None
+    bn = torch.nn.BatchNorm2d(c)
+    with torch.no_grad():
+        bn.weight.copy_(rnd(c, seed=3) * 0.2 + 1), bn.bias.copy_(rnd(c, seed=4) * 0.1)
+        bn.running_mean.copy_(rnd(c, seed=5)), bn.running_var.copy_(rnd(c, seed=6).abs() + 0.5)
+    rm, rv = bn.running_mean.clone().cuda(), bn.running_var.clone().cuda()
+    xr = x.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if res else None
+    y_ref = bn(xr)
+    if res:
+        y_ref = y_ref + rr
+    if relu:
+        y_ref = torch.relu(y_ref)
+    dy = rnd(*shape, seed=7)
+    y_ref.backward(dy)
+
+    xg = nhwc(x)
+    mom = K.bn_stats(xg)
+    mean, invstd = K.bn_finalize(mom, c, bn.eps, rm, rv, 0.1)
+    assert rel(mean, x.mean((0, 2, 3))) < 1e-5
+    assert rel(rm, bn.running_mean) < 1e-5 and rel(rv, bn.running_var) < 1e-5
+    g, b = bn.weight.detach().cuda(), bn.bias.detach().cuda()
+    y = K.bn_apply(xg, mean, invstd, g, b, residual=nhwc(r) if res else None, relu=relu)
+    assert rel(nchw(y), y_ref.detach()) < 1e-5
+    dyg = nhwc(dy)
+    sums = K.bn_bwd_reduce(dyg, y, xg, mean, invstd, relu)
+    dx, dres = K.bn_bwd_apply(dyg, y, xg, mean, invstd, g, sums, n * h * w, relu, res)
+    assert rel(sums[:c], bn.bias.grad) < 2e-5 and rel(sums[c:], bn.weight.grad) < 2e-5
+    assert rel(nchw(dx), xr.grad) < 5e-5
+    if res:
+        assert rel(nchw(dres), rr.grad) < 1e-6
+
+
+def test_pool_and_resize(K):
+    x = rnd(2, 64, 21, 18, seed=1)
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.max_pool2d(torch.relu(xr), 3, 2, 1)
+    dy = rnd(*y_ref.shape, seed=2)
+    y_ref.backward(dy)
+    xg = nhwc(torch.relu(x))
+    y, arg = K.maxpool_fwd(xg)
+    assert rel(nchw(y), y_ref.detach()) == 0
+    dx = K.maxpool_bwd(nhwc(dy), arg, tuple(xg.shape))
+    dx = dx * (xg > 0)                                   # relu mask, as the full graph applies it
+    assert rel(nchw(dx), xr.grad) < 1e-6
+
+    x = rnd(3, 128, 7, 9, seed=3)
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.adaptive_avg_pool2d(xr, 1)
+    dy = rnd(3, 128, 1, 1, seed=4)
+    y_ref.backward(dy)
+    y = K.global_avgpool_fwd(nhwc(x))
+    assert rel(nchw(y), y_ref.detach()) < 1e-6
+    assert rel(nchw(K.global_avgpool_bwd(nhwc(dy), (3, 7, 9, 128))), xr.grad) < 1e-6
+
+    for (shape, size) in [((2, 64, 12, 12), (48, 48)), ((2, 19, 24, 24), (96, 96)), ((2, 256, 1, 1), (12, 12)), ((1, 32, 11, 7), (30, 41)),
+                          ((1, 8, 10, 10), (10, 10))]:
+        x = rnd(*shape, seed=5)
+        xr = x.clone().requires_grad_(True)
+        y_ref = F.interpolate(xr, size=size, mode='bilinear', align_corners=True)
+        dy = rnd(*y_ref.shape, seed=6)
+        y_ref.backward(dy)
+        xg = K.new((shape[0], shape[2], shape[3], shape[1]), torch.zeros(1, device='cuda'), pitch_pad=True)
+        xg.copy_(nhwc(x))
+        y = K.resize_fwd(xg, size)
+        assert rel(nchw(y), y_ref.detach()) < 2e-6, (shape, size)
+        dyg = K.new(tuple(y.shape), y, pitch_pad=True)
+        dyg.copy_(nhwc(dy))
+        dx = K.resize_bwd(dyg, tuple(xg.shape))
+        assert rel(nchw(dx), xr.grad) < 1e-5, (shape, size)
+
+
+def test_layout_and_labels(K):
+    x = rnd(2, 3, 37, 41, seed=1).cuda()
+    y = K.nchw_to_nhwc(x, c_pad=4)
+    assert torch.equal(y[..., :3], x.permute(0, 2, 3, 1)) and y[..., 3].abs().max().item() == 0
+    z = rnd(2, 19, 9, 13, seed=2)
+    assert torch.equal(K.nhwc_to_nchw(nhwc(z)).cpu(), z)
+    lab = torch.randint(0, 19, (2, 64, 48), generator=torch.Generator().manual_seed(3))
+    ref = F.interpolate(lab.unsqueeze(1).float(), size=(4, 3), mode='nearest').squeeze(1).long()
+    assert torch.equal(K.label_nearest(lab.cuda(), (4, 3)).cpu(), ref)
+    ref = F.interpolate(lab.unsqueeze(1).float(), size=(9, 7), mode='nearest').squeeze(1).long()
+    assert torch.equal(K.label_nearest(lab.cuda(), (9, 7)).cpu(), ref)
+
+
+@pytest.mark.parametrize('hw,HW,temp', [((12, 12), (48, 48), 1.0), ((6, 6), (96, 96), 0.5), ((16, 16), (16, 16), 1.0), ((5, 7), (33, 29), 2.0)])
+def test_upsample_ce(K, hw, HW, temp):
+    n, C = 2, 19
+    lg = rnd(n, C, *hw, seed=1) * 3
+    g = torch.Generator().manual_seed(2)
+    lab = torch.randint(0, C, (n, *HW), generator=g)
+    lab[torch.rand(n, *HW, generator=g) < 0.1] = 255
+    lab[:, :2] = 255
+    lr = lg.clone().requires_grad_(True)
+    loss_ref = F.cross_entropy(F.interpolate(lr / temp, size=HW, mode='bilinear', align_corners=True), lab, ignore_index=255)
+    (loss_ref * 1.7).backward()
+    lgg = K.new((n, hw[0], hw[1], C), torch.zeros(1, device='cuda'), pitch_pad=True)
+    lgg.copy_(nhwc(lg))
+    labg = lab.cuda()
+    out = K.upsample_ce_fwd(lgg, labg, 1.0 / temp)
+    assert abs(out[0].item() - loss_ref.item()) < 2e-6 * max(1, abs(loss_ref.item()))
+    assert out[1].item() == (lab != 255).sum().item()
+    dl = K.upsample_ce_bwd(lgg, labg, out, torch.tensor([1.7], device='cuda'), 1.0 / temp)
+    assert rel(nchw(dl), lr.grad) < 2e-5
+
+
+def test_memory_read(K):
+    n, h, w, d, m = 2, 9, 7, 256, 19
+    x = torch.relu(rnd(n, d, h, w, seed=1))
+    x[0, :, 0, 0] = 0                                     # an all-zero row exercises the eps clamp
+    mem = F.normalize(rnd(m, d, seed=2), dim=1)
+    xr = x.clone().requires_grad_(True)
+    mr = mem.clone().requires_grad_(True)
+    q = F.normalize(xr, dim=1).permute(0, 2, 3, 1).contiguous()
+    s = torch.matmul(q, mr.t()).view(-1, m)
+    pq, pm = F.softmax(s, 0), F.softmax(s, 1)
+    qr_ref = torch.cat((q.view(-1, d), torch.matmul(pm, mr)), 1)
+    dqr, dsx = rnd(n * h * w, 2 * d, seed=3), rnd(n * h * w, m, seed=4) * 0.1
+    ((qr_ref * dqr).sum() + (s * dsx).sum()).backward()
+
+    xg, memg = nhwc(x), mem.cuda()
+    qr, score, pmem = K.mem_read_fwd(xg, memg)
+    assert rel(qr.view(-1, 2 * d), qr_ref.detach()) < 2e-6
+    assert rel(score, s.detach()) < 2e-6 and rel(pmem, pm.detach()) < 2e-6
+    assert rel(K.mem_colsoftmax(score), pq.detach()) < 2e-6
+    dx, dmem = K.mem_read_bwd(xg, memg, pmem, dqr.view(n, h, w, 2 * d).cuda(), dsx.cuda(), want_dmem=True)
+    assert rel(nchw(dx)[:, :, 1:], xr.grad[:, :, 1:]) < 2e-5
+    assert rel(dmem, mr.grad) < 2e-5
+    # gumbel path with injected noise (memory.py:181-184): softmax((S + g) / 1)
+    noise = -torch.empty(n * h * w, m).exponential_(generator=torch.Generator().manual_seed(5)).log()
+    _, _, pg = K.mem_read_fwd(xg, memg, noise.cuda())
+    assert rel(pg, F.softmax(s.detach() + noise, 1)) < 2e-6
+    assert rel(K.mem_colsoftmax(score, noise.cuda()), F.softmax(s.detach() + noise, 0)) < 2e-6
+
+
+def test_memory_write(K):
+    n, h, w, d, m, H, W = 2, 6, 5, 256, 19, 48, 40
+    z = torch.relu(rnd(n, d, h, w, seed=1))
+    g = torch.Generator().manual_seed(2)
+    lab = torch.randint(0, 12, (n, H, W), generator=g)      # classes 12..18 absent -> slots keep their value
+    lab[torch.rand(n, H, W, generator=g) < 0.1] = 255
+    mem = F.normalize(rnd(m, d, seed=3), dim=1)
+    mu = 0.8
+    zr = z.clone().requires_grad_(True)
+    zh = F.normalize(zr, dim=1).view(n, d, -1)
+    t = lab.clone()
+    t[t == 255] = m
+    y = F.interpolate(F.one_hot(t, m + 1).permute(0, 3, 1, 2).float(), [h, w], mode='bilinear', align_corners=True).permute(0, 2, 3, 1).reshape(n, -1, m + 1)
+    nom, den = torch.matmul(zh, y).sum(0).t(), y.sum(1).sum(0)
+    upd = mem.clone()
+    for j in range(m):
+        if den[j] != 0:
+            upd[j] = mu * mem[j] + (1 - mu) * nom[j] / den[j]
+    new = F.normalize(upd, dim=1)
+    dout = rnd(m, d, seed=4)
+    (new * dout).sum().backward()
+
+    zg, labg = nhwc(z), lab.cuda()
+    nomden = K.mem_write_accum(zg, labg, m)
+    assert rel(nomden[:(m + 1) * d].view(m + 1, d), nom.detach()) < 2e-6
+    assert rel(nomden[(m + 1) * d:], den) < 2e-6
+    out, u = K.mem_write_update(mem.cuda(), nomden, mu, want_u=True)
+    assert rel(out, new.detach()) < 2e-6
+    assert rel(out[12:], mem[12:]) < 1e-6                 # absent classes keep their slot (memory.py:235)
+    dnom = K.mem_write_update_bwd(u, nomden, mu, dout.cuda())
+    dz = K.mem_write_accum_bwd(zg, labg, m, dnom)
+    assert rel(nchw(dz), zr.grad) < 2e-5
+
+
+def test_sgd(K):
+    p, g = rnd(1000, seed=1), rnd(1000, seed=2)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.SGD([pr], lr=0.01, momentum=0.9, weight_decay=5e-4)
+    pg, buf = p.cuda(), torch.zeros(1000, device='cuda')
+    for it in range(3):
+        pr.grad = g.clone() * (it + 1)
+        opt.step()
+        K.sgd_momentum(pg, (g * (it + 1)).cuda(), buf, 0.01, 0.9, 5e-4, it == 0)
+    assert rel(pg, pr.detach()) < 1e-6
