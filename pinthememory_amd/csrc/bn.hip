@@ -45,11 +45,25 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
   }
 }
 
-__global__ void bn_stats_final(const float* __restrict__ part, int nb, const float* __restrict__ x, long P, int C, float* __restrict__ moments) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < nb; ++b) s1 += (double)part[((long)b * C + c) * 2], s2 += (double)part[((long)b * C + c) * 2 + 1];
+// Second stage: 32 channels x 8 lanes per block; each lane sums a strided subset of the block partials in double, the 8
+// lane sums are combined in fixed order (deterministic, ~10 us instead of a 512-long serial chain per channel).
+__device__ __forceinline__ void final_sums(const float* __restrict__ part, int nb, int C, int c, int lane, double& s1, double& s2) {
+  __shared__ double red[8][32][2];
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (int i = lane; i < nb; i += 8) a += (double)part[((long)i * C + c) * 2], b += (double)part[((long)i * C + c) * 2 + 1];
+  red[lane][threadIdx.x & 31][0] = a, red[lane][threadIdx.x & 31][1] = b;
+  __syncthreads();
+  s1 = s2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s1 += red[i][threadIdx.x & 31][0], s2 += red[i][threadIdx.x & 31][1];
+}
+
+__global__ __launch_bounds__(256) void bn_stats_final(const float* __restrict__ part, int nb, const float* __restrict__ x, long P, int C, float* __restrict__ moments) {
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), lane = threadIdx.x >> 5;
+  double s1, s2;
+  final_sums(part, nb, C, c, lane, s1, s2);
+  if (lane != 0 || c >= C) return;
   const double n = (double)P;
   moments[c] = (float)((double)x[c] + s1 / n);
   moments[C + c] = (float)fmax(s2 - s1 * s1 / n, 0.0);
@@ -104,11 +118,11 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
     if (ch < C) part[((long)blockIdx.x * C + ch) * 2 + w] = s;
   }
 }
-__global__ void bn_bwd_final(const float* __restrict__ part, int nb, int C, float* __restrict__ sums) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < nb; ++b) s1 += (double)part[((long)b * C + c) * 2], s2 += (double)part[((long)b * C + c) * 2 + 1];
+__global__ __launch_bounds__(256) void bn_bwd_final(const float* __restrict__ part, int nb, int C, float* __restrict__ sums) {
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), lane = threadIdx.x >> 5;
+  double s1, s2;
+  final_sums(part, nb, C, c, lane, s1, s2);
+  if (lane != 0 || c >= C) return;
   sums[c] = (float)s1;
   sums[C + c] = (float)s2;
 }
@@ -143,7 +157,7 @@ extern "C" int pm_bn_stats(const pm_tensor* x, float* moments, void* ws, size_t 
   const int rows = chunk_rows(P), nb = pm_cdiv(P, rows);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_stats_partial, dim3(nb, pm_cdiv(x->c, CB)), dim3(256), 0, st, (const float*)x->ptr, (long)x->pitch, P, x->c, rows, (float*)ws);
-  hipLaunchKernelGGL(bn_stats_final, dim3(pm_cdiv(x->c, 64)), dim3(64), 0, st, (const float*)ws, nb, (const float*)x->ptr, P, x->c, moments);
+  hipLaunchKernelGGL(bn_stats_final, dim3(pm_cdiv(x->c, 32)), dim3(256), 0, st, (const float*)ws, nb, (const float*)x->ptr, P, x->c, moments);
   return pm_check_launch("bn_stats");
 }
 
@@ -204,7 +218,7 @@ extern "C" int pm_bn_bwd_reduce(const pm_tensor* dy, const pm_tensor* y, const p
   else
     hipLaunchKernelGGL(bn_bwd_partial<false>, grid, dim3(256), 0, st, (const float*)dy->ptr, (long)dy->pitch, (const float*)nullptr, 0l,
                        (const float*)x->ptr, (long)x->pitch, mean, invstd, P, x->c, rows, (float*)ws);
-  hipLaunchKernelGGL(bn_bwd_final, dim3(pm_cdiv(x->c, 64)), dim3(64), 0, st, (const float*)ws, nb, x->c, sums);
+  hipLaunchKernelGGL(bn_bwd_final, dim3(pm_cdiv(x->c, 32)), dim3(256), 0, st, (const float*)ws, nb, x->c, sums);
   return pm_check_launch("bn_bwd_reduce");
 }
 

@@ -423,32 +423,39 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int nb, int 
 }
 
 struct Plan {
-  int bn;        // 128 / 64 / 32
+  int bm, bn;    // block tile: bm 128 / 64, bn 128 / 64 / 32
   int tiles_m, tiles_n, ksplit, kper;
   size_t ws_bytes;
 };
 
+// Split-K choice by a small cost model (units: one K-step of one block on an MFMA-bound CU ~ 4096 cycles ~ 2 us):
+//   T(ks) = ceil(blocks / 256 CUs) * (K-steps per block + 2 for prologue/epilogue) + workspace round trip + reduce launch.
+// It fills the 256 CUs when a problem has few output tiles (wgrad: Cout x taps*Cin) without paying for partial slabs
+// when the tile count alone already does.
 Plan make_plan(int mode, long M, long Nn, long K) {
   Plan p;
   p.bn = Nn > 64 ? 128 : (Nn > 32 ? 64 : 32);
-  p.tiles_m = pm_cdiv(M, 128);
+  p.bm = (mode == MODE_WGRAD && M <= 64 && p.bn >= 64) ? 64 : 128;
+  p.tiles_m = pm_cdiv(M, p.bm);
   p.tiles_n = pm_cdiv(Nn, p.bn);
   const long tiles = (long)p.tiles_m * p.tiles_n;
   const long ksteps = (K + BK - 1) / BK;
-  int ks = 1;
-  const long target = (mode == MODE_WGRAD) ? 1024 : 768;
-  if (tiles < target) {
-    ks = (int)((target + tiles - 1) / tiles);
-    const long max_by_k = ksteps / 8 > 0 ? ksteps / 8 : 1;  // at least 8 K-steps per split
-    if (ks > max_by_k) ks = (int)max_by_k;
-    if (ks > 64) ks = 64;
-    if (ks < 1) ks = 1;
+  const double unit_us = 2.0 * (p.bm / 128.0) * (p.bn / 128.0);
+  const long ks_max = std::max<long>(1, std::min<long>(ksteps / 4, 512));
+  double best = 1e30;
+  long best_ks = 1, best_steps = ksteps;
+  for (long ks = 1; ks <= ks_max; ++ks) {
+    const long steps_per = (ksteps + ks - 1) / ks;
+    const long ks_eff = (ksteps + steps_per - 1) / steps_per;
+    if (ks_eff != ks) continue;
+    const long blocks = tiles * ks;
+    double t = (double)((blocks + 255) / 256) * (double)(steps_per + 2) * unit_us;
+    if (ks > 1) t += 2.0 * (double)ks * (double)M * (double)Nn * 4.0 / 3.0e6 + 6.0;  // bytes / (3 TB/s) in us + reduce launch
+    if (t < best) best = t, best_ks = ks, best_steps = steps_per;
   }
-  long steps_per = (ksteps + ks - 1) / ks;
-  ks = (int)((ksteps + steps_per - 1) / steps_per);
-  p.ksplit = ks;
-  p.kper = (int)(steps_per * BK);
-  p.ws_bytes = ks > 1 ? (size_t)ks * M * Nn * sizeof(float) : 0;
+  p.ksplit = (int)best_ks;
+  p.kper = (int)(best_steps * BK);
+  p.ws_bytes = p.ksplit > 1 ? (size_t)p.ksplit * M * Nn * sizeof(float) : 0;
   return p;
 }
 
@@ -488,7 +495,12 @@ int launch(const ConvK& k0, const Plan& p, hipStream_t st) {
   }
   constexpr bool akc = MODE != MODE_WGRAD, bkc = MODE == MODE_FWD;
   auto smem = [&](int bm, int bn) { return (size_t)2 * ((akc ? bm * LDK : BK * bm) + (bkc ? bn * LDK : BK * bn)) * sizeof(float); };
-  if (p.bn == 128) {
+  if (p.bm == 64) {
+    if constexpr (MODE == MODE_WGRAD) {
+      if (p.bn == 128) launch_one<MODE, 64, 128, 2, 2>(k, grid, smem(64, 128), st);
+      else launch_one<MODE, 64, 64, 2, 2>(k, grid, smem(64, 64), st);
+    }
+  } else if (p.bn == 128) {
     launch_one<MODE, 128, 128, 2, 2>(k, grid, smem(128, 128), st);
   } else if (p.bn == 64) {
     launch_one<MODE, 128, 64, 2, 2>(k, grid, smem(128, 64), st);
