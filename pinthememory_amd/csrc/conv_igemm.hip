@@ -36,6 +36,8 @@ struct ConvK {
   long c_pitch;           // row pitch of C
   long c_split;           // floats between split-K slabs (ksplit > 1 -> C is the workspace)
   int tiles_m, tiles_n;
+  unsigned a_bytes, b_bytes;  // extents of the A / B buffers (buffer-descriptor range)
+  int smallc;                 // 1: a per-K-step counter may wrap more than once (needs the looping variant)
   const float* bias;
   const float* scale;
   const float* shift;
@@ -44,15 +46,14 @@ struct ConvK {
   int relu;
 };
 
-__device__ __forceinline__ float4 ld4(const float* p, bool ok) {
-  return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
-}
-// keep the first `nv` (1..4) lanes of a float4
-__device__ __forceinline__ float4 mask4(float4 v, int nv) {
-  if (nv < 4) v.w = 0.f;
-  if (nv < 3) v.z = 0.f;
-  if (nv < 2) v.y = 0.f;
-  return v;
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr int OOB = 0x7fffffff;  // any byte offset beyond num_records makes a raw buffer load return zeros
+
+// 16-byte load through a buffer descriptor: out-of-range lanes read 0 without a branch (padding taps, tile edges),
+// and the address is a 32-bit byte offset (half the VALU work of 64-bit pointer arithmetic).
+__device__ __forceinline__ float4 bload(__amdgpu_buffer_rsrc_t r, int off) {
+  const v4f v = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+  return make_float4(v.x, v.y, v.z, v.w);
 }
 
 // XCD-aware bijective remap: consecutive logical ids (which share the A row-panel) land on one XCD's L2.
@@ -62,7 +63,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
-template <int MODE, int BM, int BN, int WM, int WN>
+// SMALLC: the per-K-step wrap of the running (channel | pixel-column) counter may happen more than once
+// (Cin or Cout < BK, or Wo < BK in wgrad) -> loop instead of a single compare/select.
+template <int MODE, int BM, int BN, int WM, int WN, bool SMALLC>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   constexpr bool A_KC = (MODE != MODE_WGRAD);  // A tile stored [BM][LDK] (k contiguous) else [BK][BM]
   constexpr bool B_KC = (MODE == MODE_FWD);    // B tile stored [BN][LDK] else [BK][BN]
@@ -91,17 +94,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   const int k_begin = z * a.kper;
   const int k_end = min(a.K, k_begin + a.kper);
   const int nk = (k_end - k_begin + BK - 1) / BK;
-
   const int T = a.kh * a.kw;
 
-  // ------------------------------------------------------------------------------------------------------------
-  // per-thread gather state
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, (int)a.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.B), 0, (int)a.b_bytes, 0x00020000);
+  const int xp4 = (int)a.x_pitch * 4, yp4 = (int)a.y_pitch * 4;
+
+  // ---- per-thread gather state ----------------------------------------------------------------------------------
   // KC tiles: thread -> (k-group g = t&7 of 4 floats, rows t>>3 + 32*i);  MC tiles: thread -> (col group, k rows)
-  // ------------------------------------------------------------------------------------------------------------
-  // ---- A ----
-  int a_pix[A_ROWS], a_y0[A_ROWS], a_x0[A_ROWS];  // FWD/DGRAD: image pixel base + window origin per row
-  int a_ch = 0, a_tap = 0, a_ky = 0, a_kx = 0;    // FWD/DGRAD: running (tap, channel) of this thread's k-group
-  int a_col = 0, a_nv = 0;                        // WGRAD: channel column of dy, valid lanes
+  int a_base[A_ROWS], a_y0[A_ROWS], a_x0[A_ROWS];  // FWD/DGRAD: byte offset of the row's window origin, window origin
+  int a_ch = 0, a_tap = 0, a_ky = 0, a_kx = 0;     // FWD/DGRAD: running (tap, channel) of this thread's k-group
+  int a_col4 = OOB;                                // WGRAD: byte offset of this thread's dy channel group (OOB if beyond Cout)
   if constexpr (MODE == MODE_FWD || MODE == MODE_DGRAD) {
     const int rh = (MODE == MODE_FWD) ? a.Ho : a.H, rw = (MODE == MODE_FWD) ? a.Wo : a.W;
 #pragma unroll
@@ -111,16 +114,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
         const int img = m / (rh * rw), rem = m - img * (rh * rw);
         const int py = rem / rw, px = rem - py * rw;
         if constexpr (MODE == MODE_FWD) {
-          a_pix[i] = img * a.H * a.W;
           a_y0[i] = py * a.stride - a.pad;
           a_x0[i] = px * a.stride - a.pad;
+          a_base[i] = (img * a.H * a.W + a_y0[i] * a.W + a_x0[i]) * xp4;
         } else {
-          a_pix[i] = img * a.Ho * a.Wo;
           a_y0[i] = py + a.pad;
           a_x0[i] = px + a.pad;
+          a_base[i] = img * a.Ho * a.Wo;           // pixel index; the (oy, ox) part is added per tap
         }
       } else {
-        a_pix[i] = 0;
+        a_base[i] = 0;
         a_y0[i] = -(1 << 28);
         a_x0[i] = -(1 << 28);
       }
@@ -132,19 +135,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
     a_ky = a_tap / a.kw;
     a_kx = a_tap - a_ky * a.kw;
   } else {
-    a_col = m0 + (t % (BM / 4)) * 4;
-    a_nv = min(4, a.Cout - a_col);
+    const int col = m0 + (t % (BM / 4)) * 4;
+    a_col4 = col < a.Cout ? col * 4 : OOB;
   }
-  // ---- B ----
-  int b_row[B_ROWS];                              // FWD: weight row (cout) ; DGRAD: running co ; WGRAD: running ox
-  int b_aux[B_ROWS], b_aux2[B_ROWS];              // DGRAD: running tap ; WGRAD: running oy, img
-  int b_col = 0, b_nv = 0, b_ky = 0, b_kx = 0, b_ci = 0;
+  int b_row[B_ROWS];               // FWD: byte offset of the weight row (OOB if beyond Cout); DGRAD: running co; WGRAD: running ox
+  int b_aux[B_ROWS], b_aux2[B_ROWS];  // DGRAD: running tap ; WGRAD: running oy, img
+  int b_col4 = OOB, b_ky = 0, b_kx = 0;
   if constexpr (MODE == MODE_FWD) {
 #pragma unroll
-    for (int i = 0; i < B_ROWS; ++i) b_row[i] = n0 + (t >> 3) + 32 * i;
+    for (int i = 0; i < B_ROWS; ++i) {
+      const int r = n0 + (t >> 3) + 32 * i;
+      b_row[i] = r < a.Cout ? r * a.K * 4 : OOB;
+    }
   } else if constexpr (MODE == MODE_DGRAD) {
-    b_col = n0 + (t % (BN / 4)) * 4;
-    b_nv = min(4, a.Cin - b_col);
+    const int col = n0 + (t % (BN / 4)) * 4;
+    b_col4 = col < a.Cin ? col * 4 : OOB;
 #pragma unroll
     for (int i = 0; i < B_ROWS; ++i) {
       const int k = k_begin + t / (BN / 4) + B_RSTEP * i;
@@ -153,12 +158,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
     }
   } else {
     const int n = n0 + (t % (BN / 4)) * 4;
-    b_nv = n < a.Nn ? 4 : 0;
-    const int tap = b_nv ? n / a.Cin : 0;
-    b_ci = n - tap * a.Cin;
+    const int tap = n < a.Nn ? n / a.Cin : 0;
+    b_col4 = n < a.Nn ? (n - tap * a.Cin) * 4 : OOB;
     b_ky = tap / a.kw;
     b_kx = tap - b_ky * a.kw;
-    b_nv = b_nv ? min(4, a.Cin - b_ci) : 0;
 #pragma unroll
     for (int i = 0; i < B_ROWS; ++i) {
       const int p = k_begin + t / (BN / 4) + B_RSTEP * i;
@@ -171,60 +174,55 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
 
   float4 ra[A_ROWS], rb[B_ROWS];
 
-  auto load_tiles = [&](int kt) {
+  auto load_tiles = [&](int kt) {   // branch-free: every lane always issues its loads, invalid ones at offset OOB
     const int kbase = k_begin + kt * BK;
-    // ---------------- A ----------------
     if constexpr (MODE == MODE_FWD) {
-      const bool kok = a_tap < T;
-      const int nv = min(4, a.Cin - a_ch);
+      const int dy = a_ky * a.dil, dx = a_kx * a.dil;
+      const int toff = a_tap < T ? (dy * a.W + dx) * xp4 + a_ch * 4 : OOB;
 #pragma unroll
       for (int i = 0; i < A_ROWS; ++i) {
-        const int iy = a_y0[i] + a_ky * a.dil, ix = a_x0[i] + a_kx * a.dil;
-        const bool ok = kok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        const float* p = a.A + (long)(a_pix[i] + iy * a.W + ix) * a.x_pitch + a_ch;
-        ra[i] = mask4(ld4(p, ok), nv);
+        const bool ok = ((unsigned)(a_y0[i] + dy) < (unsigned)a.H) & ((unsigned)(a_x0[i] + dx) < (unsigned)a.W) & (toff != OOB);
+        const int off = a_base[i] + toff;
+        ra[i] = bload(rA, ok ? off : OOB);
+      }
+      const int k4 = (kbase + (t & 7) * 4) * 4;
+      const bool kok = kbase + (t & 7) * 4 < k_end;
+#pragma unroll
+      for (int i = 0; i < B_ROWS; ++i) {
+        const int off = b_row[i] + k4;
+        rb[i] = bload(rB, (kok & (b_row[i] != OOB)) ? off : OOB);
       }
     } else if constexpr (MODE == MODE_DGRAD) {
+      const int dy = a_ky * a.dil, dx = a_kx * a.dil, smask = a.stride - 1;
       const bool kok = a_tap < T;
-      const int nv = min(4, a.Cout - a_ch);
-      const int smask = a.stride - 1;
 #pragma unroll
       for (int i = 0; i < A_ROWS; ++i) {
-        const int ty = a_y0[i] - a_ky * a.dil, tx = a_x0[i] - a_kx * a.dil;
+        const int ty = a_y0[i] - dy, tx = a_x0[i] - dx;
         const int oy = ty >> a.sshift, ox = tx >> a.sshift;
-        const bool ok = kok && ty >= 0 && tx >= 0 && ((ty | tx) & smask) == 0 && oy < a.Ho && ox < a.Wo;
-        const float* p = a.A + (long)(a_pix[i] + oy * a.Wo + ox) * a.y_pitch + a_ch;
-        ra[i] = mask4(ld4(p, ok), nv);
+        const bool ok = kok & ((ty | tx) >= 0) & (((ty | tx) & smask) == 0) & (oy < a.Ho) & (ox < a.Wo);   // '&': no short-circuit branches
+        const int off = (a_base[i] + oy * a.Wo + ox) * yp4 + a_ch * 4;   // computed unconditionally: keeps the loop body branch-free
+        ra[i] = bload(rA, ok ? off : OOB);
+      }
+#pragma unroll
+      for (int i = 0; i < B_ROWS; ++i) {
+        const bool ok = (b_aux[i] < T) & (b_col4 != OOB) & ((kbase + t / (BN / 4) + B_RSTEP * i) < k_end);
+        const int off = (b_row[i] * T + b_aux[i]) * (a.Cin * 4) + b_col4;
+        rb[i] = bload(rB, ok ? off : OOB);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < A_ROWS; ++i) {
         const int p = kbase + t / (BM / 4) + A_RSTEP * i;
-        const bool ok = p < k_end && a_nv > 0;
-        ra[i] = mask4(ld4(a.A + (long)p * a.y_pitch + a_col, ok), a_nv);
+        const int off = p * yp4 + a_col4;
+        ra[i] = bload(rA, ((p < k_end) & (a_col4 != OOB)) ? off : OOB);
       }
-    }
-    // ---------------- B ----------------
-    if constexpr (MODE == MODE_FWD) {
-      const int k = kbase + (t & 7) * 4;
-#pragma unroll
-      for (int i = 0; i < B_ROWS; ++i) {
-        const bool ok = b_row[i] < a.Cout && k < k_end;
-        rb[i] = mask4(ld4(a.B + (long)b_row[i] * a.K + k, ok), k_end - k);
-      }
-    } else if constexpr (MODE == MODE_DGRAD) {
-#pragma unroll
-      for (int i = 0; i < B_ROWS; ++i) {
-        const bool ok = b_aux[i] < T && b_nv > 0 && (kbase + t / (BN / 4) + B_RSTEP * i) < k_end;
-        rb[i] = mask4(ld4(a.B + ((long)b_row[i] * T + b_aux[i]) * a.Cin + b_col, ok), b_nv);
-      }
-    } else {
 #pragma unroll
       for (int i = 0; i < B_ROWS; ++i) {
         const int p = kbase + t / (BN / 4) + B_RSTEP * i;
         const int iy = b_aux[i] * a.stride - a.pad + b_ky * a.dil, ix = b_row[i] * a.stride - a.pad + b_kx * a.dil;
-        const bool ok = p < k_end && b_nv > 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        rb[i] = mask4(ld4(a.B + ((long)b_aux2[i] * a.H * a.W + iy * a.W + ix) * a.x_pitch + b_ci, ok), b_nv);
+        const bool ok = (p < k_end) & (b_col4 != OOB) & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
+        const int off = ((b_aux2[i] * a.H + iy) * a.W + ix) * xp4 + b_col4;
+        rb[i] = bload(rB, ok ? off : OOB);
       }
     }
   };
@@ -233,34 +231,48 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
     if constexpr (MODE == MODE_FWD || MODE == MODE_DGRAD) {
       const int cdim = (MODE == MODE_FWD) ? a.Cin : a.Cout;
       a_ch += BK;
-      while (a_ch >= cdim) {
-        a_ch -= cdim;
-        ++a_tap;
-        if (++a_kx == a.kw) {
-          a_kx = 0;
-          ++a_ky;
+      if constexpr (SMALLC) {
+        while (a_ch >= cdim) {
+          a_ch -= cdim;
+          ++a_tap;
+          if (++a_kx == a.kw) a_kx = 0, ++a_ky;
         }
+      } else {
+        const bool wrap = a_ch >= cdim;
+        a_ch -= wrap ? cdim : 0;
+        a_tap += wrap ? 1 : 0;
+        const bool roww = wrap & (a_kx + 1 == a.kw);
+        a_kx = roww ? 0 : a_kx + (wrap ? 1 : 0);
+        a_ky += roww ? 1 : 0;
       }
     }
     if constexpr (MODE == MODE_DGRAD) {
 #pragma unroll
       for (int i = 0; i < B_ROWS; ++i) {
         b_row[i] += BK;
-        while (b_row[i] >= a.Cout) {
-          b_row[i] -= a.Cout;
-          ++b_aux[i];
+        if constexpr (SMALLC) {
+          while (b_row[i] >= a.Cout) b_row[i] -= a.Cout, ++b_aux[i];
+        } else {
+          const bool wrap = b_row[i] >= a.Cout;
+          b_row[i] -= wrap ? a.Cout : 0;
+          b_aux[i] += wrap ? 1 : 0;
         }
       }
     } else if constexpr (MODE == MODE_WGRAD) {
 #pragma unroll
       for (int i = 0; i < B_ROWS; ++i) {
         b_row[i] += BK;
-        while (b_row[i] >= a.Wo) {
-          b_row[i] -= a.Wo;
-          if (++b_aux[i] == a.Ho) {
-            b_aux[i] = 0;
-            ++b_aux2[i];
+        if constexpr (SMALLC) {
+          while (b_row[i] >= a.Wo) {
+            b_row[i] -= a.Wo;
+            if (++b_aux[i] == a.Ho) b_aux[i] = 0, ++b_aux2[i];
           }
+        } else {
+          const bool wrap = b_row[i] >= a.Wo;
+          b_row[i] -= wrap ? a.Wo : 0;
+          const bool imgw = wrap & (b_aux[i] + 1 == a.Ho);
+          b_aux[i] = imgw ? 0 : b_aux[i] + (wrap ? 1 : 0);
+          b_aux2[i] += imgw ? 1 : 0;
         }
       }
     }
@@ -336,49 +348,62 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
     }
   };
 
-  // ---- main loop: register prefetch of slab kt+1 overlaps the MFMAs of slab kt ---------------------------------
+  // ---- main loop: the gather + address math of slab kt+1 sits in the same straight-line block as the MFMAs of slab kt,
+  // so the scheduler can hide it in the 64-cycle MFMA shadows (one barrier per K-step) --------------------------------
   if (nk > 0) {
     load_tiles(0);
     advance();
     store_tiles(0);
-  }
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = kt + 1 < nk;
-    if (more) {
-      load_tiles(kt + 1);
-      advance();
-    }
-    compute(kt & 1);
-    if (more) store_tiles((kt + 1) & 1);
     __syncthreads();
+    for (int kt = 0; kt < nk - 1; ++kt) {
+      load_tiles(kt + 1);
+      __builtin_amdgcn_sched_barrier(0);  // keep the 8 gathers ahead of the MFMAs: their latency hides under the whole slab
+      advance();
+      compute(kt & 1);
+      store_tiles((kt + 1) & 1);
+      __syncthreads();
+    }
+    compute((nk - 1) & 1);
   }
 
   // ---- epilogue -------------------------------------------------------------------------------------------------
   float* Cb = a.C + (a.ksplit > 1 ? (long)z * a.c_split : 0);
-  const bool plain = a.ksplit > 1;
+  const bool plain = a.ksplit > 1 || !(a.bias || a.scale || a.residual || a.relu);
+  const bool full = m0 + BM <= a.M && n0 + BN <= a.Nn;
+  const int rbase = m0 + wm * (BM / WM) + 4 * half, cbase = n0 + wn * (BN / WN) + l31;
+  if (plain && full) {  // straight-line stores, no per-element predicate
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          Cb[(long)(rbase + i * 32 + (r & 3) + 8 * (r >> 2)) * a.c_pitch + cbase + n * 32] = acc[i][n][r];
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
-      const int col = n0 + wn * (BN / WN) + n * 32 + l31;
-      if (col >= a.Nn) continue;
+      const int col = cbase + n * 32;
+      const bool cok = col < a.Nn;
       float bi = 0.f, sc = 1.f, sh = 0.f;
-      if (!plain) {
+      if (!plain && cok) {
         if (a.bias) bi = a.bias[col];
         if (a.scale) sc = a.scale[col], sh = a.shift[col];
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (row >= a.M) continue;
-        float v = acc[i][n][r];
-        if (!plain) {
-          v = (v + bi) * sc + sh;
-          if (a.residual) v += a.residual[(long)row * a.res_pitch + col];
-          if (a.relu) v = fmaxf(v, 0.f);
+        const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
+        if (row < a.M && cok) {
+          float v = acc[i][n][r];
+          if (!plain) {
+            v = (v + bi) * sc + sh;
+            if (a.residual) v += a.residual[(long)row * a.res_pitch + col];
+            if (a.relu) v = fmaxf(v, 0.f);
+          }
+          Cb[(long)row * a.c_pitch + col] = v;
         }
-        Cb[(long)row * a.c_pitch + col] = v;
       }
     }
 }
@@ -459,15 +484,20 @@ Plan make_plan(int mode, long M, long Nn, long K) {
   return p;
 }
 
-template <int MODE, int BM, int BN, int WM, int WN>
-void launch_one(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
+template <int MODE, int BM, int BN, int WM, int WN, bool SMALLC>
+void launch_inst(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
   static const bool attr_set = [] {  // > 64 KB of dynamic LDS needs an explicit opt-in, once per kernel
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<MODE, BM, BN, WM, WN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<MODE, BM, BN, WM, WN, SMALLC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return true;
   }();
   (void)attr_set;
-  hipLaunchKernelGGL((conv_igemm_kernel<MODE, BM, BN, WM, WN>), grid, dim3(256), smem, st, k);
+  hipLaunchKernelGGL((conv_igemm_kernel<MODE, BM, BN, WM, WN, SMALLC>), grid, dim3(256), smem, st, k);
+}
+template <int MODE, int BM, int BN, int WM, int WN>
+void launch_one(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
+  if (k.smallc) launch_inst<MODE, BM, BN, WM, WN, true>(k, grid, smem, st);
+  else launch_inst<MODE, BM, BN, WM, WN, false>(k, grid, smem, st);
 }
 
 // ---- optional in-library timing of the implicit-GEMM kernel itself (HIP events on the launch stream) ----------------
@@ -525,8 +555,8 @@ int check_common(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p
   PM_REQUIRE(x->c % 4 == 0, PM_EUNSUPPORTED, "conv: Cin %% 4 != 0 unsupported (pad the input channels)");
   PM_REQUIRE((y->c % 4 == 0) || (p->kh * p->kw == 1), PM_EUNSUPPORTED, "conv: Cout %% 4 != 0 only for 1x1");
   PM_REQUIRE(x->pitch >= x->c && y->pitch >= y->c, PM_EINVAL, "conv: pitch < channels");
-  PM_REQUIRE(pm_pixels(x) * x->pitch < (1ll << 31) && pm_pixels(y) * y->pitch < (1ll << 31) && (int64_t)y->c * x->c * p->kh * p->kw < (1ll << 31),
-             PM_EUNSUPPORTED, "conv: tensor too large for 32-bit pixel indexing");
+  PM_REQUIRE(pm_pixels(x) * x->pitch < (1ll << 29) && pm_pixels(y) * y->pitch < (1ll << 29) && (int64_t)y->c * x->c * p->kh * p->kw < (1ll << 29),
+             PM_EUNSUPPORTED, "conv: tensor too large for 32-bit byte offsets (2 GiB per tensor)");
   return PM_OK;
 }
 
@@ -593,6 +623,7 @@ extern "C" int pm_conv_fwd(const pm_tensor* x, const float* w, const pm_tensor* 
   fill_geom(k, x, y, p);
   k.A = (const float*)x->ptr, k.B = w;
   k.M = (int)M, k.Nn = (int)Nn, k.K = (int)K;
+  k.a_bytes = (unsigned)(pm_pixels(x) * x->pitch * 4), k.b_bytes = (unsigned)((long)y->c * K * 4), k.smallc = x->c < BK;
   pm_conv_epilogue e0 = {nullptr, nullptr, nullptr, nullptr, 0, 0};
   if (ep) e0 = *ep;
   PM_REQUIRE((e0.scale == nullptr) == (e0.shift == nullptr), PM_EINVAL, "conv_fwd: scale and shift go together");
@@ -625,6 +656,7 @@ extern "C" int pm_conv_bwd_data(const pm_tensor* dy, const float* w, const pm_te
   fill_geom(k, dx, dy, p);
   k.A = (const float*)dy->ptr, k.B = w;
   k.M = (int)M, k.Nn = (int)Nn, k.K = (int)K;
+  k.a_bytes = (unsigned)(pm_pixels(dy) * dy->pitch * 4), k.b_bytes = (unsigned)((long)dy->c * p->kh * p->kw * dx->c * 4), k.smallc = dy->c < BK;
   hipStream_t st = (hipStream_t)stream;
   if (pl.ksplit > 1) {
     k.C = (float*)ws, k.c_pitch = Nn, k.c_split = M * Nn;
@@ -652,6 +684,7 @@ extern "C" int pm_conv_bwd_weight(const pm_tensor* x, const pm_tensor* dy, float
   fill_geom(k, x, dy, p);
   k.A = (const float*)dy->ptr, k.B = (const float*)x->ptr;
   k.M = (int)M, k.Nn = (int)Nn, k.K = (int)K;
+  k.a_bytes = (unsigned)(pm_pixels(dy) * dy->pitch * 4), k.b_bytes = (unsigned)(pm_pixels(x) * x->pitch * 4), k.smallc = dy->w < BK;
   hipStream_t st = (hipStream_t)stream;
   if (pl.ksplit > 1) {
     k.C = (float*)ws, k.c_pitch = Nn, k.c_split = M * Nn;
