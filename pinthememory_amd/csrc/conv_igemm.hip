@@ -37,7 +37,7 @@ struct ConvK {
   long c_split;           // floats between split-K slabs (ksplit > 1 -> C is the workspace)
   int tiles_m, tiles_n;
   unsigned a_bytes, b_bytes;  // extents of the A / B buffers (buffer-descriptor range)
-  int smallc;                 // 1: a per-K-step counter may wrap more than once (needs the looping variant)
+  int kmode;                  // K_FAST / K_MID / K_SMALL: how the gather's K-state advances (see the kernel)
   const float* bias;
   const float* scale;
   const float* shift;
@@ -63,21 +63,27 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
-// SMALLC: the per-K-step wrap of the running (channel | pixel-column) counter may happen more than once
-// (Cin or Cout < BK, or Wo < BK in wgrad) -> loop instead of a single compare/select.
-template <int MODE, int BM, int BN, int WM, int WN, bool SMALLC>
+// KM selects how the running K-state of the gather advances by one K-step:
+//   K_FAST  the channel extent is a multiple of BK (and stride 1 for dgrad): a K-slab never straddles a tap, so
+//           (tap, channel) are wave-uniform -> they live in SGPRs and the per-row work is add / compare / select;
+//   K_MID   channel extent (or Wo for wgrad) >= BK: at most one wrap per step, per-lane state, compare + select;
+//   K_SMALL extent < BK (stem Cin = 4, Cout = 19, tiny test images): per-lane state, looping wrap.
+enum { K_FAST = 0, K_MID = 1, K_SMALL = 2 };
+
+// Thread -> tile element mapping (256 threads, g = t & 7, r = t >> 3):
+//   k-contiguous (KC) tiles [rows][LDK]: thread owns k-group g (4 floats) of rows r + 32*i   -> 1 K-state, static rows
+//   m-contiguous (MC) tiles [BK][cols] : thread owns k-row r, column groups (g + 8*j) * 4      -> 1 K-state, static cols
+template <int MODE, int BM, int BN, int WM, int WN, int KM>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   constexpr bool A_KC = (MODE != MODE_WGRAD);  // A tile stored [BM][LDK] (k contiguous) else [BK][BM]
   constexpr bool B_KC = (MODE == MODE_FWD);    // B tile stored [BN][LDK] else [BK][BN]
+  constexpr bool FAST = (KM == K_FAST) && (MODE != MODE_WGRAD);
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_FLOATS = A_KC ? BM * LDK : BK * BM;
   constexpr int B_FLOATS = B_KC ? BN * LDK : BK * BN;
   constexpr int STAGE = A_FLOATS + B_FLOATS;
-  constexpr int A_ROWS = A_KC ? BM / 32 : BK / (256 / (BM / 4));  // rows per thread
-  constexpr int B_ROWS = B_KC ? BN / 32 : BK / (256 / (BN / 4));
-  constexpr int A_RSTEP = A_KC ? 32 : 256 / (BM / 4);
-  constexpr int B_RSTEP = B_KC ? 32 : 256 / (BN / 4);
-  static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && A_ROWS >= 1 && B_ROWS >= 1, "bad tile config");
+  constexpr int A_N = BM / 32, B_N = BN / 32;  // float4 per thread and tile
+  static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BK == 32, "bad tile config");
 
   extern __shared__ __align__(16) float smem[];
 
@@ -85,6 +91,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int half = lane >> 5, l31 = lane & 31;
+  const int g = t & 7, r = t >> 3;
 
   const int ntile = a.tiles_m * a.tiles_n;
   const int lid = xcd_remap(blockIdx.x, ntile);
@@ -100,27 +107,35 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.B), 0, (int)a.b_bytes, 0x00020000);
   const int xp4 = (int)a.x_pitch * 4, yp4 = (int)a.y_pitch * 4;
 
-  // ---- per-thread gather state ----------------------------------------------------------------------------------
-  // KC tiles: thread -> (k-group g = t&7 of 4 floats, rows t>>3 + 32*i);  MC tiles: thread -> (col group, k rows)
-  int a_base[A_ROWS], a_y0[A_ROWS], a_x0[A_ROWS];  // FWD/DGRAD: byte offset of the row's window origin, window origin
-  int a_ch = 0, a_tap = 0, a_ky = 0, a_kx = 0;     // FWD/DGRAD: running (tap, channel) of this thread's k-group
-  int a_col4 = OOB;                                // WGRAD: byte offset of this thread's dy channel group (OOB if beyond Cout)
+  // ---- gather state ---------------------------------------------------------------------------------------------
+  // uniform K-state (FAST) / per-lane K-state (MID, SMALL) of the (tap, channel) decomposition of k
+  int u_ch = 0, u_tap = 0, u_ky = 0, u_kx = 0;     // FAST: wave-uniform (SGPR)
+  int a_ch = 0, a_tap = 0, a_ky = 0, a_kx = 0;     // MID/SMALL FWD+DGRAD A
+  int b_co = 0, b_tap = 0;                         // MID/SMALL DGRAD B row (tap, co)
+  int p_ox = 0, p_oy = 0, p_img = 0;               // WGRAD B: output pixel of this thread's k-row
+  // static per-item constants
+  int a_base[A_N], a_y0[A_N], a_x0[A_N];           // FWD/DGRAD A rows: byte offset of the window origin, window origin
+  int a_col4[A_N];                                 // WGRAD A: byte offset of dy channel group j (OOB beyond Cout)
+  int b_base[B_N];                                 // FWD: weight-row byte offset; DGRAD: ci group byte offset; WGRAD: tap+channel offset
+  int b_dy[B_N], b_dx[B_N];                        // WGRAD B: tap displacement of column group j
+
   if constexpr (MODE == MODE_FWD || MODE == MODE_DGRAD) {
     const int rh = (MODE == MODE_FWD) ? a.Ho : a.H, rw = (MODE == MODE_FWD) ? a.Wo : a.W;
+    const int cdim = (MODE == MODE_FWD) ? a.Cin : a.Cout;
 #pragma unroll
-    for (int i = 0; i < A_ROWS; ++i) {
-      const int m = m0 + (t >> 3) + 32 * i;
+    for (int i = 0; i < A_N; ++i) {
+      const int m = m0 + r + 32 * i;
       if (m < a.M) {
         const int img = m / (rh * rw), rem = m - img * (rh * rw);
         const int py = rem / rw, px = rem - py * rw;
         if constexpr (MODE == MODE_FWD) {
           a_y0[i] = py * a.stride - a.pad;
           a_x0[i] = px * a.stride - a.pad;
-          a_base[i] = (img * a.H * a.W + a_y0[i] * a.W + a_x0[i]) * xp4;
+          a_base[i] = (img * a.H * a.W + a_y0[i] * a.W + a_x0[i]) * xp4 + (FAST ? g * 16 : 0);
         } else {
           a_y0[i] = py + a.pad;
           a_x0[i] = px + a.pad;
-          a_base[i] = img * a.Ho * a.Wo;           // pixel index; the (oy, ox) part is added per tap
+          a_base[i] = FAST ? ((img * a.Ho + a_y0[i]) * a.Wo + a_x0[i]) * yp4 + g * 16 : img * a.Ho * a.Wo;
         }
       } else {
         a_base[i] = 0;
@@ -128,152 +143,186 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
         a_x0[i] = -(1 << 28);
       }
     }
-    const int cdim = (MODE == MODE_FWD) ? a.Cin : a.Cout;
-    const int k = k_begin + (t & 7) * 4;
-    a_tap = k / cdim;
-    a_ch = k - a_tap * cdim;
-    a_ky = a_tap / a.kw;
-    a_kx = a_tap - a_ky * a.kw;
+    if constexpr (FAST) {
+      u_tap = __builtin_amdgcn_readfirstlane(k_begin / cdim);
+      u_ch = k_begin - u_tap * cdim;
+      u_ky = u_tap / a.kw;
+      u_kx = u_tap - u_ky * a.kw;
+    } else {
+      const int k = k_begin + g * 4;
+      a_tap = k / cdim;
+      a_ch = k - a_tap * cdim;
+      a_ky = a_tap / a.kw;
+      a_kx = a_tap - a_ky * a.kw;
+    }
   } else {
-    const int col = m0 + (t % (BM / 4)) * 4;
-    a_col4 = col < a.Cout ? col * 4 : OOB;
+#pragma unroll
+    for (int j = 0; j < A_N; ++j) {
+      const int col = m0 + (g + 8 * j) * 4;
+      a_col4[j] = col < a.Cout ? col * 4 : OOB;
+    }
   }
-  int b_row[B_ROWS];               // FWD: byte offset of the weight row (OOB if beyond Cout); DGRAD: running co; WGRAD: running ox
-  int b_aux[B_ROWS], b_aux2[B_ROWS];  // DGRAD: running tap ; WGRAD: running oy, img
-  int b_col4 = OOB, b_ky = 0, b_kx = 0;
   if constexpr (MODE == MODE_FWD) {
 #pragma unroll
-    for (int i = 0; i < B_ROWS; ++i) {
-      const int r = n0 + (t >> 3) + 32 * i;
-      b_row[i] = r < a.Cout ? r * a.K * 4 : OOB;
+    for (int i = 0; i < B_N; ++i) {
+      const int row = n0 + r + 32 * i;
+      b_base[i] = row < a.Cout ? row * a.K * 4 + g * 16 : OOB;
     }
   } else if constexpr (MODE == MODE_DGRAD) {
-    const int col = n0 + (t % (BN / 4)) * 4;
-    b_col4 = col < a.Cin ? col * 4 : OOB;
 #pragma unroll
-    for (int i = 0; i < B_ROWS; ++i) {
-      const int k = k_begin + t / (BN / 4) + B_RSTEP * i;
-      b_aux[i] = k / a.Cout;
-      b_row[i] = k - b_aux[i] * a.Cout;
+    for (int j = 0; j < B_N; ++j) {
+      const int col = n0 + (g + 8 * j) * 4;
+      b_base[j] = col < a.Cin ? col * 4 + (FAST ? r * T * a.Cin * 4 : 0) : OOB;
+    }
+    if constexpr (!FAST) {
+      const int k = k_begin + r;
+      b_tap = k / a.Cout;
+      b_co = k - b_tap * a.Cout;
     }
   } else {
-    const int n = n0 + (t % (BN / 4)) * 4;
-    const int tap = n < a.Nn ? n / a.Cin : 0;
-    b_col4 = n < a.Nn ? (n - tap * a.Cin) * 4 : OOB;
-    b_ky = tap / a.kw;
-    b_kx = tap - b_ky * a.kw;
 #pragma unroll
-    for (int i = 0; i < B_ROWS; ++i) {
-      const int p = k_begin + t / (BN / 4) + B_RSTEP * i;
-      const int img = p / (a.Ho * a.Wo), rem = p - img * (a.Ho * a.Wo);
-      b_aux2[i] = img;
-      b_aux[i] = rem / a.Wo;
-      b_row[i] = rem - b_aux[i] * a.Wo;
+    for (int j = 0; j < B_N; ++j) {
+      const int n = n0 + (g + 8 * j) * 4;
+      const int tap = n < a.Nn ? n / a.Cin : 0;
+      const int ky = tap / a.kw, kx = tap - ky * a.kw;
+      b_dy[j] = ky * a.dil - a.pad;
+      b_dx[j] = kx * a.dil - a.pad;
+      b_base[j] = n < a.Nn ? (b_dy[j] * a.W + b_dx[j]) * xp4 + (n - tap * a.Cin) * 4 : OOB;
     }
+    const int p = k_begin + r;
+    p_img = p / (a.Ho * a.Wo);
+    const int rem = p - p_img * (a.Ho * a.Wo);
+    p_oy = rem / a.Wo;
+    p_ox = rem - p_oy * a.Wo;
   }
 
-  float4 ra[A_ROWS], rb[B_ROWS];
+  float4 ra[A_N], rb[B_N];
 
   auto load_tiles = [&](int kt) {   // branch-free: every lane always issues its loads, invalid ones at offset OOB
     const int kbase = k_begin + kt * BK;
     if constexpr (MODE == MODE_FWD) {
-      const int dy = a_ky * a.dil, dx = a_kx * a.dil;
-      const int toff = a_tap < T ? (dy * a.W + dx) * xp4 + a_ch * 4 : OOB;
+      const int ky = FAST ? u_ky : a_ky, kx = FAST ? u_kx : a_kx, tap = FAST ? u_tap : a_tap, ch = FAST ? u_ch : a_ch;
+      const int dy = ky * a.dil, dx = kx * a.dil;
+      const int toff = (dy * a.W + dx) * xp4 + ch * 4;
+      const bool tok = tap < T;
 #pragma unroll
-      for (int i = 0; i < A_ROWS; ++i) {
-        const bool ok = ((unsigned)(a_y0[i] + dy) < (unsigned)a.H) & ((unsigned)(a_x0[i] + dx) < (unsigned)a.W) & (toff != OOB);
+      for (int i = 0; i < A_N; ++i) {
+        const bool ok = ((unsigned)(a_y0[i] + dy) < (unsigned)a.H) & ((unsigned)(a_x0[i] + dx) < (unsigned)a.W) & tok;
         const int off = a_base[i] + toff;
         ra[i] = bload(rA, ok ? off : OOB);
       }
-      const int k4 = (kbase + (t & 7) * 4) * 4;
-      const bool kok = kbase + (t & 7) * 4 < k_end;
+      const bool kok = FAST ? true : (kbase + g * 4 < k_end);
 #pragma unroll
-      for (int i = 0; i < B_ROWS; ++i) {
-        const int off = b_row[i] + k4;
-        rb[i] = bload(rB, (kok & (b_row[i] != OOB)) ? off : OOB);
+      for (int i = 0; i < B_N; ++i) {
+        const int off = b_base[i] + kbase * 4;   // b_base already carries this thread's k-group (g * 16 bytes)
+        rb[i] = bload(rB, (kok & (b_base[i] != OOB)) ? off : OOB);
       }
     } else if constexpr (MODE == MODE_DGRAD) {
-      const int dy = a_ky * a.dil, dx = a_kx * a.dil, smask = a.stride - 1;
-      const bool kok = a_tap < T;
+      if constexpr (FAST) {   // stride 1, Cout % BK == 0: uniform (tap, co0)
+        const int dy = u_ky * a.dil, dx = u_kx * a.dil;
+        const int toff = (dy * a.Wo + dx) * yp4 - u_ch * 4;
+        const bool tok = u_tap < T;
 #pragma unroll
-      for (int i = 0; i < A_ROWS; ++i) {
-        const int ty = a_y0[i] - dy, tx = a_x0[i] - dx;
-        const int oy = ty >> a.sshift, ox = tx >> a.sshift;
-        const bool ok = kok & ((ty | tx) >= 0) & (((ty | tx) & smask) == 0) & (oy < a.Ho) & (ox < a.Wo);   // '&': no short-circuit branches
-        const int off = (a_base[i] + oy * a.Wo + ox) * yp4 + a_ch * 4;   // computed unconditionally: keeps the loop body branch-free
-        ra[i] = bload(rA, ok ? off : OOB);
-      }
+        for (int i = 0; i < A_N; ++i) {
+          const bool ok = ((unsigned)(a_y0[i] - dy) < (unsigned)a.Ho) & ((unsigned)(a_x0[i] - dx) < (unsigned)a.Wo) & tok;
+          const int off = a_base[i] - toff;
+          ra[i] = bload(rA, ok ? off : OOB);
+        }
+        const int uoff = (u_ch * T + u_tap) * a.Cin * 4;
 #pragma unroll
-      for (int i = 0; i < B_ROWS; ++i) {
-        const bool ok = (b_aux[i] < T) & (b_col4 != OOB) & ((kbase + t / (BN / 4) + B_RSTEP * i) < k_end);
-        const int off = (b_row[i] * T + b_aux[i]) * (a.Cin * 4) + b_col4;
-        rb[i] = bload(rB, ok ? off : OOB);
+        for (int j = 0; j < B_N; ++j) {
+          const int off = b_base[j] + uoff;
+          rb[j] = bload(rB, (tok & (b_base[j] != OOB)) ? off : OOB);
+        }
+      } else {
+        const int dy = a_ky * a.dil, dx = a_kx * a.dil, smask = a.stride - 1;
+        const bool kok = a_tap < T;
+#pragma unroll
+        for (int i = 0; i < A_N; ++i) {
+          const int ty = a_y0[i] - dy, tx = a_x0[i] - dx;
+          const int oy = ty >> a.sshift, ox = tx >> a.sshift;
+          const bool ok = kok & ((ty | tx) >= 0) & (((ty | tx) & smask) == 0) & (oy < a.Ho) & (ox < a.Wo);   // '&': no short-circuit branches
+          const int off = (a_base[i] + oy * a.Wo + ox) * yp4 + a_ch * 4;   // computed unconditionally: keeps the loop body branch-free
+          ra[i] = bload(rA, ok ? off : OOB);
+        }
+        const bool rok = (b_tap < T) & (kbase + r < k_end);
+        const int roff = (b_co * T + b_tap) * a.Cin * 4;
+#pragma unroll
+        for (int j = 0; j < B_N; ++j) {
+          const int off = roff + b_base[j];
+          rb[j] = bload(rB, (rok & (b_base[j] != OOB)) ? off : OOB);
+        }
       }
     } else {
+      const int p = kbase + r;
+      const bool pok = p < k_end;
+      const int poff = p * yp4;
 #pragma unroll
-      for (int i = 0; i < A_ROWS; ++i) {
-        const int p = kbase + t / (BM / 4) + A_RSTEP * i;
-        const int off = p * yp4 + a_col4;
-        ra[i] = bload(rA, ((p < k_end) & (a_col4 != OOB)) ? off : OOB);
+      for (int j = 0; j < A_N; ++j) {
+        const int off = poff + a_col4[j];
+        ra[j] = bload(rA, (pok & (a_col4[j] != OOB)) ? off : OOB);
       }
+      const int by = p_oy * a.stride, bx = p_ox * a.stride;
+      const int rowbase = ((p_img * a.H + by) * a.W + bx) * xp4;
 #pragma unroll
-      for (int i = 0; i < B_ROWS; ++i) {
-        const int p = kbase + t / (BN / 4) + B_RSTEP * i;
-        const int iy = b_aux[i] * a.stride - a.pad + b_ky * a.dil, ix = b_row[i] * a.stride - a.pad + b_kx * a.dil;
-        const bool ok = (p < k_end) & (b_col4 != OOB) & ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
-        const int off = ((b_aux2[i] * a.H + iy) * a.W + ix) * xp4 + b_col4;
-        rb[i] = bload(rB, ok ? off : OOB);
+      for (int j = 0; j < B_N; ++j) {
+        const bool ok = pok & (b_base[j] != OOB) & ((unsigned)(by + b_dy[j]) < (unsigned)a.H) & ((unsigned)(bx + b_dx[j]) < (unsigned)a.W);
+        const int off = rowbase + b_base[j];
+        rb[j] = bload(rB, ok ? off : OOB);
       }
     }
   };
 
-  auto advance = [&]() {  // move the running gather state one K-step (BK) forward
+  auto advance = [&]() {  // move the K-state one K-step (BK) forward
     if constexpr (MODE == MODE_FWD || MODE == MODE_DGRAD) {
       const int cdim = (MODE == MODE_FWD) ? a.Cin : a.Cout;
-      a_ch += BK;
-      if constexpr (SMALLC) {
-        while (a_ch >= cdim) {
-          a_ch -= cdim;
-          ++a_tap;
-          if (++a_kx == a.kw) a_kx = 0, ++a_ky;
+      if constexpr (FAST) {
+        u_ch += BK;
+        if (u_ch >= cdim) {            // uniform branch on SGPRs (scalar unit), never diverges
+          u_ch = 0;
+          ++u_tap;
+          if (++u_kx == a.kw) u_kx = 0, ++u_ky;
         }
       } else {
-        const bool wrap = a_ch >= cdim;
-        a_ch -= wrap ? cdim : 0;
-        a_tap += wrap ? 1 : 0;
-        const bool roww = wrap & (a_kx + 1 == a.kw);
-        a_kx = roww ? 0 : a_kx + (wrap ? 1 : 0);
-        a_ky += roww ? 1 : 0;
-      }
-    }
-    if constexpr (MODE == MODE_DGRAD) {
-#pragma unroll
-      for (int i = 0; i < B_ROWS; ++i) {
-        b_row[i] += BK;
-        if constexpr (SMALLC) {
-          while (b_row[i] >= a.Cout) b_row[i] -= a.Cout, ++b_aux[i];
-        } else {
-          const bool wrap = b_row[i] >= a.Cout;
-          b_row[i] -= wrap ? a.Cout : 0;
-          b_aux[i] += wrap ? 1 : 0;
-        }
-      }
-    } else if constexpr (MODE == MODE_WGRAD) {
-#pragma unroll
-      for (int i = 0; i < B_ROWS; ++i) {
-        b_row[i] += BK;
-        if constexpr (SMALLC) {
-          while (b_row[i] >= a.Wo) {
-            b_row[i] -= a.Wo;
-            if (++b_aux[i] == a.Ho) b_aux[i] = 0, ++b_aux2[i];
+        a_ch += BK;
+        if constexpr (KM == K_SMALL) {
+          while (a_ch >= cdim) {
+            a_ch -= cdim;
+            ++a_tap;
+            if (++a_kx == a.kw) a_kx = 0, ++a_ky;
           }
         } else {
-          const bool wrap = b_row[i] >= a.Wo;
-          b_row[i] -= wrap ? a.Wo : 0;
-          const bool imgw = wrap & (b_aux[i] + 1 == a.Ho);
-          b_aux[i] = imgw ? 0 : b_aux[i] + (wrap ? 1 : 0);
-          b_aux2[i] += imgw ? 1 : 0;
+          const bool wrap = a_ch >= cdim;
+          a_ch -= wrap ? cdim : 0;
+          a_tap += wrap ? 1 : 0;
+          const bool roww = wrap & (a_kx + 1 == a.kw);
+          a_kx = roww ? 0 : a_kx + (wrap ? 1 : 0);
+          a_ky += roww ? 1 : 0;
         }
+        if constexpr (MODE == MODE_DGRAD) {
+          b_co += BK;
+          if constexpr (KM == K_SMALL) {
+            while (b_co >= a.Cout) b_co -= a.Cout, ++b_tap;
+          } else {
+            const bool wrap = b_co >= a.Cout;
+            b_co -= wrap ? a.Cout : 0;
+            b_tap += wrap ? 1 : 0;
+          }
+        }
+      }
+    } else {
+      p_ox += BK;
+      if constexpr (KM == K_SMALL) {
+        while (p_ox >= a.Wo) {
+          p_ox -= a.Wo;
+          if (++p_oy == a.Ho) p_oy = 0, ++p_img;
+        }
+      } else {
+        const bool wrap = p_ox >= a.Wo;
+        p_ox -= wrap ? a.Wo : 0;
+        const bool imgw = wrap & (p_oy + 1 == a.Ho);
+        p_oy = imgw ? 0 : p_oy + (wrap ? 1 : 0);
+        p_img += imgw ? 1 : 0;
       }
     }
   };
@@ -281,23 +330,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   auto store_tiles = [&](int buf) {
     float* As = smem + buf * STAGE;
     float* Bs = As + A_FLOATS;
-    if constexpr (A_KC) {
 #pragma unroll
-      for (int i = 0; i < A_ROWS; ++i)
-        *reinterpret_cast<float4*>(As + ((t >> 3) + 32 * i) * LDK + (t & 7) * 4) = ra[i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < A_ROWS; ++i)
-        *reinterpret_cast<float4*>(As + (t / (BM / 4) + A_RSTEP * i) * BM + (t % (BM / 4)) * 4) = ra[i];
+    for (int i = 0; i < A_N; ++i) {
+      if constexpr (A_KC) *reinterpret_cast<float4*>(As + (r + 32 * i) * LDK + g * 4) = ra[i];
+      else *reinterpret_cast<float4*>(As + r * BM + (g + 8 * i) * 4) = ra[i];
     }
-    if constexpr (B_KC) {
 #pragma unroll
-      for (int i = 0; i < B_ROWS; ++i)
-        *reinterpret_cast<float4*>(Bs + ((t >> 3) + 32 * i) * LDK + (t & 7) * 4) = rb[i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < B_ROWS; ++i)
-        *reinterpret_cast<float4*>(Bs + (t / (BN / 4) + B_RSTEP * i) * BN + (t % (BN / 4)) * 4) = rb[i];
+    for (int i = 0; i < B_N; ++i) {
+      if constexpr (B_KC) *reinterpret_cast<float4*>(Bs + (r + 32 * i) * LDK + g * 4) = rb[i];
+      else *reinterpret_cast<float4*>(Bs + r * BN + (g + 8 * i) * 4) = rb[i];
     }
   };
 
@@ -307,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
   auto compute = [&](int buf) {
     const float* As = smem + buf * STAGE;
@@ -348,8 +389,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
     }
   };
 
-  // ---- main loop: the gather + address math of slab kt+1 sits in the same straight-line block as the MFMAs of slab kt,
-  // so the scheduler can hide it in the 64-cycle MFMA shadows (one barrier per K-step) --------------------------------
+  // ---- main loop: the gathers of slab kt+1 are issued (branch-free) ahead of the MFMAs of slab kt, whose 4096 matrix-pipe
+  // cycles cover the load latency; LDS is double-buffered, one barrier per K-step ----------------------------------------
   if (nk > 0) {
     load_tiles(0);
     advance();
@@ -357,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
     __syncthreads();
     for (int kt = 0; kt < nk - 1; ++kt) {
       load_tiles(kt + 1);
-      __builtin_amdgcn_sched_barrier(0);  // keep the 8 gathers ahead of the MFMAs: their latency hides under the whole slab
+      __builtin_amdgcn_sched_barrier(0);  // keep the gathers ahead of the MFMAs: their latency hides under the whole slab
       advance();
       compute(kt & 1);
       store_tiles((kt + 1) & 1);
@@ -377,8 +418,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
 #pragma unroll
       for (int n = 0; n < TN; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          Cb[(long)(rbase + i * 32 + (r & 3) + 8 * (r >> 2)) * a.c_pitch + cbase + n * 32] = acc[i][n][r];
+        for (int q = 0; q < 16; ++q)
+          Cb[(long)(rbase + i * 32 + (q & 3) + 8 * (q >> 2)) * a.c_pitch + cbase + n * 32] = acc[i][n][q];
     return;
   }
 #pragma unroll
@@ -393,10 +434,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
         if (a.scale) sc = a.scale[col], sh = a.shift[col];
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
+      for (int q = 0; q < 16; ++q) {
+        const int row = rbase + i * 32 + (q & 3) + 8 * (q >> 2);
         if (row < a.M && cok) {
-          float v = acc[i][n][r];
+          float v = acc[i][n][q];
           if (!plain) {
             v = (v + bi) * sc + sh;
             if (a.residual) v += a.residual[(long)row * a.res_pitch + col];
@@ -474,7 +515,8 @@ Plan make_plan(int mode, long M, long Nn, long K) {
     const long ks_eff = (ksteps + steps_per - 1) / steps_per;
     if (ks_eff != ks) continue;
     const long blocks = tiles * ks;
-    double t = (double)((blocks + 255) / 256) * (double)(steps_per + 2) * unit_us;
+    const long per_cu = (blocks + 255) / 256;
+    double t = (double)per_cu * (double)(steps_per + 2) * unit_us * (per_cu == 1 ? 1.25 : 1.0);  // a lone block per CU cannot hide its own stalls
     if (ks > 1) t += 2.0 * (double)ks * (double)M * (double)Nn * 4.0 / 3.0e6 + 6.0;  // bytes / (3 TB/s) in us + reduce launch
     if (t < best) best = t, best_ks = ks, best_steps = steps_per;
   }
@@ -484,20 +526,21 @@ Plan make_plan(int mode, long M, long Nn, long K) {
   return p;
 }
 
-template <int MODE, int BM, int BN, int WM, int WN, bool SMALLC>
+template <int MODE, int BM, int BN, int WM, int WN, int KM>
 void launch_inst(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
   static const bool attr_set = [] {  // > 64 KB of dynamic LDS needs an explicit opt-in, once per kernel
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<MODE, BM, BN, WM, WN, SMALLC>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<MODE, BM, BN, WM, WN, KM>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return true;
   }();
   (void)attr_set;
-  hipLaunchKernelGGL((conv_igemm_kernel<MODE, BM, BN, WM, WN, SMALLC>), grid, dim3(256), smem, st, k);
+  hipLaunchKernelGGL((conv_igemm_kernel<MODE, BM, BN, WM, WN, KM>), grid, dim3(256), smem, st, k);
 }
 template <int MODE, int BM, int BN, int WM, int WN>
 void launch_one(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
-  if (k.smallc) launch_inst<MODE, BM, BN, WM, WN, true>(k, grid, smem, st);
-  else launch_inst<MODE, BM, BN, WM, WN, false>(k, grid, smem, st);
+  if (k.kmode == K_SMALL) launch_inst<MODE, BM, BN, WM, WN, K_SMALL>(k, grid, smem, st);
+  else if (k.kmode == K_FAST && MODE != MODE_WGRAD) launch_inst<MODE, BM, BN, WM, WN, (MODE != MODE_WGRAD ? K_FAST : K_MID)>(k, grid, smem, st);
+  else launch_inst<MODE, BM, BN, WM, WN, K_MID>(k, grid, smem, st);
 }
 
 // ---- optional in-library timing of the implicit-GEMM kernel itself (HIP events on the launch stream) ----------------
@@ -623,7 +666,7 @@ extern "C" int pm_conv_fwd(const pm_tensor* x, const float* w, const pm_tensor* 
   fill_geom(k, x, y, p);
   k.A = (const float*)x->ptr, k.B = w;
   k.M = (int)M, k.Nn = (int)Nn, k.K = (int)K;
-  k.a_bytes = (unsigned)(pm_pixels(x) * x->pitch * 4), k.b_bytes = (unsigned)((long)y->c * K * 4), k.smallc = x->c < BK;
+  k.a_bytes = (unsigned)(pm_pixels(x) * x->pitch * 4), k.b_bytes = (unsigned)((long)y->c * K * 4), k.kmode = x->c % BK == 0 ? 0 : (x->c >= BK ? 1 : 2);
   pm_conv_epilogue e0 = {nullptr, nullptr, nullptr, nullptr, 0, 0};
   if (ep) e0 = *ep;
   PM_REQUIRE((e0.scale == nullptr) == (e0.shift == nullptr), PM_EINVAL, "conv_fwd: scale and shift go together");
@@ -656,7 +699,7 @@ extern "C" int pm_conv_bwd_data(const pm_tensor* dy, const float* w, const pm_te
   fill_geom(k, dx, dy, p);
   k.A = (const float*)dy->ptr, k.B = w;
   k.M = (int)M, k.Nn = (int)Nn, k.K = (int)K;
-  k.a_bytes = (unsigned)(pm_pixels(dy) * dy->pitch * 4), k.b_bytes = (unsigned)((long)dy->c * p->kh * p->kw * dx->c * 4), k.smallc = dy->c < BK;
+  k.a_bytes = (unsigned)(pm_pixels(dy) * dy->pitch * 4), k.b_bytes = (unsigned)((long)dy->c * p->kh * p->kw * dx->c * 4), k.kmode = (dy->c % BK == 0 && p->stride == 1) ? 0 : (dy->c >= BK ? 1 : 2);
   hipStream_t st = (hipStream_t)stream;
   if (pl.ksplit > 1) {
     k.C = (float*)ws, k.c_pitch = Nn, k.c_split = M * Nn;
@@ -684,7 +727,7 @@ extern "C" int pm_conv_bwd_weight(const pm_tensor* x, const pm_tensor* dy, float
   fill_geom(k, x, dy, p);
   k.A = (const float*)dy->ptr, k.B = (const float*)x->ptr;
   k.M = (int)M, k.Nn = (int)Nn, k.K = (int)K;
-  k.a_bytes = (unsigned)(pm_pixels(dy) * dy->pitch * 4), k.b_bytes = (unsigned)(pm_pixels(x) * x->pitch * 4), k.smallc = dy->w < BK;
+  k.a_bytes = (unsigned)(pm_pixels(dy) * dy->pitch * 4), k.b_bytes = (unsigned)(pm_pixels(x) * x->pitch * 4), k.kmode = dy->w >= BK ? 1 : 2;
   hipStream_t st = (hipStream_t)stream;
   if (pl.ksplit > 1) {
     k.C = (float*)ws, k.c_pitch = Nn, k.c_split = M * Nn;
