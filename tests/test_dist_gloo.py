@@ -1,0 +1,142 @@
+"""CPU, world_size 2 over gloo: the three data-parallel exchanges of the hot path (pinthememory_amd/dist.py) reproduce the
+single-process big-batch result. The math on each rank is the oracle's (this is host logic: no GPU, no HIP library)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(rank, world, port, fn, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        out[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def spawn(fn, world=2):
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_run, args=(world, _free_port(), fn, out), nprocs=world, join=True)
+    return [out[r] for r in range(world)]
+
+
+# ---- C3: memory-slot all-reduce ------------------------------------------------------------------------------------
+def _mem_inputs():
+    from pinthememory_amd import synth
+    z = torch.relu(synth.det_tensor((4, 256, 6, 6), 5))
+    _, mask = synth.make_batch(4, 48, seed=9, block=8)
+    return z, mask
+
+
+def _c3(rank, world):
+    from oracle.ref_cpu.memory import Memory_sup
+    from pinthememory_amd import dist as D, synth
+    z, mask = _mem_inputs()
+    M = Memory_sup(19, 256, 256, 0.8, 1, gumbel_read=False)
+    M.m_items = synth.det_memory()
+    lo, hi = rank * 2, rank * 2 + 2                                  # rank r owns images [2r, 2r+2)
+    zl = z[lo:hi].clone().requires_grad_(True)
+    nom, den = M.accumulate(F.normalize(zl, dim=1), mask[lo:hi])
+    flat = D.all_reduce_sum_autograd(torch.cat([nom.reshape(-1), den.reshape(-1)]))
+    nom, den = flat[:20 * 256].view(20, 256), flat[20 * 256:]
+    upd = M.update(nom, den)
+    (upd * synth.det_tensor((19, 256), 3)).sum().backward()
+    return upd.detach(), zl.grad
+
+
+def test_memory_slot_allreduce_equals_big_batch():
+    from oracle.ref_cpu.memory import Memory_sup
+    from pinthememory_amd import synth
+    res = spawn(_c3)
+    z, mask = _mem_inputs()
+    M = Memory_sup(19, 256, 256, 0.8, 1, gumbel_read=False)
+    M.m_items = synth.det_memory()
+    zr = z.clone().requires_grad_(True)
+    nom, den = M.accumulate(F.normalize(zr, dim=1), mask)
+    upd = M.update(nom, den)
+    (upd * synth.det_tensor((19, 256), 3)).sum().backward()
+    for r in range(2):
+        assert torch.allclose(res[r][0], upd.detach(), atol=1e-6)            # every rank holds the big-batch memory
+        # each rank's loss sees every rank's features: grads arrive summed over ranks (= world x the single-process grad)
+        assert torch.allclose(res[r][1], 2 * zr.grad[r * 2:r * 2 + 2], atol=1e-6, rtol=1e-4)
+
+
+# ---- C2: BatchNorm statistics merge ----------------------------------------------------------------------------------
+def _c2(rank, world):
+    from pinthememory_amd import dist as D
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(6, 16, 5, 5, generator=g) * 3 + 1
+    xl = x[rank * 3:rank * 3 + 3]
+    n = xl.numel() // 16
+    mean = xl.mean((0, 2, 3))
+    m2 = ((xl - mean[None, :, None, None]) ** 2).sum((0, 2, 3))
+    mom = torch.cat([mean, m2, torch.full((16,), float(n))])
+    return D.merge_moments(mom, 16)
+
+
+def test_syncbn_moment_merge_equals_global_stats():
+    res = spawn(_c2)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(6, 16, 5, 5, generator=g) * 3 + 1
+    mean = x.mean((0, 2, 3))
+    m2 = ((x - mean[None, :, None, None]) ** 2).sum((0, 2, 3))
+    for r in range(2):
+        assert torch.allclose(res[r][:16], mean, atol=1e-6)
+        assert torch.allclose(res[r][16:32], m2, rtol=1e-5)
+        assert torch.all(res[r][32:] == 150)
+
+
+# ---- C1: bucketed gradient all-reduce ---------------------------------------------------------------------------------
+def _c1(rank, world):
+    from pinthememory_amd import dist as D
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 4, 1))
+    net[0].weight.data = net[0].weight.data.contiguous(memory_format=torch.channels_last)
+    buckets = D.GradBuckets(net.parameters(), bucket_bytes=64)           # tiny buckets -> several async all-reduces
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 3, 6, 6, generator=g)
+    out = []
+    for it in range(2):                                                  # two steps: zero() must reset the arena and the hooks
+        buckets.zero()
+        net(x[rank * 2:rank * 2 + 2] * (it + 1)).square().mean().backward()
+        buckets.finish()
+        out.append([p.grad.clone() for p in net.parameters()])
+    assert all(p.grad.data_ptr() >= buckets.flat.data_ptr() for p in net.parameters())
+    return out, len(buckets.buckets)
+
+
+def test_grad_buckets_average_equals_full_batch_grad():
+    res = spawn(_c1)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 4, 1))
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 3, 6, 6, generator=g)
+    assert res[0][1] > 1
+    for it in range(2):
+        net.zero_grad()
+        net(x * (it + 1)).square().mean().backward()                    # mean over 4 images == average of the two rank means
+        for r in range(2):
+            for p, got in zip(net.parameters(), res[r][0][it]):
+                assert torch.allclose(got, p.grad, atol=1e-6, rtol=1e-4)
+
+
+def test_single_process_is_a_noop():
+    from pinthememory_amd import dist as D
+    t = torch.arange(6.0)
+    assert D.all_reduce_sum(t.clone()).equal(t) and D.merge_moments(t, 2).equal(t) and D.group_size() == 1
+    assert D.all_reduce_sum_autograd(t) is t and D.bn_group(torch.nn.SyncBatchNorm(4)) is None
