@@ -65,10 +65,16 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs a GPU: the HIP path has no CPU fallback'
+    # one process per GPU; PM_BENCH_BACKEND=gloo lets two ranks share one GPU to rehearse the N > 1 code path on a 1-GPU box
+    backend = os.environ.get('PM_BENCH_BACKEND', 'nccl')
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend=backend)
     dev = torch.device('cuda', local)
 
     from pinthememory_amd import dist as D, harness, synth
@@ -121,6 +127,7 @@ def main():
                                          'launches_per_step': tot_n / a.steps}}
     if rank == 0:
         imgs = a.batch * world * a.steps
+        gf_img = STEP_GFLOP_PER_IMG * (a.size / 768.0) ** 2      # conv FLOPs scale with the pixel count
         out = {'metric': 'train imgs/sec 768x768 bs=8 R50-DeepLabV3+ +mem', 'value': round(imgs / dt, 3), 'unit': 'imgs/sec', 'n_gpus': world,
                'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
                'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
@@ -128,8 +135,8 @@ def main():
                                       '(fwd + bwd + SGD + eval-mode memory-commit fwd%s)' % (a.batch, a.size, a.size,
                                                                                             ', decoder skipped in the commit fwd' if a.truncate_second_forward else ''),
                           'global_batch': a.batch * world, 'crop': a.size, 'parallelism': 'dp%d' % world,
-                          'conv_tflop_per_step': round(STEP_GFLOP_PER_IMG * a.batch / 1e3, 3),
-                          'step_mfma_frac': round(STEP_GFLOP_PER_IMG * a.batch * world * a.steps / 1e3 / dt / (PEAK_TFLOPS_F32_MFMA * world), 4),
+                          'conv_tflop_per_step': round(gf_img * a.batch / 1e3, 3),
+                          'step_mfma_frac': round(gf_img * a.batch * world * a.steps / 1e3 / dt / (PEAK_TFLOPS_F32_MFMA * world), 4),
                           'final_loss': round(float(losses['total']), 5)},
                'roofline': roof}
         if not a.no_cpu_baseline and world == 1:
