@@ -350,11 +350,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-  auto compute = [&](int buf) {
+  auto compute_kg = [&](int buf, int kg) {
     const float* As = smem + buf * STAGE;
     const float* Bs = As + A_FLOATS;
-#pragma unroll
-    for (int kg = 0; kg < BK / 8; ++kg) {
+    {
       const int kk = kg * 8 + half * 4;  // this lane-half's 4 consecutive k of the 8-k group
       float fa[TM][4], fb[TN][4];
 #pragma unroll
@@ -388,6 +387,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
             acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[n][j], acc[i][n], 0, 0, 0);
     }
   };
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int kg = 0; kg < BK / 8; ++kg) compute_kg(buf, kg);
+  };
 
   // ---- main loop: the gathers of slab kt+1 are issued (branch-free) ahead of the MFMAs of slab kt, whose 4096 matrix-pipe
   // cycles cover the load latency; LDS is double-buffered, one barrier per K-step ----------------------------------------
@@ -397,10 +400,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
     store_tiles(0);
     __syncthreads();
     for (int kt = 0; kt < nk - 1; ++kt) {
+      // Region 1: first k-group (fragment reads + TM*TN*4 MFMAs) with the whole gather of slab kt+1 (address VALU + the
+      // buffer loads) interleaved into the 64-cycle MFMA shadows, so the matrix pipe restarts right after the barrier.
+      compute_kg(kt & 1, 0);
       load_tiles(kt + 1);
-      __builtin_amdgcn_sched_barrier(0);  // keep the gathers ahead of the MFMAs: their latency hides under the whole slab
       advance();
-      compute(kt & 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, TM + TN + (A_KC ? 0 : 3 * TM) + (B_KC ? 0 : 3 * TN), 0);  // fragment DS reads
+#define PM_SG(I)                                                                   \
+      if constexpr (A_N + B_N > I) {                                                \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  /* 2 MFMA            */ \
+        __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);  /* <= 8 VALU / SALU  */ \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  /* 1 buffer load     */ \
+      }
+      PM_SG(0) PM_SG(1) PM_SG(2) PM_SG(3) PM_SG(4) PM_SG(5) PM_SG(6) PM_SG(7)
+#undef PM_SG
+      __builtin_amdgcn_sched_barrier(0);
+      // Region 2: the remaining three k-groups cover the load latency; then the LDS write of slab kt+1 and the barrier
+#pragma unroll
+      for (int kg = 1; kg < BK / 8; ++kg) compute_kg(kt & 1, kg);
       store_tiles((kt + 1) & 1);
       __syncthreads();
     }
