@@ -127,3 +127,57 @@ def miou(hist):                                       # utils/misc.py:152-168
     with np.errstate(divide='ignore', invalid='ignore'):
         iu = np.diag(hist) / (hist.sum(1) + hist.sum(0) - np.diag(hist))
     return float(np.nanmean(iu)), iu
+
+
+# ---- train_memory_mldg (train.py:493-632) with get_updated_network / put_theta (train.py:246-277) -------------------------
+def put_theta(model, theta):
+    """Rewire every leaf module's _parameters with the tensors in `theta` (non-leaf, still attached to the graph)."""
+    def walk(mod, name=None):
+        if len(mod._modules) != 0:
+            for k, v in mod._modules.items():
+                walk(v, str(k) if name is None else str(name + '.' + k))
+        else:
+            for k, v in mod._parameters.items():
+                if isinstance(v, torch.Tensor):
+                    mod._parameters[k] = theta[str(name + '.' + k)]
+    walk(model)
+    return model
+
+
+def get_updated_network(old, new, lr):
+    """theta' = theta - lr * grad for every parameter with a gradient (first-order: grad is a constant), buffers copied."""
+    sd, params = old.state_dict(), dict(old.named_parameters())
+    theta = {k: (params[k] - lr * params[k].grad if k in params and params[k].grad is not None else sd[k]) for k in sd}
+    return put_theta(new, theta)
+
+
+def mldg_train_step(net, updated_net, updated_net2, opt, x_tr, y_tr, x_te, y_te, inner_lr=0.01, sched=None):
+    """One iteration of train_memory_mldg for the memory configuration (no whitening). Returns inner/outer loss dicts."""
+    net.train()
+    mem_t = net.memory.m_items.clone().detach()
+    opt.zero_grad()
+    out_in = net(x_tr, gts=y_tr, aux_gts=y_tr, memory_writing=True, writing_detach=False)
+    inner = total_loss(out_in)
+    inner.backward(retain_graph=True)
+    updated_net = get_updated_network(net, updated_net, inner_lr).train()
+    updated_net2 = get_updated_network(net, updated_net2, inner_lr).train()
+    updated_net2.memory.m_items = mem_t
+    for k, v in updated_net2.named_parameters():               # freeze the encoder (train.py:549-552)
+        if k.split('.')[0] != 'memory':
+            v.detach_()
+            v.requires_grad_(False)
+    updated_net2(x_tr, gts=y_tr, aux_gts=y_tr, memory_writing=True, writing_detach=False)   # seen-domain memory write
+    updated_net.memory.m_items = updated_net2.memory.m_items.clone()
+    out_te = updated_net(x_te, gts=y_te, aux_gts=y_te, memory_writing=False)                # meta-test: read only
+    outer = out_te[0] + LOSS_W['aux'] * out_te[1] + LOSS_W['read'] * out_te[-2]            # writeloss is [0, 0]
+    outer.backward()
+    opt.step()
+    with torch.no_grad():
+        net.eval()
+        net.memory.m_items = mem_t
+        net(x_tr, gts=y_tr, aux_gts=y_tr, memory_writing=True)
+        net.train()
+    if sched is not None:
+        sched.step()
+    return dict(inner=inner.detach(), outer=outer.detach(), inner_loss1=out_in[0].detach(), outer_loss1=out_te[0].detach(),
+                outer_read=out_te[-2].detach())

@@ -148,6 +148,47 @@ def test_agg_train_step_vs_oracle_and_golden(env, golden):
     assert all(torch.equal(hip2['state'][k], hip['state'][k]) for k in hip['state'] if 'memory' not in k and 'running' not in k and 'tracked' not in k)
 
 
+def test_mldg_train_step_vs_oracle(env):
+    """the meta-learning step (functional weights via put_theta, frozen-encoder memory write, gradient
+    through the written memory into the meta-test read). Same criterion as the agg step: as close to an fp64 oracle as the
+    reference's fp32 arithmetic is."""
+    import copy
+    synth = env['synth']
+    x, y = synth.make_batch(4, 96)
+    # the deterministic weights give O(500) trunk gradients whose fp32 noise is percents (see _oracle): a small inner step keeps
+    # theta' = theta - lr*g out of the chaotic regime so that the mldg-specific paths can be compared tightly
+    INNER_LR = 1e-5
+
+    def run(kind, dtype=torch.float32):
+        if kind == 'hip':
+            net = synth.load_det_weights(env['deepv3plus'].DeepR50V3PlusD(synth.model_args(), 19, CRIT, CRIT)).cuda()
+            h, xx, yy = env['harness'], x.cuda(), y.cuda()
+        else:
+            net = synth.load_det_weights(env['o_deeplab'].DeepR50V3PlusD(synth.model_args(), 19, CRIT, CRIT)).to(dtype)
+            net.memory.m_items = net.memory.m_items.to(dtype)
+            h, xx, yy = env['o_harness'], x.to(dtype), y
+        net.dsn[3].p = 0.0
+        u1, u2 = copy.deepcopy(net), copy.deepcopy(net)
+        opt, _ = h.make_optimizer(net)
+        losses = h.mldg_train_step(net, u1, u2, opt, xx[:2], yy[:2], xx[2:], yy[2:], inner_lr=INNER_LR)
+        return dict(losses={k: v.double().cpu() for k, v in losses.items()}, state={k: v.detach().double().cpu() for k, v in net.state_dict().items()},
+                    grads={k: v.grad.detach().double().cpu() for k, v in net.named_parameters()}, m_items=net.memory.m_items.detach().double().cpu())
+    truth, o32, hip = run('oracle', torch.float64), run('oracle'), run('hip')
+    for k, t in truth['losses'].items():
+        assert abs(hip['losses'][k].item() - o32['losses'][k].item()) < 5e-4 * max(1, abs(t.item())), k
+        assert abs(hip['losses'][k].item() - t.item()) <= 3 * abs(o32['losses'][k].item() - t.item()) + 1e-4 * max(1, abs(t.item())), k
+    bad = _as_good_as_fp32(hip, o32, truth, 'grads', floor=1e-4)
+    assert not bad, bad[:8]
+    # gradient that reaches the write path ONLY through the written memory read at meta-test time (plus the inner step's own)
+    for k in ('memory.writenet.writefeat.0.weight', 'memory.clsfier.weight', 'memory.output.0.weight', 'final2.0.weight'):
+        e_h, e_o = _relerr(hip['grads'][k], truth['grads'][k]), _relerr(o32['grads'][k], truth['grads'][k])
+        assert e_h <= 1.5 * e_o + 1e-3, (k, e_h, e_o)       # even the fp32 reference is ~10 % off on the 1e-5-sized writenet gradient
+    bad = _as_good_as_fp32(hip, o32, truth, 'state', floor=2e-6)
+    assert not bad, bad[:8]
+    e_o = (o32['m_items'] - truth['m_items']).abs().max().item()
+    assert (hip['m_items'] - truth['m_items']).abs().max().item() <= 3 * e_o + 1e-6
+
+
 def test_memory_initialize_vs_golden(env, golden):
     synth = env['synth']
     net = synth.load_det_weights(env['deepv3plus'].DeepR50V3PlusD(synth.model_args(), 19, CRIT, CRIT)).cuda()

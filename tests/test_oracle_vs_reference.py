@@ -64,3 +64,22 @@ def test_agg_train_step_bit_equal(refmods):
     assert all(torch.equal(gr[k].grad, gm[k].grad) for k in gr)
     sr, sm = ref.state_dict(), mine.state_dict()
     assert all(torch.equal(sr[k], sm[k]) for k in sr)
+
+
+def test_mldg_train_step_bit_equal(refmods):
+    """train_memory_mldg semantics (train.py:493-632) restated in oracle.ref_cpu.harness, driven on the reference's own
+    model classes vs the oracle's: identical losses, memory, gradients and post-step parameters."""
+    import copy
+    ref, mine = _pair(refmods, 'v3')
+    synth.load_det_weights(ref), synth.load_det_weights(mine)
+    ref.dsn[3].p = mine.dsn[3].p = 0.0
+    x, y = synth.make_batch(4, 96)
+    res = []
+    for net in (ref, mine):
+        u1, u2 = copy.deepcopy(net), copy.deepcopy(net)
+        opt, _ = harness.make_optimizer(net)
+        res.append(harness.mldg_train_step(net, u1, u2, opt, x[:2], y[:2], x[2:], y[2:]))
+    assert all(torch.equal(res[0][k], res[1][k]) for k in res[0])
+    assert torch.equal(ref.memory.m_items, mine.memory.m_items)
+    sr, sm = ref.state_dict(), mine.state_dict()
+    assert all(torch.equal(sr[k], sm[k]) for k in sr)
