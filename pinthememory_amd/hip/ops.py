@@ -50,6 +50,78 @@ class BNState:
             bn.num_batches_tracked.add_(1)
 
 
+def _bn_train_fwd(y, gamma, beta, bn, residual, relu, out=None):
+    """Batch statistics (merged across ranks for SyncBN) -> normalise + residual + ReLU. Returns (o, mean, invstd)."""
+    c = y.shape[3]
+    mom = K.bn_stats(y)
+    if bn.group is not None:
+        mom = D.merge_moments(mom, c, bn.group)
+    mean, invstd = K.bn_finalize(mom, c, bn.eps, bn.running_mean, bn.running_var, bn.momentum)
+    return K.bn_apply(y, mean, invstd, gamma, beta, residual=residual, relu=relu, out=out), mean, invstd
+
+
+def _bn_train_bwd(dv, o, y, mean, invstd, gamma, relu, group, want_dres):
+    """-> (dy, dres, dgamma, dbeta): gradient of the conv output, of the residual input, and of the affine parameters."""
+    c = y.shape[3]
+    sums = K.bn_bwd_reduce(dv, o, y, mean, invstd, relu)
+    if group is not None:
+        sums = D.all_reduce_sum(sums, group)
+    count = float(y.shape[0] * y.shape[1] * y.shape[2]) * (D.group_size(group) if group is not None else 1)
+    dy, dres = K.bn_bwd_apply(dv, o, y, mean, invstd, gamma, sums, count, relu, want_dres)
+    return dy, dres, sums[c:], sums[:c]
+
+
+class _Bottleneck(torch.autograd.Function):
+    """One ResNet Bottleneck (Resnet.py:181-216) as a single autograd node in train mode: the gradient of the block input is
+    produced by conv1's dgrad with the skip-path gradient fused in (`add`), so autograd never launches a separate add, and the
+    16 blocks cost 16 nodes instead of ~60."""
+
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, w3, g3, b3, wd, gd, bd, geoms, bns):
+        xv = nhwc(x)
+        k1, k2, k3 = K.krsc(w1), K.krsc(w2), K.krsc(w3)
+        y1 = K.conv_fwd(xv, k1, *geoms[0])
+        o1, m1, i1 = _bn_train_fwd(y1, g1, b1, bns[0], None, True)
+        y2 = K.conv_fwd(o1, k2, *geoms[1])
+        o2, m2, i2 = _bn_train_fwd(y2, g2, b2, bns[1], None, True)
+        y3 = K.conv_fwd(o2, k3, *geoms[2])
+        if wd is not None:
+            kd = K.krsc(wd)
+            yd = K.conv_fwd(xv, kd, *geoms[3])
+            res, md, idd = _bn_train_fwd(yd, gd, bd, bns[3], None, False)
+        else:
+            kd = yd = md = idd = None
+            res = xv
+        out, m3, i3 = _bn_train_fwd(y3, g3, b3, bns[2], res, True)
+        ctx.geoms, ctx.groups, ctx.has_ds = geoms, [b.group for b in bns], wd is not None
+        ctx.save_for_backward(xv, k1, k2, k3, kd, y1, o1, y2, o2, y3, yd, out, m1, i1, m2, i2, m3, i3, md, idd, g1, g2, g3, gd)
+        return nchw(out)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xv, k1, k2, k3, kd, y1, o1, y2, o2, y3, yd, out, m1, i1, m2, i2, m3, i3, md, idd, g1, g2, g3, gd = ctx.saved_tensors
+        ge, gr = ctx.geoms, ctx.groups
+        dv = _grad_view(dout)
+        dy3, dres, dg3, db3 = _bn_train_bwd(dv, out, y3, m3, i3, g3, True, gr[2], True)
+        dw3, _ = K.conv_bwd_weight(o2, dy3, tuple(k3.shape), *ge[2])
+        do2 = K.conv_bwd_data(dy3, k3, tuple(o2.shape), *ge[2])
+        dy2, _, dg2, db2 = _bn_train_bwd(do2, o2, y2, m2, i2, g2, True, gr[1], False)
+        dw2, _ = K.conv_bwd_weight(o1, dy2, tuple(k2.shape), *ge[1])
+        do1 = K.conv_bwd_data(dy2, k2, tuple(o1.shape), *ge[1])
+        dy1, _, dg1, db1 = _bn_train_bwd(do1, o1, y1, m1, i1, g1, True, gr[0], False)
+        dw1, _ = K.conv_bwd_weight(xv, dy1, tuple(k1.shape), *ge[0])
+        dwd = dgd = dbd = None
+        skip = dres
+        if ctx.has_ds:
+            dyd, _, dgd, dbd = _bn_train_bwd(dres, None, yd, md, idd, gd, False, gr[3], False)
+            dwdk, _ = K.conv_bwd_weight(xv, dyd, tuple(kd.shape), *ge[3])
+            dwd = dwdk.permute(0, 3, 1, 2)
+            skip = K.conv_bwd_data(dyd, kd, tuple(xv.shape), *ge[3]) if ctx.needs_input_grad[0] else None
+        dx = nchw(K.conv_bwd_data(dy1, k1, tuple(xv.shape), *ge[0], add=skip)) if ctx.needs_input_grad[0] else None
+        p = lambda d: d.permute(0, 3, 1, 2)
+        return dx, p(dw1), dg1, db1, p(dw2), dg2, db2, p(dw3), dg3, db3, dwd, dgd, dbd, None, None
+
+
 class _ConvBnAct(torch.autograd.Function):
     """conv -> BatchNorm(train: batch statistics | eval: folded into the conv epilogue) -> (+residual) -> ReLU.
     Replaces e.g. Resnet.py:195-216 conv/bn/relu triples and every Sequential(Conv2d, Norm2d, ReLU) of deepv3plus.py."""
@@ -66,12 +138,7 @@ class _ConvBnAct(torch.autograd.Function):
             o = K.conv_fwd(xv, wk, stride, pad, dil, scale=scale, shift=shift, residual=rv, relu=relu, out=ov)
             return nchw(o)
         y = K.conv_fwd(xv, wk, stride, pad, dil, bias=bias)
-        c = y.shape[3]
-        mom = K.bn_stats(y)
-        if bn.group is not None:
-            mom = D.merge_moments(mom, c, bn.group)
-        mean, invstd = K.bn_finalize(mom, c, bn.eps, bn.running_mean, bn.running_var, bn.momentum)
-        o = K.bn_apply(y, mean, invstd, gamma, beta, residual=rv, relu=relu, out=ov)
+        o, mean, invstd = _bn_train_fwd(y, gamma, beta, bn, rv, relu, ov)
         ctx.group, ctx.has_bias, ctx.has_res = bn.group, bias is not None, residual is not None
         ctx.save_for_backward(xv, wk, y, o, mean, invstd, gamma)
         return nchw(o)
@@ -83,18 +150,13 @@ class _ConvBnAct(torch.autograd.Function):
         xv, wk, y, o, mean, invstd, gamma = ctx.saved_tensors
         stride, pad, dil = ctx.geom
         dv = _grad_view(dout)
-        c = y.shape[3]
-        sums = K.bn_bwd_reduce(dv, o, y, mean, invstd, ctx.relu)
-        if ctx.group is not None:
-            sums = D.all_reduce_sum(sums, ctx.group)
-        count = float(y.shape[0] * y.shape[1] * y.shape[2]) * (D.group_size(ctx.group) if ctx.group is not None else 1)
-        dy, dres = K.bn_bwd_apply(dv, o, y, mean, invstd, gamma, sums, count, ctx.relu, ctx.has_res and ctx.needs_input_grad[5])
+        dy, dres, dgamma, dbeta = _bn_train_bwd(dv, o, y, mean, invstd, gamma, ctx.relu, ctx.group, ctx.has_res and ctx.needs_input_grad[5])
         dx = nchw(K.conv_bwd_data(dy, wk, tuple(xv.shape), stride, pad, dil)) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dwk, db = K.conv_bwd_weight(xv, dy, tuple(wk.shape), stride, pad, dil, want_bias=ctx.has_bias)
             dw = dwk.permute(0, 3, 1, 2)
-        return dx, dw, db, sums[c:], sums[:c], (nchw(dres) if dres is not None else None), None, None, None, None
+        return dx, dw, db, dgamma, dbeta, (nchw(dres) if dres is not None else None), None, None, None, None
 
 
 class _Conv(torch.autograd.Function):
@@ -278,6 +340,17 @@ def _geom(conv):
 
 def conv_bn_act(x, conv, bn, relu=True, residual=None, out=None):
     return _ConvBnAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, residual, _geom(conv), BNState(bn), relu, out)
+
+
+def bottleneck(x, blk):
+    """Whole Bottleneck as one autograd node (train mode with gradients); eval / no-grad keeps the fused-epilogue per-conv path."""
+    ds = blk.downsample
+    mods = [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2), (blk.conv3, blk.bn3)] + ([(ds[0], ds[1])] if ds is not None else [])
+    geoms = [_geom(c) for c, _ in mods]
+    bns = [BNState(b) for _, b in mods]
+    wd, gd, bd = (ds[0].weight, ds[1].weight, ds[1].bias) if ds is not None else (None, None, None)
+    return _Bottleneck.apply(x, blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight, blk.bn2.weight, blk.bn2.bias,
+                             blk.conv3.weight, blk.bn3.weight, blk.bn3.bias, wd, gd, bd, geoms, bns)
 
 
 def conv(x, conv_mod):

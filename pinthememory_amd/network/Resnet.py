@@ -1,6 +1,7 @@
 """ResNet-50/101 trunk whose forward runs on the HIP kernels. Mirrors the class surface and state_dict layout of
 /root/reference/network/Resnet.py (Bottleneck :137-216 with its [x, w_arr] list protocol, ResNet :395-495,
 resnet50/resnet101 :527-559); only the whitening-free (iw = 0) path exists."""
+import torch
 import torch.nn as nn
 
 from . import mynn
@@ -31,6 +32,8 @@ class Bottleneck(nn.Module):
             print("error!!!")
             return
         x, w_arr = x_tuple
+        if self.training and torch.is_grad_enabled() and all(c.bias is None for c in (self.conv1, self.conv2, self.conv3)):
+            return [ops.bottleneck(x, self), w_arr]
         out = ops.conv_bn_act(x, self.conv1, self.bn1, relu=True)
         out = ops.conv_bn_act(out, self.conv2, self.bn2, relu=True)
         residual = x if self.downsample is None else ops.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
