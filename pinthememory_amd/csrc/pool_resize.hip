@@ -134,10 +134,14 @@ __device__ __forceinline__ void support(float scale, int i, int out, int& lo, in
 }
 __device__ __forceinline__ float tap_weight(const pm_lerp& l, int i) { return (l.i0 == i ? l.w0 : 0.f) + (l.i1 == i ? l.w1 : 0.f); }
 
+// Gather formulation: each input pixel sums the output pixels whose bilinear taps touch it. The per-row / per-column tap
+// weights of the (small) support window are computed once into registers (MAXT x 2), so the inner loops are pure
+// load + FMA; windows larger than MAXT (e.g. the 1x1 -> HxW broadcast of the ASPP image feature) take the generic loop.
 template <bool VEC>
 __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict__ dy, long dp, int H, int W, float* __restrict__ dx, long xp, int h, int w,
                                                          int C, long total, float sy, float sx, int accumulate) {
   constexpr int V = VEC ? 4 : 1;
+  constexpr int MAXT = 14;
   const int cg = C / V;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long ip = i / cg;
@@ -149,20 +153,47 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict
     float g[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) g[e] = 0.f;
-    for (int Y = ylo; Y <= yhi; ++Y) {
-      const float wy = tap_weight(pm_ac_lerp(sy, Y, h), y);
-      if (wy == 0.f) continue;
-      for (int X = xlo; X <= xhi; ++X) {
-        const float wx = tap_weight(pm_ac_lerp(sx, X, w), x);
-        if (wx == 0.f) continue;
-        const float* p = dy + ((long)(n * H + Y) * W + X) * dp + ch;
-        const float ww = wy * wx;
-        if constexpr (VEC) {
-          const float4 q = PM_LD4(p);
-          g[0] += ww * q.x;
-          if (V > 1) g[1 % V] += ww * q.y, g[2 % V] += ww * q.z, g[3 % V] += ww * q.w;
-        } else {
-          g[0] += ww * *p;
+    if (yhi - ylo < MAXT && xhi - xlo < MAXT) {
+      float wyv[MAXT], wxv[MAXT];
+#pragma unroll
+      for (int k = 0; k < MAXT; ++k) {
+        wyv[k] = ylo + k <= yhi ? tap_weight(pm_ac_lerp(sy, ylo + k, h), y) : 0.f;
+        wxv[k] = xlo + k <= xhi ? tap_weight(pm_ac_lerp(sx, xlo + k, w), x) : 0.f;
+      }
+      const float* base = dy + ((long)(n * H + ylo) * W + xlo) * dp + ch;
+#pragma unroll
+      for (int k = 0; k < MAXT; ++k) {
+        if (wyv[k] == 0.f) continue;
+#pragma unroll
+        for (int l = 0; l < MAXT; ++l) {
+          if (wxv[l] == 0.f) continue;
+          const float* p = base + ((long)k * W + l) * dp;
+          const float ww = wyv[k] * wxv[l];
+          if constexpr (VEC) {
+            const float4 q = PM_LD4(p);
+            g[0] += ww * q.x;
+            if (V > 1) g[1 % V] += ww * q.y, g[2 % V] += ww * q.z, g[3 % V] += ww * q.w;
+          } else {
+            g[0] += ww * *p;
+          }
+        }
+      }
+    } else {
+      for (int Y = ylo; Y <= yhi; ++Y) {
+        const float wy = tap_weight(pm_ac_lerp(sy, Y, h), y);
+        if (wy == 0.f) continue;
+        for (int X = xlo; X <= xhi; ++X) {
+          const float wx = tap_weight(pm_ac_lerp(sx, X, w), x);
+          if (wx == 0.f) continue;
+          const float* p = dy + ((long)(n * H + Y) * W + X) * dp + ch;
+          const float ww = wy * wx;
+          if constexpr (VEC) {
+            const float4 q = PM_LD4(p);
+            g[0] += ww * q.x;
+            if (V > 1) g[1 % V] += ww * q.y, g[2 % V] += ww * q.z, g[3 % V] += ww * q.w;
+          } else {
+            g[0] += ww * *p;
+          }
         }
       }
     }
