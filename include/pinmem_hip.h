@@ -61,15 +61,18 @@ int pm_conv_bwd_weight(const pm_tensor* x, const pm_tensor* dy, float* dw_krsc, 
 
 /* In-library HIP-event timing of the implicit-GEMM kernel (bench.py's roofline leg). While enabled every conv launch is
  * bracketed by two events on its stream; pm_profile_read sums duration and algorithmic FLOPs (2*M*N*K) of one
- * instantiation (mode 0/1/2, N-tile 128/64/32; negative / zero = any) and optionally clears the records. */
+ * instantiation conv_igemm_kernel<mode, bm, bn, .., km> (mode 0 fwd / 1 dgrad / 2 wgrad, block tile bm x bn, K-state variant
+ * km 0 fast / 1 mid / 2 small; negative = any) and optionally clears the records. */
 int pm_profile_enable(int on);
-int pm_profile_read(int mode, int bn, double* total_ms, double* total_flops, int64_t* launches, int clear);
+int pm_profile_read(int mode, int bm, int bn, int km, double* total_ms, double* total_flops, int64_t* launches, int clear);
 
 /* ---- K4 BatchNorm2d (mynn.py:8-14 -> nn.BatchNorm2d / SyncBatchNorm, eps 1e-5, momentum 0.1) -------------------
  * stats: per-channel shifted sums -> (count, mean, M2) so that ranks can be merged exactly (SyncBN, train.py:95).
  * moments layout: float[3*C] = mean[C] | m2[C] | count (replicated [C]). */
 size_t pm_bn_workspace(const pm_tensor* x);
 int pm_bn_stats(const pm_tensor* x, float* moments, void* ws, size_t ws_bytes, void* stream);
+/* SyncBatchNorm (train.py:95): exact merge of the per-rank moments gathered over the process group, parts = float[world][3*C] */
+int pm_bn_merge(const float* parts, int world, int c, float* moments, void* stream);
 /* mean/var(biased) -> invstd; optionally updates running stats (unbiased var), momentum as torch. */
 int pm_bn_finalize(const float* moments, int c, float eps, float* mean, float* invstd,
                    float* running_mean, float* running_var, float momentum, void* stream);

@@ -127,6 +127,24 @@ __global__ __launch_bounds__(256) void bn_bwd_final(const float* __restrict__ pa
   sums[C + c] = (float)s2;
 }
 
+// Chan et al. merge of per-rank (mean | M2 | count) rows gathered over the process group: [W][3C] -> [3C], in double.
+__global__ void bn_merge_kernel(const float* __restrict__ parts, int W, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double n = 0.0, s = 0.0;
+  for (int r = 0; r < W; ++r) {
+    const double cnt = parts[(long)r * 3 * C + 2 * C + c];
+    n += cnt, s += cnt * (double)parts[(long)r * 3 * C + c];
+  }
+  const double mean = s / n;
+  double m2 = 0.0;
+  for (int r = 0; r < W; ++r) {
+    const double cnt = parts[(long)r * 3 * C + 2 * C + c], d = (double)parts[(long)r * 3 * C + c] - mean;
+    m2 += (double)parts[(long)r * 3 * C + C + c] + cnt * d * d;
+  }
+  out[c] = (float)mean, out[C + c] = (float)m2, out[2 * C + c] = (float)n;
+}
+
 __global__ void bn_fold_kernel(const float* __restrict__ g, const float* __restrict__ b, const float* __restrict__ rm, const float* __restrict__ rv,
                                const float* __restrict__ cb, int C, float eps, float* __restrict__ scale, float* __restrict__ shift) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -167,6 +185,12 @@ extern "C" int pm_bn_finalize(const float* moments, int c, float eps, float* mea
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(pm_cdiv(c, 64)), dim3(64), 0, (hipStream_t)stream, moments, c, eps, mean, invstd, running_mean, running_var,
                      momentum);
   return pm_check_launch("bn_finalize");
+}
+
+extern "C" int pm_bn_merge(const float* parts, int world, int c, float* moments, void* stream) {
+  PM_REQUIRE(parts && moments && world >= 1 && c > 0, PM_EINVAL, "bn_merge: bad args");
+  hipLaunchKernelGGL(bn_merge_kernel, dim3(pm_cdiv(c, 64)), dim3(64), 0, (hipStream_t)stream, parts, world, c, moments);
+  return pm_check_launch("bn_merge");
 }
 
 extern "C" int pm_bn_fold(const float* gamma, const float* beta, const float* rm, const float* rv, const float* conv_bias, int c, float eps, float* scale,

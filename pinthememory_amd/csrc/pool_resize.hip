@@ -73,7 +73,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
 }
 
 // ---------------- global average pool ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ x, long xp, long HW, int C, float* __restrict__ y, long yp) {
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ x, long xp, long HW, int C, float* __restrict__ y, long yp, float scale,
+                                                      int accumulate) {
   __shared__ float sm[16][64];
   const int g = threadIdx.x & 15, r = threadIdx.x >> 4;
   const int c = blockIdx.y * 64 + g * 4, n = blockIdx.x;
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < 16; ++i) t += sm[i][threadIdx.x];
     const int ch = blockIdx.y * 64 + threadIdx.x;
-    if (ch < C) y[(long)n * yp + ch] = t / (float)HW;
+    if (ch < C) y[(long)n * yp + ch] = (accumulate ? y[(long)n * yp + ch] : 0.f) + t * scale;
   }
 }
 
@@ -232,7 +233,7 @@ extern "C" int pm_maxpool3x3s2_bwd(const pm_tensor* dy, const uint8_t* argmax, c
 extern "C" int pm_global_avgpool_fwd(const pm_tensor* x, const pm_tensor* y, void* stream) {
   PM_REQUIRE(x && y && pm_vec4(x) && y->ptr && y->h == 1 && y->w == 1 && y->n == x->n && y->c == x->c, PM_EINVAL, "global_avgpool_fwd: bad args");
   hipLaunchKernelGGL(gap_fwd_kernel, dim3(x->n, pm_cdiv(x->c, 64)), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr, (long)x->pitch,
-                     (long)x->h * x->w, x->c, (float*)y->ptr, (long)y->pitch);
+                     (long)x->h * x->w, x->c, (float*)y->ptr, (long)y->pitch, 1.f / (float)((long)x->h * x->w), 0);
   return pm_check_launch("global_avgpool_fwd");
 }
 
@@ -267,6 +268,11 @@ extern "C" int pm_resize_bilinear_fwd(const pm_tensor* x, const pm_tensor* y, vo
 extern "C" int pm_resize_bilinear_bwd(const pm_tensor* dy, const pm_tensor* dx, int accumulate, void* stream) {
   PM_REQUIRE(dy && dx && dy->ptr && dx->ptr && dy->n == dx->n && dy->c == dx->c, PM_EINVAL, "resize_bwd: bad args");
   const bool v = pm_vec4(dy) && pm_vec4(dx);
+  if (dx->h == 1 && dx->w == 1 && v) {  // 1x1 source (ASPP image feature): every output pixel has weight 1 -> a plain column sum
+    hipLaunchKernelGGL(gap_fwd_kernel, dim3(dy->n, pm_cdiv(dy->c, 64)), dim3(256), 0, (hipStream_t)stream, (const float*)dy->ptr, (long)dy->pitch,
+                       (long)dy->h * dy->w, dy->c, (float*)dx->ptr, (long)dx->pitch, 1.f, accumulate);
+    return pm_check_launch("resize_bwd(1x1)");
+  }
   const long total = pm_pixels(dx) * (v ? dx->c / 4 : dx->c);
   const float sy = pm_ac_scale(dx->h, dy->h), sx = pm_ac_scale(dx->w, dy->w);
   if (v)

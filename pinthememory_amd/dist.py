@@ -46,11 +46,16 @@ def merge_moments_list(parts, c):
 
 
 def merge_moments(mom, c, group=None):
+    """One all-gather of [3c] floats per BN layer, then one merge kernel (GPU) / a few torch ops (CPU tensors in the gloo tests)."""
     if not is_dist():
         return mom
-    parts = [torch.empty_like(mom) for _ in range(dist.get_world_size(group))]
-    dist.all_gather(parts, mom.contiguous(), group=group)
-    return merge_moments_list(parts, c)
+    world = dist.get_world_size(group)
+    flat = torch.empty(world * mom.numel(), dtype=mom.dtype, device=mom.device)
+    dist.all_gather_into_tensor(flat, mom.contiguous(), group=group)
+    if mom.is_cuda:
+        from .hip import kernels as K
+        return K.bn_merge(flat, world, c)
+    return merge_moments_list(list(flat.view(world, -1)), c)
 
 
 class _AllReduceSum(torch.autograd.Function):

@@ -89,6 +89,13 @@ def bn_stats(x):
     return mom
 
 
+def bn_merge(parts, world, c):
+    """parts: float[world, 3c] gathered per-rank moments -> merged float[3c]."""
+    out = torch.empty(3 * c, dtype=torch.float32, device=parts.device)
+    check(_lib().pm_bn_merge(parts.data_ptr(), world, c, out.data_ptr(), stream()), 'pm_bn_merge')
+    return out
+
+
 def bn_finalize(moments, c, eps, running_mean=None, running_var=None, momentum=0.1):
     mean = torch.empty(c, dtype=torch.float32, device=moments.device)
     invstd = torch.empty_like(mean)
@@ -312,9 +319,9 @@ def profile_enable(on):
     check(_lib().pm_profile_enable(1 if on else 0), 'pm_profile_enable')
 
 
-def profile_read(mode=-1, bn=0, clear=False):
-    """-> (total_ms, total_flops, launches) of the conv implicit-GEMM launches recorded since the last clear."""
+def profile_read(mode=-1, bm=-1, bn=-1, km=-1, clear=False):
+    """-> (total_ms, total_flops, launches) of the conv_igemm_kernel<mode, bm, bn, .., km> launches recorded since the last clear."""
     import ctypes
     ms, fl, n = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int64(0)
-    check(_lib().pm_profile_read(mode, bn, byref(ms), byref(fl), byref(n), 1 if clear else 0), 'pm_profile_read')
+    check(_lib().pm_profile_read(mode, bm, bn, km, byref(ms), byref(fl), byref(n), 1 if clear else 0), 'pm_profile_read')
     return ms.value, fl.value, n.value

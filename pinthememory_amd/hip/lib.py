@@ -39,9 +39,10 @@ SIGNATURES = {
     'pm_conv_bwd_data': (_i, [_T, _vp, _T, _P, _T, _vp, _sz, _vp]),
     'pm_conv_bwd_weight': (_i, [_T, _T, _vp, _vp, _P, _vp, _sz, _vp]),
     'pm_profile_enable': (_i, [_i]),
-    'pm_profile_read': (_i, [_i, _i, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64), _i]),
+    'pm_profile_read': (_i, [_i, _i, _i, _i, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64), _i]),
     'pm_bn_workspace': (_sz, [_T]),
     'pm_bn_stats': (_i, [_T, _vp, _vp, _sz, _vp]),
+    'pm_bn_merge': (_i, [_vp, _i, _i, _vp, _vp]),
     'pm_bn_finalize': (_i, [_vp, _i, _f, _vp, _vp, _vp, _vp, _f, _vp]),
     'pm_bn_fold': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp]),
     'pm_bn_apply': (_i, [_T, _vp, _vp, _vp, _vp, _T, _i, _T, _vp]),

@@ -278,3 +278,18 @@ def test_sgd(K):
         opt.step()
         K.sgd_momentum(pg, (g * (it + 1)).cuda(), buf, 0.01, 0.9, 5e-4, it == 0)
     assert rel(pg, pr.detach()) < 1e-6
+
+
+def test_bn_merge(K):
+    """SyncBN moment merge kernel == the host formula used by the gloo tests == statistics of the concatenated batch."""
+    from pinthememory_amd import dist as D
+    c = 48
+    x = rnd(6, c, 7, 5, seed=1) * 2 + 1
+    parts = []
+    for r in range(3):
+        xl = x[r * 2:r * 2 + 2]
+        mean = xl.mean((0, 2, 3))
+        parts.append(torch.cat([mean, ((xl - mean[None, :, None, None]) ** 2).sum((0, 2, 3)), torch.full((c,), float(xl.numel() // c))]))
+    got = K.bn_merge(torch.stack(parts).cuda().contiguous(), 3, c).cpu()
+    assert rel(got, D.merge_moments_list(parts, c)) < 1e-6
+    assert rel(got[:c], x.mean((0, 2, 3))) < 1e-6 and rel(got[c:2 * c], ((x - x.mean((0, 2, 3))[None, :, None, None]) ** 2).sum((0, 2, 3))) < 1e-5
