@@ -21,6 +21,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS_F32_MFMA = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_TFLOPS_BF16_MFMA = 2500.0        # same guide: bf16 MFMA dense peak (never the 2:1-sparsity figure)
 STEP_GFLOP_PER_IMG = 1311.8            # train fwd 334.16 + bwd 665.55 + eval-mode 2nd fwd 312.07
 
 
@@ -36,6 +37,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=2)
     ap.add_argument('--no-profile', action='store_true', help='do not bracket conv launches with HIP events')
+    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
+                    help='f32 = BASELINE configs[1] (the metric; default). bf16 = configs[2]: conv operands rounded to bf16 for the bf16 MFMA, fp32 accumulate/storage')
     return ap.parse_args()
 
 
@@ -81,6 +84,8 @@ def main():
     from pinthememory_amd.hip import kernels as K
     from pinthememory_amd.network import deepv3plus, mynn
     crit = torch.nn.CrossEntropyLoss(reduction='mean', ignore_index=255)
+    K.set_conv_precision(a.dtype)
+    peak = PEAK_TFLOPS_BF16_MFMA if a.dtype == 'bf16' else PEAK_TFLOPS_F32_MFMA
     if world > 1:
         mynn.set_bnfunc(torch.nn.SyncBatchNorm)        # train.py:95 converts to SyncBN under DDP
     net = synth.load_det_weights(deepv3plus.DeepR50V3PlusD(synth.model_args(gumbel_off=False), 19, crit, crit)).to(dev)
@@ -120,8 +125,8 @@ def main():
         tot_ms, tot_fl, tot_n = K.profile_read(clear=True)
         if n:
             ach = fl / (ms * 1e-3) / 1e12
-            roof = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<0, 128, 128, 2, 2, 0> (forward, 128x128x32 tile, v_mfma_f32_32x32x2_f32)', 'achieved': round(ach, 2),
-                    'peak': PEAK_TFLOPS_F32_MFMA, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_TFLOPS_F32_MFMA, 4), 'traffic': None,
+            roof = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<0, 128, 128, 2, 2, 0, %d> (forward, 128x128x32 tile, %s)' % (1 if a.dtype == 'bf16' else 0, 'v_mfma_f32_32x32x16_bf16' if a.dtype == 'bf16' else 'v_mfma_f32_32x32x2_f32'), 'achieved': round(ach, 2),
+                    'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': None,
                     'launches_per_step': n / a.steps, 'avg_launch_ms': round(ms / n, 5), 'gflop_per_launch': round(fl / n / 1e9, 3),
                     'all_conv_kernels': {'achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), 'ms_per_step': round(tot_ms / a.steps, 3),
                                          'launches_per_step': tot_n / a.steps}}
@@ -130,13 +135,14 @@ def main():
         gf_img = STEP_GFLOP_PER_IMG * (a.size / 768.0) ** 2      # conv FLOPs scale with the pixel count
         out = {'metric': 'train imgs/sec 768x768 bs=8 R50-DeepLabV3+ +mem', 'value': round(imgs / dt, 3), 'unit': 'imgs/sec', 'n_gpus': world,
                'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-               'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-               'config': {'workload': 'configs[1]: ResNet-50 DeepLabV3+ + memory, bs=%d/GPU %dx%d synthetic, fp32 reference-faithful agg train step '
-                                      '(fwd + bwd + SGD + eval-mode memory-commit fwd%s)' % (a.batch, a.size, a.size,
+               'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+               'config': {'workload': '%s: ResNet-50 DeepLabV3+ + memory, bs=%d/GPU %dx%d synthetic, %s reference-faithful agg train step '
+                                      '(fwd + bwd + SGD + eval-mode memory-commit fwd%s)' % ('configs[2]' if a.dtype == 'bf16' else 'configs[1]', a.batch, a.size, a.size,
+                                                                                            'bf16-MFMA (fp32 accumulate/storage)' if a.dtype == 'bf16' else 'fp32',
                                                                                             ', decoder skipped in the commit fwd' if a.truncate_second_forward else ''),
                           'global_batch': a.batch * world, 'crop': a.size, 'parallelism': 'dp%d' % world,
                           'conv_tflop_per_step': round(gf_img * a.batch / 1e3, 3),
-                          'step_mfma_frac': round(gf_img * a.batch * world * a.steps / 1e3 / dt / (PEAK_TFLOPS_F32_MFMA * world), 4),
+                          'step_mfma_frac': round(gf_img * a.batch * world * a.steps / 1e3 / dt / (peak * world), 4),
                           'final_loss': round(float(losses['total']), 5)},
                'roofline': roof}
         if not a.no_cpu_baseline and world == 1:

@@ -31,6 +31,8 @@ typedef struct pm_tensor {      /* NHWC fp32 activation view */
 
 typedef struct pm_conv_params { /* nn.Conv2d geometry (square kernels/strides as used by the reference) */
   int32_t kh, kw, stride, pad, dil;
+  int32_t prec;                 /* 0: fp32 MFMA (exact fp32 chain, parity path); 1: operands rounded to bf16 for
+                                   v_mfma_f32_32x32x16_bf16, fp32 accumulate and storage (BASELINE configs[2]) */
 } pm_conv_params;
 
 typedef struct pm_conv_epilogue { /* optional fused epilogue of pm_conv_fwd; all pointers may be NULL */

@@ -15,6 +15,7 @@
 #include "pm_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -38,6 +39,7 @@ struct ConvK {
   int tiles_m, tiles_n;
   unsigned a_bytes, b_bytes;  // extents of the A / B buffers (buffer-descriptor range)
   int kmode;                  // K_FAST / K_MID / K_SMALL: how the gather's K-state advances (see the kernel)
+  int prec;                   // 0 fp32 MFMA, 1 bf16 MFMA operands (fp32 storage and accumulation)
   const float* bias;
   const float* scale;
   const float* shift;
@@ -73,7 +75,10 @@ enum { K_FAST = 0, K_MID = 1, K_SMALL = 2 };
 // Thread -> tile element mapping (256 threads, g = t & 7, r = t >> 3):
 //   k-contiguous (KC) tiles [rows][LDK]: thread owns k-group g (4 floats) of rows r + 32*i   -> 1 K-state, static rows
 //   m-contiguous (MC) tiles [BK][cols] : thread owns k-row r, column groups (g + 8*j) * 4      -> 1 K-state, static cols
-template <int MODE, int BM, int BN, int WM, int WN, int KM>
+// PREC 0: operands stay fp32 -> v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 157 TF). PREC 1: the fp32 tiles staged in LDS are
+// rounded to bf16 (RNE, v_cvt_pk_bf16_f32) as the fragments are read -> v_mfma_f32_32x32x16_bf16 with fp32 accumulation (2.5 PF):
+// BASELINE configs[2]. Gathers, LDS layout and epilogue are shared; storage stays fp32.
+template <int MODE, int BM, int BN, int WM, int WN, int KM, int PREC>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   constexpr bool A_KC = (MODE != MODE_WGRAD);  // A tile stored [BM][LDK] (k contiguous) else [BK][BM]
   constexpr bool B_KC = (MODE == MODE_FWD);    // B tile stored [BN][LDK] else [BK][BN]
@@ -350,10 +355,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-  auto compute_kg = [&](int buf, int kg) {
+  auto compute_kg = [&](int buf, int kg) {   // one 8-k group (fp32) or one 16-k block (bf16: kg = 0, 2 cover the slab)
     const float* As = smem + buf * STAGE;
     const float* Bs = As + A_FLOATS;
-    {
+    if constexpr (PREC == 0) {
       const int kk = kg * 8 + half * 4;  // this lane-half's 4 consecutive k of the 8-k group
       float fa[TM][4], fb[TN][4];
 #pragma unroll
@@ -385,6 +390,42 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
 #pragma unroll
           for (int n = 0; n < TN; ++n)
             acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[n][j], acc[i][n], 0, 0, 0);
+    } else {
+      if (kg & 1) return;                       // bf16: two 16-k blocks per slab, issued on the even groups
+      const int kk = (kg >> 1) * 16 + half * 8;  // this lane-half's 8 consecutive k of the 16-k block
+      bf16x8 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * (BM / WM) + i * 32 + l31;
+        float v[8];
+        if constexpr (A_KC) {
+          const float4 p = *reinterpret_cast<const float4*>(As + row * LDK + kk), q = *reinterpret_cast<const float4*>(As + row * LDK + kk + 4);
+          v[0] = p.x, v[1] = p.y, v[2] = p.z, v[3] = p.w, v[4] = q.x, v[5] = q.y, v[6] = q.z, v[7] = q.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = As[(kk + j) * BM + row];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fa[i][j] = (__bf16)v[j];
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int col = wn * (BN / WN) + i * 32 + l31;
+        float v[8];
+        if constexpr (B_KC) {
+          const float4 p = *reinterpret_cast<const float4*>(Bs + col * LDK + kk), q = *reinterpret_cast<const float4*>(Bs + col * LDK + kk + 4);
+          v[0] = p.x, v[1] = p.y, v[2] = p.z, v[3] = p.w, v[4] = q.x, v[5] = q.y, v[6] = q.z, v[7] = q.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = Bs[(kk + j) * BN + col];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fb[i][j] = (__bf16)v[j];
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[n], acc[i][n], 0, 0, 0);
     }
   };
   auto compute = [&](int buf) {
@@ -549,15 +590,20 @@ Plan make_plan(int mode, long M, long Nn, long K) {
   return best_p;
 }
 
-template <int MODE, int BM, int BN, int WM, int WN, int KM>
-void launch_inst(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
+template <int MODE, int BM, int BN, int WM, int WN, int KM, int PREC>
+void launch_prec(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
   static const bool attr_set = [] {  // > 64 KB of dynamic LDS needs an explicit opt-in, once per kernel
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<MODE, BM, BN, WM, WN, KM>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<MODE, BM, BN, WM, WN, KM, PREC>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return true;
   }();
   (void)attr_set;
-  hipLaunchKernelGGL((conv_igemm_kernel<MODE, BM, BN, WM, WN, KM>), grid, dim3(256), smem, st, k);
+  hipLaunchKernelGGL((conv_igemm_kernel<MODE, BM, BN, WM, WN, KM, PREC>), grid, dim3(256), smem, st, k);
+}
+template <int MODE, int BM, int BN, int WM, int WN, int KM>
+void launch_inst(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
+  if (k.prec == 1) launch_prec<MODE, BM, BN, WM, WN, KM, 1>(k, grid, smem, st);
+  else launch_prec<MODE, BM, BN, WM, WN, KM, 0>(k, grid, smem, st);
 }
 template <int MODE, int BM, int BN, int WM, int WN>
 void launch_one(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
@@ -569,7 +615,7 @@ void launch_one(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
 // ---- optional in-library timing of the implicit-GEMM kernel itself (HIP events on the launch stream) ----------------
 struct ProfRec {
   hipEvent_t a, b;
-  int mode, bm, bn, km;
+  int mode, bm, bn, km, prec;
   double flops;
 };
 bool g_prof_on = false;
@@ -586,7 +632,7 @@ int launch(const ConvK& k0, const Plan& p, hipStream_t st) {
   ProfRec rec;
   if (g_prof_on) {
     (void)hipEventCreate(&rec.a), (void)hipEventCreate(&rec.b);
-    rec.mode = MODE, rec.bm = p.bm, rec.bn = p.bn, rec.km = (MODE == MODE_WGRAD && k.kmode == K_FAST) ? K_MID : k.kmode, rec.flops = 2.0 * (double)k.M * (double)k.Nn * (double)k.K;
+    rec.mode = MODE, rec.bm = p.bm, rec.bn = p.bn, rec.km = (MODE == MODE_WGRAD && k.kmode == K_FAST) ? K_MID : k.kmode, rec.prec = k.prec, rec.flops = 2.0 * (double)k.M * (double)k.Nn * (double)k.K;
     (void)hipEventRecord(rec.a, st);
   }
   constexpr bool akc = MODE != MODE_WGRAD, bkc = MODE == MODE_FWD;
@@ -629,6 +675,7 @@ void fill_geom(ConvK& k, const pm_tensor* x, const pm_tensor* y, const pm_conv_p
   k.Ho = y->h, k.Wo = y->w, k.Cout = y->c, k.y_pitch = y->pitch;
   k.kh = p->kh, k.kw = p->kw, k.stride = p->stride, k.pad = p->pad, k.dil = p->dil;
   k.sshift = p->stride == 2 ? 1 : 0;
+  k.prec = p->prec == 1 ? 1 : 0;
   k.bias = k.scale = k.shift = k.residual = nullptr;
   k.res_pitch = 0, k.relu = 0;
 }

@@ -12,6 +12,14 @@ def _lib():
     return L.load()
 
 
+CONV_PREC = 0      # 0: fp32 MFMA (parity path, BASELINE configs[1]); 1: bf16 MFMA operands, fp32 accumulate/storage (configs[2])
+
+
+def set_conv_precision(name):
+    global CONV_PREC
+    CONV_PREC = {'f32': 0, 'fp32': 0, 'bf16': 1}[name]
+
+
 def new(shape, like, pitch_pad=False):
     """Fresh NHWC tensor. Channel counts that are not a multiple of 4 (the 19 logits) get a padded pitch so rows stay 16B aligned."""
     n, h, w, c = shape
@@ -38,7 +46,7 @@ def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, res
     ho, wo = conv_out_hw(h, w_, kh, stride, pad, dil)
     y = out if out is not None else new((n, ho, wo, cout), x, pitch_pad=True)
     xd, yd = tdesc(x), tdesc(y)
-    p = PmConvParams(kh, kw, stride, pad, dil)
+    p = PmConvParams(kh, kw, stride, pad, dil, CONV_PREC)
     lib = _lib()
     nb = lib.pm_conv_workspace(byref(xd), byref(yd), byref(p), 0)
     ws = workspace(nb, x.device) if nb else None
@@ -54,7 +62,7 @@ def conv_bwd_data(dy, w_krsc, x_shape, stride, pad, dil, add=None):
     cout, kh, kw, cin = w_krsc.shape
     dx = new(x_shape, dy)
     dyd, dxd = tdesc(dy), tdesc(dx)
-    p = PmConvParams(kh, kw, stride, pad, dil)
+    p = PmConvParams(kh, kw, stride, pad, dil, CONV_PREC)
     lib = _lib()
     nb = lib.pm_conv_workspace(byref(dxd), byref(dyd), byref(p), 1)
     ws = workspace(nb, dy.device) if nb else None
@@ -68,7 +76,7 @@ def conv_bwd_weight(x, dy, w_shape_krsc, stride, pad, dil, want_bias=False):
     dw = torch.empty(w_shape_krsc, dtype=torch.float32, device=x.device)
     db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_bias else None
     xd, dyd = tdesc(x), tdesc(dy)
-    p = PmConvParams(kh, kw, stride, pad, dil)
+    p = PmConvParams(kh, kw, stride, pad, dil, CONV_PREC)
     lib = _lib()
     nb = lib.pm_conv_workspace(byref(xd), byref(dyd), byref(p), 2)
     ws = workspace(nb, x.device)

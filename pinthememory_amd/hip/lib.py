@@ -15,7 +15,7 @@ class PmTensor(ctypes.Structure):
 
 
 class PmConvParams(ctypes.Structure):
-    _fields_ = [('kh', c_int32), ('kw', c_int32), ('stride', c_int32), ('pad', c_int32), ('dil', c_int32)]
+    _fields_ = [('kh', c_int32), ('kw', c_int32), ('stride', c_int32), ('pad', c_int32), ('dil', c_int32), ('prec', c_int32)]
 
 
 class PmConvEpilogue(ctypes.Structure):

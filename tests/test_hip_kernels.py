@@ -293,3 +293,35 @@ def test_bn_merge(K):
     got = K.bn_merge(torch.stack(parts).cuda().contiguous(), 3, c).cpu()
     assert rel(got, D.merge_moments_list(parts, c)) < 1e-6
     assert rel(got[:c], x.mean((0, 2, 3))) < 1e-6 and rel(got[c:2 * c], ((x - x.mean((0, 2, 3))[None, :, None, None]) ** 2).sum((0, 2, 3))) < 1e-5
+
+
+@pytest.mark.parametrize('case', [CONV_CASES[1], CONV_CASES[3], CONV_CASES[5], CONV_CASES[8], CONV_CASES[9], CONV_CASES[10]])
+def test_conv_bf16_operands(K, case):
+    """BASELINE configs[2]: operands rounded to bf16 (RNE) feeding v_mfma_f32_32x32x16_bf16, fp32 accumulation.
+    Oracle: the same convolution in fp32 on inputs pre-rounded to bf16 -- only the accumulation order differs."""
+    n, cin, h, w, cout, k, s, p, d, has_bias = case
+    r16 = lambda t: t.bfloat16().float()
+    x = rnd(n, cin, h, w, seed=1)
+    wt = rnd(cout, cin, k, k, seed=2, scale=(2.0 / (cin * k * k)) ** 0.5)
+    xr, wr = r16(x).requires_grad_(True), r16(wt).requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, None, stride=s, padding=p, dilation=d)
+    dy = rnd(*y_ref.shape, seed=4)
+    K.set_conv_precision('bf16')
+    try:
+        xg, wg = nhwc(x), wt.permute(0, 2, 3, 1).contiguous().cuda()
+        y = K.conv_fwd(xg, wg, s, p, d)
+        assert rel(nchw(y), y_ref.detach()) < 1e-4
+        dyg = K.new(tuple(y.shape), y, pitch_pad=True)
+        dyg.copy_(nhwc(dy))
+        dx = K.conv_bwd_data(dyg, wg, tuple(xg.shape), s, p, d)
+        dw, _ = K.conv_bwd_weight(xg, dyg, tuple(wg.shape), s, p, d)
+    finally:
+        K.set_conv_precision('f32')
+    # backward oracles: dgrad rounds (dy, w); wgrad rounds (x, dy)
+    F.conv2d(x.clone().requires_grad_(True), wr, None, stride=s, padding=p, dilation=d)
+    x2 = x.clone().requires_grad_(True)
+    F.conv2d(x2, r16(wt), None, stride=s, padding=p, dilation=d).backward(r16(dy))
+    assert rel(nchw(dx), x2.grad) < 1e-4
+    w2 = wt.clone().requires_grad_(True)
+    F.conv2d(r16(x), w2, None, stride=s, padding=p, dilation=d).backward(r16(dy))
+    assert rel(dw.permute(0, 3, 1, 2), w2.grad) < 2e-4

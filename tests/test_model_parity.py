@@ -264,3 +264,36 @@ def test_full_size_properties(env):
         assert (sm.sum(-1) - 1).abs().max().item() < 1e-5 and (sq.sum((0, 1, 2)) - 1).abs().max().item() < 1e-4
         assert (net.memory.m_items.norm(dim=1) - 1).abs().max().item() < 1e-5
     assert outs[0] == outs[1], 'HIP path must be run-to-run deterministic'
+
+
+def test_config3_bf16_mfma_forward_and_step(env):
+    """BASELINE configs[2]: the same network with bf16-MFMA convolutions (operands rounded to bf16, fp32 accumulate / storage).
+    Gate: looser than fp32 by the operand precision -- eval logits within 2e-2 of the fp32 oracle relative to their range and
+    argmax identical wherever the oracle's top-2 margin exceeds 0.25; a train step runs and moves the losses like fp32 does."""
+    from pinthememory_amd.hip import kernels as K
+    synth = env['synth']
+    args = synth.model_args()
+    ref = synth.load_det_weights(env['o_deeplab'].DeepR50V3PlusD(args, 19, CRIT, CRIT)).eval()
+    net = synth.load_det_weights(env['deepv3plus'].DeepR50V3PlusD(args, 19, CRIT, CRIT)).cuda().eval()
+    x, y = synth.make_batch(2, 192)
+    K.set_conv_precision('bf16')
+    try:
+        with torch.no_grad():
+            want, got = ref(x)[0], net(x.cuda())[0].cpu()
+        scale = want.abs().max().item()
+        assert (got - want).abs().max().item() < 2e-2 * scale, ((got - want).abs().max().item(), scale)
+        top2 = want.topk(2, dim=1).values
+        safe = (top2[:, 0] - top2[:, 1]) > 0.25
+        assert (got.argmax(1)[safe] == want.argmax(1)[safe]).all() and safe.float().mean().item() > 0.5
+        net.train()
+        net.dsn[3].p = 0.0
+        opt, _ = env['harness'].make_optimizer(net)
+        l16 = env['harness'].agg_train_step(net, opt, x.cuda(), y.cuda())
+    finally:
+        K.set_conv_precision('f32')
+    net32 = synth.load_det_weights(env['deepv3plus'].DeepR50V3PlusD(args, 19, CRIT, CRIT)).cuda().train()
+    net32.dsn[3].p = 0.0
+    opt32, _ = env['harness'].make_optimizer(net32)
+    l32 = env['harness'].agg_train_step(net32, opt32, x.cuda(), y.cuda())
+    for k in l32:
+        assert abs(l16[k].item() - l32[k].item()) < 3e-2 * max(1.0, abs(l32[k].item())), (k, l16[k].item(), l32[k].item())
