@@ -10,6 +10,7 @@
 // registers while the current one feeds the matrix pipe (one barrier per K-step).
 // Replaces nn.Conv2d fwd/bwd of /root/reference/network/Resnet.py:145-150,404,453-457, deepv3plus.py:72-81,398-424.
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "pm_common.h"
@@ -40,6 +41,10 @@ struct ConvK {
   unsigned a_bytes, b_bytes;  // extents of the A / B buffers (buffer-descriptor range)
   int kmode;                  // K_FAST / K_MID / K_SMALL: how the gather's K-state advances (see the kernel)
   int prec;                   // 0 fp32 MFMA, 1 bf16 MFMA operands (fp32 storage and accumulation)
+  // tap list actually iterated: rows ky0 + ksy*i (i < nky), cols kx0 + ksx*j (j < tk_w); T_eff = nky * tk_w. The full kernel
+  // window for fwd / wgrad / stride-1 dgrad; the parity-matching subset for one input-pixel class of a stride-2 dgrad.
+  int T_eff, tk_w, ky0, kx0, ksy, ksx;
+  int sub, sub_cy, sub_cx, Hc, Wc;  // stride-2 dgrad: this launch covers input pixels (2*py + sub_cy, 2*px + sub_cx) only
   const float* bias;
   const float* scale;
   const float* shift;
@@ -106,7 +111,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   const int k_begin = z * a.kper;
   const int k_end = min(a.K, k_begin + a.kper);
   const int nk = (k_end - k_begin + BK - 1) / BK;
-  const int T = a.kh * a.kw;
+  const int T = a.T_eff;                 // taps iterated by this launch
+  const int Treal = a.kh * a.kw;         // tap stride of the KRSC weight layout
 
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, (int)a.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.B), 0, (int)a.b_bytes, 0x00020000);
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   int b_dy[B_N], b_dx[B_N];                        // WGRAD B: tap displacement of column group j
 
   if constexpr (MODE == MODE_FWD || MODE == MODE_DGRAD) {
-    const int rh = (MODE == MODE_FWD) ? a.Ho : a.H, rw = (MODE == MODE_FWD) ? a.Wo : a.W;
+    const int rh = (MODE == MODE_FWD) ? a.Ho : (a.sub ? a.Hc : a.H), rw = (MODE == MODE_FWD) ? a.Wo : (a.sub ? a.Wc : a.W);
     const int cdim = (MODE == MODE_FWD) ? a.Cin : a.Cout;
 #pragma unroll
     for (int i = 0; i < A_N; ++i) {
@@ -138,8 +144,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
           a_x0[i] = px * a.stride - a.pad;
           a_base[i] = (img * a.H * a.W + a_y0[i] * a.W + a_x0[i]) * xp4 + (FAST ? g * 16 : 0);
         } else {
-          a_y0[i] = py + a.pad;
-          a_x0[i] = px + a.pad;
+          a_y0[i] = (a.sub ? 2 * py + a.sub_cy : py) + a.pad;
+          a_x0[i] = (a.sub ? 2 * px + a.sub_cx : px) + a.pad;
           a_base[i] = FAST ? ((img * a.Ho + a_y0[i]) * a.Wo + a_x0[i]) * yp4 + g * 16 : img * a.Ho * a.Wo;
         }
       } else {
@@ -157,8 +163,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
       const int k = k_begin + g * 4;
       a_tap = k / cdim;
       a_ch = k - a_tap * cdim;
-      a_ky = a_tap / a.kw;
-      a_kx = a_tap - a_ky * a.kw;
+      a_ky = a_tap / a.tk_w;
+      a_kx = a_tap - a_ky * a.tk_w;
     }
   } else {
 #pragma unroll
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
 #pragma unroll
     for (int j = 0; j < B_N; ++j) {
       const int col = n0 + (g + 8 * j) * 4;
-      b_base[j] = col < a.Cin ? col * 4 + (FAST ? r * T * a.Cin * 4 : 0) : OOB;
+      b_base[j] = col < a.Cin ? col * 4 + (FAST ? r * Treal * a.Cin * 4 : 0) : OOB;
     }
     if constexpr (!FAST) {
       const int k = k_begin + r;
@@ -233,14 +239,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
           const int off = a_base[i] - toff;
           ra[i] = bload(rA, ok ? off : OOB);
         }
-        const int uoff = (u_ch * T + u_tap) * a.Cin * 4;
+        const int uoff = (u_ch * Treal + u_tap) * a.Cin * 4;
 #pragma unroll
         for (int j = 0; j < B_N; ++j) {
           const int off = b_base[j] + uoff;
           rb[j] = bload(rB, (tok & (b_base[j] != OOB)) ? off : OOB);
         }
       } else {
-        const int dy = a_ky * a.dil, dx = a_kx * a.dil, smask = a.stride - 1;
+        const int dy = (a.ky0 + a.ksy * a_ky) * a.dil, dx = (a.kx0 + a.ksx * a_kx) * a.dil, smask = a.stride - 1;
         const bool kok = a_tap < T;
 #pragma unroll
         for (int i = 0; i < A_N; ++i) {
@@ -251,7 +257,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
           ra[i] = bload(rA, ok ? off : OOB);
         }
         const bool rok = (b_tap < T) & (kbase + r < k_end);
-        const int roff = (b_co * T + b_tap) * a.Cin * 4;
+        const int b_tky = b_tap / a.tk_w, b_tkx = b_tap - b_tky * a.tk_w;
+        const int roff = (b_co * Treal + (a.ky0 + a.ksy * b_tky) * a.kw + a.kx0 + a.ksx * b_tkx) * a.Cin * 4;
 #pragma unroll
         for (int j = 0; j < B_N; ++j) {
           const int off = roff + b_base[j];
@@ -294,13 +301,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
           while (a_ch >= cdim) {
             a_ch -= cdim;
             ++a_tap;
-            if (++a_kx == a.kw) a_kx = 0, ++a_ky;
+            if (++a_kx == a.tk_w) a_kx = 0, ++a_ky;
           }
         } else {
           const bool wrap = a_ch >= cdim;
           a_ch -= wrap ? cdim : 0;
           a_tap += wrap ? 1 : 0;
-          const bool roww = wrap & (a_kx + 1 == a.kw);
+          const bool roww = wrap & (a_kx + 1 == a.tk_w);
           a_kx = roww ? 0 : a_kx + (wrap ? 1 : 0);
           a_ky += roww ? 1 : 0;
         }
@@ -470,14 +477,40 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   const bool plain = a.ksplit > 1 || !(a.bias || a.scale || a.residual || a.relu);
   const bool full = m0 + BM <= a.M && n0 + BN <= a.Nn;
   const int rbase = m0 + wm * (BM / WM) + 4 * half, cbase = n0 + wn * (BN / WN) + l31;
-  if (plain && full) {  // straight-line stores, no per-element predicate
+  if (full) {  // interior tile: straight-line epilogue specialised on the (wave-uniform) fused operations, no per-element predicate
+    auto run = [&](auto AFF, auto RES, auto RELU) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int n = 0; n < TN; ++n)
+        for (int n = 0; n < TN; ++n) {
+          const int col = cbase + n * 32;
+          float bi = 0.f, sc = 1.f, sh = 0.f;
+          if constexpr (decltype(AFF)::value) {
+            if (a.bias) bi = a.bias[col];
+            if (a.scale) sc = a.scale[col], sh = a.shift[col];
+          }
 #pragma unroll
-        for (int q = 0; q < 16; ++q)
-          Cb[(long)(rbase + i * 32 + (q & 3) + 8 * (q >> 2)) * a.c_pitch + cbase + n * 32] = acc[i][n][q];
+          for (int q = 0; q < 16; ++q) {
+            const long row = rbase + i * 32 + (q & 3) + 8 * (q >> 2);
+            float v = acc[i][n][q];
+            if constexpr (decltype(AFF)::value) v = (v + bi) * sc + sh;
+            if constexpr (decltype(RES)::value) v += a.residual[row * a.res_pitch + col];
+            if constexpr (decltype(RELU)::value) v = fmaxf(v, 0.f);
+            Cb[row * a.c_pitch + col] = v;
+          }
+        }
+    };
+    using T1 = std::true_type;
+    using T0 = std::false_type;
+    const bool aff = !plain && (a.bias || a.scale), res = !plain && a.residual, relu = !plain && a.relu;
+    if (!aff && !res && !relu) run(T0{}, T0{}, T0{});
+    else if (!aff && res && !relu) run(T0{}, T1{}, T0{});       // dgrad + fused skip gradient
+    else if (aff && !res && !relu) run(T1{}, T0{}, T0{});       // conv + bias
+    else if (aff && !res && relu) run(T1{}, T0{}, T1{});        // eval: conv + folded BN + ReLU
+    else if (aff && res && relu) run(T1{}, T1{}, T1{});         // eval: bottleneck tail
+    else if (aff && res && !relu) run(T1{}, T1{}, T0{});
+    else if (!aff && res && relu) run(T0{}, T1{}, T1{});
+    else run(T0{}, T0{}, T1{});
     return;
   }
 #pragma unroll
@@ -544,6 +577,50 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int nb, int 
   float s = 0.f;
   for (int b = 0; b < nb; ++b) s += part[(long)b * C + c];
   out[c] = s;
+}
+
+// stride-2 dgrad: scatter the four per-class results (compact [class][n*Hc*Wc][Cin]) back to dx and fuse the optional add.
+__global__ __launch_bounds__(256) void dgrad_s2_interleave_kernel(const float* __restrict__ tmp, long class_stride, int valid_mask,
+                                                                  float* __restrict__ dx, long xp, int N, int H, int W, int C, const float* __restrict__ add,
+                                                                  long add_pitch) {
+  const int c4n = C / 4;
+  const long total = (long)N * H * W * c4n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long pix = i / c4n;
+    const int c = (int)(i - pix * c4n) * 4;
+    const int ix = (int)(pix % W), iy = (int)((pix / W) % H), n = (int)(pix / ((long)W * H));
+    const int cy = iy & 1, cx = ix & 1, cls = cy * 2 + cx;
+    const int Hc = (H - cy + 1) >> 1, Wc = (W - cx + 1) >> 1;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((valid_mask >> cls) & 1) v = PM_LD4(tmp + cls * class_stride + ((long)(n * Hc + (iy >> 1)) * Wc + (ix >> 1)) * C + c);
+    if (add) {
+      const float4 q = PM_LD4(add + pix * add_pitch + c);
+      v.x += q.x, v.y += q.y, v.z += q.z, v.w += q.w;
+    }
+    PM_ST4(dx + pix * xp + c, v);
+  }
+}
+
+struct S2Class {   // one input-pixel parity class of a stride-2 dgrad
+  int cy, cx, Hc, Wc, ky0, nky, ksy, kx0, nkx, ksx;
+  long M;
+};
+// taps whose (c + pad - k*dil) is even: every second one from (c+pad)&1 when dil is odd; all or none when dil is even
+inline void s2_taps(int c, int pad, int dil, int k, int& k0, int& nk, int& ks) {
+  if (dil & 1) {
+    k0 = (c + pad) & 1, ks = 2, nk = k0 < k ? (k - k0 + 1) / 2 : 0;
+  } else {
+    k0 = 0, ks = 1, nk = ((c + pad) & 1) ? 0 : k;
+  }
+}
+inline S2Class s2_class(int cls, const pm_tensor* dx, const pm_conv_params* p) {
+  S2Class c;
+  c.cy = cls >> 1, c.cx = cls & 1;
+  c.Hc = (dx->h - c.cy + 1) >> 1, c.Wc = (dx->w - c.cx + 1) >> 1;
+  s2_taps(c.cy, p->pad, p->dil, p->kh, c.ky0, c.nky, c.ksy);
+  s2_taps(c.cx, p->pad, p->dil, p->kw, c.kx0, c.nkx, c.ksx);
+  c.M = (long)dx->n * c.Hc * c.Wc;
+  return c;
 }
 
 struct Plan {
@@ -676,6 +753,8 @@ void fill_geom(ConvK& k, const pm_tensor* x, const pm_tensor* y, const pm_conv_p
   k.kh = p->kh, k.kw = p->kw, k.stride = p->stride, k.pad = p->pad, k.dil = p->dil;
   k.sshift = p->stride == 2 ? 1 : 0;
   k.prec = p->prec == 1 ? 1 : 0;
+  k.T_eff = p->kh * p->kw, k.tk_w = p->kw, k.ky0 = k.kx0 = 0, k.ksy = k.ksx = 1;
+  k.sub = k.sub_cy = k.sub_cx = 0, k.Hc = x->h, k.Wc = x->w;
   k.bias = k.scale = k.shift = k.residual = nullptr;
   k.res_pitch = 0, k.relu = 0;
 }
@@ -715,6 +794,15 @@ extern "C" int pm_profile_read(int mode, int bm, int bn, int km, double* total_m
 }
 
 extern "C" size_t pm_conv_workspace(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p, int which) {
+  if (which == MODE_DGRAD && p->stride == 2) {   // four parity classes: compact results + the largest split-K slab set
+    size_t slab = 0, tmp = 0;
+    for (int cls = 0; cls < 4; ++cls) {
+      const S2Class c = s2_class(cls, x, p);
+      tmp = std::max(tmp, (size_t)c.M * x->c * sizeof(float));
+      if (c.M > 0 && c.nky * c.nkx > 0) slab = std::max(slab, make_plan(MODE_DGRAD, c.M, x->c, (long)c.nky * c.nkx * y->c).ws_bytes);
+    }
+    return pm_align_up(4 * pm_align_up(tmp, 256) + slab + 256, 256);
+  }
   long M, Nn, K;
   gemm_dims(which, x, y, p, M, Nn, K);
   size_t b = make_plan(which, M, Nn, K).ws_bytes;
@@ -759,6 +847,53 @@ extern "C" int pm_conv_bwd_data(const pm_tensor* dy, const float* w, const pm_te
   const float* addp = add ? (const float*)add->ptr : nullptr;
   const long add_pitch = add ? add->pitch : 0;
   PM_REQUIRE(w && pm_aligned16(w), PM_EINVAL, "conv_bwd_data: weight null or unaligned");
+  hipStream_t st0 = (hipStream_t)stream;
+  if (p->stride == 2) {
+    // Only taps with (iy + pad - ky*dil) even reach an output pixel: split the input pixels into their four parity classes,
+    // run a dense dgrad over each class with its matching tap subset (1/4 of the MFMA work of the masked formulation),
+    // then interleave the compact results into dx.
+    const size_t need = pm_conv_workspace(dx, dy, p, MODE_DGRAD);
+    PM_REQUIRE(ws && ws_bytes >= need, PM_EWORKSPACE, "conv_bwd_data(stride 2): workspace %zu < %zu", ws_bytes, need);
+    PM_REQUIRE(dx->c % 4 == 0, PM_EUNSUPPORTED, "conv_bwd_data(stride 2): Cin %% 4 != 0");
+    size_t tmp_bytes = 0;
+    for (int cls = 0; cls < 4; ++cls) tmp_bytes = std::max(tmp_bytes, (size_t)s2_class(cls, dx, p).M * dx->c * sizeof(float));
+    tmp_bytes = pm_align_up(tmp_bytes, 256);
+    float* tmp = (float*)ws;
+    float* slab = (float*)((char*)ws + 4 * tmp_bytes);
+    unsigned char valid[4];
+    for (int cls = 0; cls < 4; ++cls) {
+      const S2Class c = s2_class(cls, dx, p);
+      valid[cls] = c.M > 0 && c.nky * c.nkx > 0;
+      if (!valid[cls]) continue;
+      const long Kc = (long)c.nky * c.nkx * dy->c;
+      const Plan pl = make_plan(MODE_DGRAD, c.M, dx->c, Kc);
+      ConvK k;
+      fill_geom(k, dx, dy, p);
+      k.A = (const float*)dy->ptr, k.B = w;
+      k.M = (int)c.M, k.Nn = dx->c, k.K = (int)Kc;
+      k.a_bytes = (unsigned)(pm_pixels(dy) * dy->pitch * 4), k.b_bytes = (unsigned)((long)dy->c * p->kh * p->kw * dx->c * 4);
+      k.kmode = dy->c >= BK ? K_MID : K_SMALL;
+      k.T_eff = c.nky * c.nkx, k.tk_w = c.nkx, k.ky0 = c.ky0, k.kx0 = c.kx0, k.ksy = c.ksy, k.ksx = c.ksx;
+      k.sub = 1, k.sub_cy = c.cy, k.sub_cx = c.cx, k.Hc = c.Hc, k.Wc = c.Wc;
+      float* out = (float*)((char*)tmp + cls * tmp_bytes);
+      if (pl.ksplit > 1) {
+        k.C = slab, k.c_pitch = dx->c, k.c_split = c.M * dx->c;
+        if (int e = launch<MODE_DGRAD>(k, pl, st0)) return e;
+        const int nb = (int)std::min<long>((c.M * dx->c + 255) / 256, 4096);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st0, (const float*)slab, pl.ksplit, c.M * dx->c, (int)c.M, dx->c, out, (long)dx->c,
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0l, 0);
+      } else {
+        k.C = out, k.c_pitch = dx->c, k.c_split = 0;
+        if (int e = launch<MODE_DGRAD>(k, pl, st0)) return e;
+      }
+    }
+    const int valid_mask = valid[0] | (valid[1] << 1) | (valid[2] << 2) | (valid[3] << 3);
+    const long total = pm_pixels(dx) * (dx->c / 4);
+    hipLaunchKernelGGL(dgrad_s2_interleave_kernel, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, st0, (const float*)tmp,
+                       (long)(tmp_bytes / sizeof(float)), valid_mask, (float*)dx->ptr, (long)dx->pitch, dx->n, dx->h, dx->w, dx->c, addp,
+                       add_pitch);
+    return pm_check_launch("dgrad_s2_interleave");
+  }
   long M, Nn, K;
   gemm_dims(MODE_DGRAD, dx, dy, p, M, Nn, K);
   Plan pl = make_plan(MODE_DGRAD, M, Nn, K);
