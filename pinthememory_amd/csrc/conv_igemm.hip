@@ -83,7 +83,9 @@ enum { K_FAST = 0, K_MID = 1, K_SMALL = 2 };
 // PREC 0: operands stay fp32 -> v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 157 TF). PREC 1: the fp32 tiles staged in LDS are
 // rounded to bf16 (RNE, v_cvt_pk_bf16_f32) as the fragments are read -> v_mfma_f32_32x32x16_bf16 with fp32 accumulation (2.5 PF):
 // BASELINE configs[2]. Gathers, LDS layout and epilogue are shared; storage stays fp32.
-template <int MODE, int BM, int BN, int WM, int WN, int KM, int PREC>
+// NST: LDS stages. 2 = double-buffered (default). 1 = single buffer for short reductions (<= 4 K-steps: the 64->256 / 128->512
+// expansion 1x1s), halving the LDS footprint so that three blocks share a CU and cover each other's load / store phases.
+template <int MODE, int BM, int BN, int WM, int WN, int KM, int PREC, int NST>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   constexpr bool A_KC = (MODE != MODE_WGRAD);  // A tile stored [BM][LDK] (k contiguous) else [BK][BM]
   constexpr bool B_KC = (MODE == MODE_FWD);    // B tile stored [BN][LDK] else [BK][BN]
@@ -442,7 +444,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
 
   // ---- main loop: the gathers of slab kt+1 are issued (branch-free) ahead of the MFMAs of slab kt, whose 4096 matrix-pipe
   // cycles cover the load latency; LDS is double-buffered, one barrier per K-step ----------------------------------------
-  if (nk > 0) {
+  if constexpr (NST == 1) {
+    if (nk > 0) {
+      load_tiles(0);
+      advance();
+      store_tiles(0);
+      __syncthreads();
+      for (int kt = 0; kt < nk - 1; ++kt) {
+        load_tiles(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        advance();
+        compute(0);
+        __syncthreads();          // every wave is done reading the single buffer
+        store_tiles(0);
+        __syncthreads();
+      }
+      compute(0);
+    }
+  } else if (nk > 0) {
     load_tiles(0);
     advance();
     store_tiles(0);
@@ -667,15 +686,23 @@ Plan make_plan(int mode, long M, long Nn, long K) {
   return best_p;
 }
 
-template <int MODE, int BM, int BN, int WM, int WN, int KM, int PREC>
-void launch_prec(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
+template <int MODE, int BM, int BN, int WM, int WN, int KM, int PREC, int NST>
+void launch_nst(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
   static const bool attr_set = [] {  // > 64 KB of dynamic LDS needs an explicit opt-in, once per kernel
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<MODE, BM, BN, WM, WN, KM, PREC>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<MODE, BM, BN, WM, WN, KM, PREC, NST>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return true;
   }();
   (void)attr_set;
-  hipLaunchKernelGGL((conv_igemm_kernel<MODE, BM, BN, WM, WN, KM, PREC>), grid, dim3(256), smem, st, k);
+  hipLaunchKernelGGL((conv_igemm_kernel<MODE, BM, BN, WM, WN, KM, PREC, NST>), grid, dim3(256), smem / (NST == 1 ? 2 : 1), st, k);
+}
+template <int MODE, int BM, int BN, int WM, int WN, int KM, int PREC>
+void launch_prec(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
+  // single-stage variant only where it is used: fast-path fwd / dgrad with a short reduction per block
+  if constexpr (KM == K_FAST && MODE != MODE_WGRAD && BN >= 64) {
+    if (k.kper <= 4 * BK) return launch_nst<MODE, BM, BN, WM, WN, KM, PREC, 1>(k, grid, smem, st);
+  }
+  launch_nst<MODE, BM, BN, WM, WN, KM, PREC, 2>(k, grid, smem, st);
 }
 template <int MODE, int BM, int BN, int WM, int WN, int KM>
 void launch_inst(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
