@@ -121,11 +121,11 @@ def main():
     roof = None
     if prof:
         K.profile_enable(False)
-        ms, fl, n = K.profile_read(mode=0, bm=128, bn=128, km=0)     # dominant kernel symbol: conv_igemm_kernel<0, 128, 128, 2, 2, 0>
+        ms, fl, n = K.profile_read(mode=0, bm=128, bn=128, km=0, nst=2)     # one kernel symbol: conv_igemm_kernel<0, 128, 128, 2, 2, 0, prec, 2>
         tot_ms, tot_fl, tot_n = K.profile_read(clear=True)
         if n:
             ach = fl / (ms * 1e-3) / 1e12
-            roof = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<0, 128, 128, 2, 2, 0, %d, *> (forward, 128x128x32 tile, wave-uniform K-state, %s)' % (1 if a.dtype == 'bf16' else 0, 'v_mfma_f32_32x32x16_bf16' if a.dtype == 'bf16' else 'v_mfma_f32_32x32x2_f32'), 'achieved': round(ach, 2),
+            roof = {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<0, 128, 128, 2, 2, 0, %d, 2> (forward, 128x128x32 tile, wave-uniform K-state, double-buffered LDS, %s)' % (1 if a.dtype == 'bf16' else 0, 'v_mfma_f32_32x32x16_bf16' if a.dtype == 'bf16' else 'v_mfma_f32_32x32x2_f32'), 'achieved': round(ach, 2),
                     'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': None,
                     'launches_per_step': n / a.steps, 'avg_launch_ms': round(ms / n, 5), 'gflop_per_launch': round(fl / n / 1e9, 3),
                     'all_conv_kernels': {'achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), 'ms_per_step': round(tot_ms / a.steps, 3),

@@ -64,9 +64,9 @@ int pm_conv_bwd_weight(const pm_tensor* x, const pm_tensor* dy, float* dw_krsc, 
 /* In-library HIP-event timing of the implicit-GEMM kernel (bench.py's roofline leg). While enabled every conv launch is
  * bracketed by two events on its stream; pm_profile_read sums duration and algorithmic FLOPs (2*M*N*K) of one
  * instantiation conv_igemm_kernel<mode, bm, bn, .., km> (mode 0 fwd / 1 dgrad / 2 wgrad, block tile bm x bn, K-state variant
- * km 0 fast / 1 mid / 2 small; negative = any) and optionally clears the records. */
+ * km 0 fast / 1 mid / 2 small, nst LDS stages 1 / 2; negative = any) and optionally clears the records. */
 int pm_profile_enable(int on);
-int pm_profile_read(int mode, int bm, int bn, int km, double* total_ms, double* total_flops, int64_t* launches, int clear);
+int pm_profile_read(int mode, int bm, int bn, int km, int nst, double* total_ms, double* total_flops, int64_t* launches, int clear);
 
 /* ---- K4 BatchNorm2d (mynn.py:8-14 -> nn.BatchNorm2d / SyncBatchNorm, eps 1e-5, momentum 0.1) -------------------
  * stats: per-channel shifted sums -> (count, mean, M2) so that ranks can be merged exactly (SyncBN, train.py:95).
@@ -107,6 +107,13 @@ int pm_global_avgpool_bwd(const pm_tensor* dy, const pm_tensor* dx, int accumula
 /* ---- K5 bilinear resize, align_corners=True (mynn.py:57-62), fp32 index math as ATen ---------------------------- */
 int pm_resize_bilinear_fwd(const pm_tensor* x, const pm_tensor* y, void* stream);
 int pm_resize_bilinear_bwd(const pm_tensor* dy, const pm_tensor* dx, int accumulate, void* stream);
+
+/* ---- pooled multi-scale / flip evaluation (eval.py:133-145,277-337) -------------------------------------------------
+ * half-pixel bilinear (F.interpolate(mode='bilinear') default, align_corners=False) of the logits to the original size;
+ * MeanFusion: buffer += (softmax(logits) - buffer) / counter in float64 (buffer NHWC double); argmax over channels. */
+int pm_resize_bilinear_hp_fwd(const pm_tensor* x, const pm_tensor* y, int flip_w, void* stream);
+int pm_softmax_mean_update(const pm_tensor* logits, double* buffer, int counter, void* stream);
+int pm_argmax_f64(const double* buffer, int n, int h, int w, int c, int64_t* out_cls, double* out_prob /*nullable*/, void* stream);
 
 /* ---- layout edges ------------------------------------------------------------------------------------------------ */
 int pm_nchw_to_nhwc(const float* x_nchw, int c_src, const pm_tensor* y, void* stream);   /* zero-fills y.c > c_src */

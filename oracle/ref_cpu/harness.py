@@ -181,3 +181,20 @@ def mldg_train_step(net, updated_net, updated_net2, opt, x_tr, y_tr, x_te, y_te,
         sched.step()
     return dict(inner=inner.detach(), outer=outer.detach(), inner_loss1=out_in[0].detach(), outer_loss1=out_te[0].detach(),
                 outer_read=out_te[-2].detach())
+
+
+# ---- inference_pool + MeanFusion (eval.py:133-145,277-337) ---------------------------------------------------------------
+def inference_pool(net, imgs, orisize, no_flip=False):
+    """imgs[flip][scale] -> (probs, preds): softmax of the half-pixel-upsampled logits, float64 running mean, max over classes."""
+    net.eval()
+    buf = torch.zeros(imgs[0][0].shape[0], 19, orisize[0], orisize[1], dtype=torch.float64)
+    cnt = 0
+    with torch.no_grad():
+        for flip in range(1 if no_flip else 2):
+            for img in imgs[flip]:
+                y = F.interpolate(net(img)[0], size=orisize, mode='bilinear')
+                if flip == 1:
+                    y = torch.flip(y, dims=[3])
+                cnt += 1
+                buf.add_((F.softmax(y, dim=1) - buf) / cnt)
+    return buf.max(1)

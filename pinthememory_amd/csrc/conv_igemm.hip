@@ -719,7 +719,7 @@ void launch_one(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
 // ---- optional in-library timing of the implicit-GEMM kernel itself (HIP events on the launch stream) ----------------
 struct ProfRec {
   hipEvent_t a, b;
-  int mode, bm, bn, km, prec;
+  int mode, bm, bn, km, prec, nst;
   double flops;
 };
 bool g_prof_on = false;
@@ -736,7 +736,7 @@ int launch(const ConvK& k0, const Plan& p, hipStream_t st) {
   ProfRec rec;
   if (g_prof_on) {
     (void)hipEventCreate(&rec.a), (void)hipEventCreate(&rec.b);
-    rec.mode = MODE, rec.bm = p.bm, rec.bn = p.bn, rec.km = (MODE == MODE_WGRAD && k.kmode == K_FAST) ? K_MID : k.kmode, rec.prec = k.prec, rec.flops = 2.0 * (double)k.M * (double)k.Nn * (double)k.K;
+    rec.mode = MODE, rec.bm = p.bm, rec.bn = p.bn, rec.km = (MODE == MODE_WGRAD && k.kmode == K_FAST) ? K_MID : k.kmode, rec.prec = k.prec, rec.nst = (MODE != MODE_WGRAD && k.kmode == K_FAST && p.bn >= 64 && k.kper <= 4 * BK) ? 1 : 2, rec.flops = 2.0 * (double)k.M * (double)k.Nn * (double)k.K;
     (void)hipEventRecord(rec.a, st);
   }
   constexpr bool akc = MODE != MODE_WGRAD, bkc = MODE == MODE_FWD;
@@ -800,12 +800,12 @@ extern "C" int pm_profile_enable(int on) {
   return PM_OK;
 }
 // Sums (and clears) the records of one kernel instantiation conv_igemm_kernel<mode, bm, bn, .., km>: mode 0 fwd / 1 dgrad /
-// 2 wgrad, bm x bn the block tile, km the K-state variant. Negative values act as wildcards. Synchronises on the recorded events only.
-extern "C" int pm_profile_read(int mode, int bm, int bn, int km, double* total_ms, double* total_flops, int64_t* launches, int clear) {
+// 2 wgrad, bm x bn the block tile, km the K-state variant, nst the LDS stage count. Negative values act as wildcards. Synchronises on the recorded events only.
+extern "C" int pm_profile_read(int mode, int bm, int bn, int km, int nst, double* total_ms, double* total_flops, int64_t* launches, int clear) {
   double ms = 0.0, fl = 0.0;
   int64_t n = 0;
   for (const ProfRec& r : g_prof) {
-    if ((mode >= 0 && r.mode != mode) || (bm >= 0 && r.bm != bm) || (bn >= 0 && r.bn != bn) || (km >= 0 && r.km != km)) continue;
+    if ((mode >= 0 && r.mode != mode) || (bm >= 0 && r.bm != bm) || (bn >= 0 && r.bn != bn) || (km >= 0 && r.km != km) || (nst >= 0 && r.nst != nst)) continue;
     float t = 0.f;
     if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
     ms += t, fl += r.flops, ++n;

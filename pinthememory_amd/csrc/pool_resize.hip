@@ -204,6 +204,63 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict
   }
 }
 
+// F.interpolate(..., mode='bilinear') with align_corners=False as ATen computes it: scale = in/out (float),
+// src = scale * (dst + 0.5) - 0.5 clamped at 0, i0 = floor(src), i1 = i0 + (i0 < in-1), lambda = src - i0.
+__device__ __forceinline__ pm_lerp hp_lerp(float scale, int dst, int in) {
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  int i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  pm_lerp r;
+  r.i0 = i0;
+  r.i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  float l1 = src - (float)i0;
+  l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
+  r.w1 = l1;
+  r.w0 = 1.f - l1;
+  return r;
+}
+__global__ __launch_bounds__(256) void resize_hp_fwd_kernel(const float* __restrict__ x, long xp, int h, int w, float* __restrict__ y, long yp, int H, int W,
+                                                            int C, long total, float sy, float sx, int flip_w) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long op = i / C;
+    const int ch = (int)(i - op * C);
+    const int X = (int)(op % W), Y = (int)((op / W) % H), n = (int)(op / ((long)W * H));
+    const pm_lerp ly = hp_lerp(sy, Y, h), lx = hp_lerp(sx, X, w);
+    const float* r0 = x + ((long)(n * h + ly.i0) * w) * xp + ch;
+    const float* r1 = x + ((long)(n * h + ly.i1) * w) * xp + ch;
+    const float v = ly.w0 * (lx.w0 * r0[lx.i0 * xp] + lx.w1 * r0[lx.i1 * xp]) + ly.w1 * (lx.w0 * r1[lx.i0 * xp] + lx.w1 * r1[lx.i1 * xp]);
+    const int Xo = flip_w ? W - 1 - X : X;   // un-flip on the way out (eval.py:330 flip_tensor2(y, -1))
+    y[((long)(n * H + Y) * W + Xo) * yp + ch] = v;
+  }
+}
+// one thread per pixel: softmax over C <= 32 classes in fp32 (as torch.softmax on fp32 logits), running mean in fp64
+__global__ __launch_bounds__(256) void softmax_mean_kernel(const float* __restrict__ lg, long lp, long pixels, int C, double* __restrict__ buf, double inv_cnt) {
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < pixels; p += (long)gridDim.x * 256) {
+    float v[32];
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) v[c] = lg[p * lp + c], mx = fmaxf(mx, v[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) v[c] = expf(v[c] - mx), se += v[c];
+    for (int c = 0; c < C; ++c) {
+      const double pr = (double)(v[c] / se), b = buf[p * C + c];
+      buf[p * C + c] = b + (pr - b) * inv_cnt;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void argmax_f64_kernel(const double* __restrict__ buf, long pixels, int C, int64_t* __restrict__ cls, double* __restrict__ prob) {
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < pixels; p += (long)gridDim.x * 256) {
+    double best = buf[p * C];
+    int bi = 0;
+    for (int c = 1; c < C; ++c) {
+      const double v = buf[p * C + c];
+      if (v > best) best = v, bi = c;             // first maximum wins, as torch.max
+    }
+    cls[p] = bi;
+    if (prob) prob[p] = best;
+  }
+}
+
 inline int grid_for(long work) { return (int)std::min<long>((work + 255) / 256, 256 * 32); }
 
 }  // namespace
@@ -282,4 +339,25 @@ extern "C" int pm_resize_bilinear_bwd(const pm_tensor* dy, const pm_tensor* dx, 
     hipLaunchKernelGGL(resize_bwd_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)dy->ptr, (long)dy->pitch, dy->h, dy->w,
                        (float*)dx->ptr, (long)dx->pitch, dx->h, dx->w, dx->c, total, sy, sx, accumulate);
   return pm_check_launch("resize_bwd");
+}
+
+extern "C" int pm_resize_bilinear_hp_fwd(const pm_tensor* x, const pm_tensor* y, int flip_w, void* stream) {
+  PM_REQUIRE(x && y && x->ptr && y->ptr && x->n == y->n && x->c == y->c, PM_EINVAL, "resize_hp_fwd: bad args");
+  const long total = pm_pixels(y) * y->c;
+  hipLaunchKernelGGL(resize_hp_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr, (long)x->pitch, x->h, x->w,
+                     (float*)y->ptr, (long)y->pitch, y->h, y->w, y->c, total, (float)x->h / (float)y->h, (float)x->w / (float)y->w, flip_w);
+  return pm_check_launch("resize_hp_fwd");
+}
+extern "C" int pm_softmax_mean_update(const pm_tensor* logits, double* buffer, int counter, void* stream) {
+  PM_REQUIRE(logits && logits->ptr && buffer && counter >= 1 && logits->c >= 1 && logits->c <= 32, PM_EINVAL, "softmax_mean_update: bad args");
+  const long pixels = pm_pixels(logits);
+  hipLaunchKernelGGL(softmax_mean_kernel, dim3(grid_for(pixels)), dim3(256), 0, (hipStream_t)stream, (const float*)logits->ptr, (long)logits->pitch, pixels,
+                     logits->c, buffer, 1.0 / (double)counter);
+  return pm_check_launch("softmax_mean_update");
+}
+extern "C" int pm_argmax_f64(const double* buffer, int n, int h, int w, int c, int64_t* out_cls, double* out_prob, void* stream) {
+  PM_REQUIRE(buffer && out_cls && c >= 1, PM_EINVAL, "argmax_f64: bad args");
+  const long pixels = (long)n * h * w;
+  hipLaunchKernelGGL(argmax_f64_kernel, dim3(grid_for(pixels)), dim3(256), 0, (hipStream_t)stream, buffer, pixels, c, out_cls, out_prob);
+  return pm_check_launch("argmax_f64");
 }

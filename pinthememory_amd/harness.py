@@ -200,3 +200,24 @@ def mldg_train_step(net, updated_net, updated_net2, opt, x_tr, y_tr, x_te, y_te,
         sched.step()
     return dict(inner=inner.detach(), outer=outer.detach(), inner_loss1=out_in[0].detach(), outer_loss1=out_te[0].detach(),
                 outer_read=out_te[-2].detach())
+
+
+# ---- pooled multi-scale / flip evaluation: inference_pool + MeanFusion (eval.py:133-145,277-337) -------------------------
+def inference_pool(net, imgs, orisize, no_flip=False):
+    """imgs[flip][scale]: pre-scaled (and pre-flipped for flip = 1) NCHW image batches as the reference's loader provides them.
+    Per entry: logits -> half-pixel bilinear to `orisize` (un-flipping flipped inputs) -> softmax -> float64 running mean;
+    returns (probs, preds) = max over classes of the fused buffer. All of it stays on the GPU (the reference moves every
+    map to the CPU, eval.py:328-330)."""
+    net.eval()
+    n = imgs[0][0].shape[0]
+    buf, cnt = None, 0
+    with torch.no_grad():
+        for flip in range(1 if no_flip else 2):
+            for img in imgs[flip]:
+                lg = ops.nhwc(net(img)[0])
+                up = K.resize_hp_fwd(lg, orisize, flip_w=(flip == 1))
+                if buf is None:
+                    buf = torch.zeros((n, orisize[0], orisize[1], up.shape[3]), dtype=torch.float64, device=up.device)
+                cnt += 1
+                K.softmax_mean_update(up, buf, cnt)
+    return K.argmax_f64(buf)

@@ -210,6 +210,26 @@ def resize_bwd(dy, x_shape):
     return dx
 
 
+def resize_hp_fwd(x, size, flip_w=False):
+    """F.interpolate(mode='bilinear', align_corners=False) of an NHWC tensor, optionally un-flipping the width on the way out."""
+    n, h, w, c = x.shape
+    y = torch.empty((n, size[0], size[1], c), dtype=torch.float32, device=x.device)
+    check(_lib().pm_resize_bilinear_hp_fwd(byref(tdesc(x)), byref(tdesc(y)), 1 if flip_w else 0, stream()), 'pm_resize_bilinear_hp_fwd')
+    return y
+
+
+def softmax_mean_update(logits, buffer, counter):
+    check(_lib().pm_softmax_mean_update(byref(tdesc(logits)), buffer.data_ptr(), counter, stream()), 'pm_softmax_mean_update')
+
+
+def argmax_f64(buffer):
+    n, h, w, c = buffer.shape
+    cls = torch.empty((n, h, w), dtype=torch.int64, device=buffer.device)
+    prob = torch.empty((n, h, w), dtype=torch.float64, device=buffer.device)
+    check(_lib().pm_argmax_f64(buffer.data_ptr(), n, h, w, c, cls.data_ptr(), prob.data_ptr(), stream()), 'pm_argmax_f64')
+    return prob, cls
+
+
 def nchw_to_nhwc(x, c_pad=None):
     n, c, h, w = x.shape
     x = x.contiguous()
@@ -327,9 +347,9 @@ def profile_enable(on):
     check(_lib().pm_profile_enable(1 if on else 0), 'pm_profile_enable')
 
 
-def profile_read(mode=-1, bm=-1, bn=-1, km=-1, clear=False):
+def profile_read(mode=-1, bm=-1, bn=-1, km=-1, nst=-1, clear=False):
     """-> (total_ms, total_flops, launches) of the conv_igemm_kernel<mode, bm, bn, .., km> launches recorded since the last clear."""
     import ctypes
     ms, fl, n = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int64(0)
-    check(_lib().pm_profile_read(mode, bm, bn, km, byref(ms), byref(fl), byref(n), 1 if clear else 0), 'pm_profile_read')
+    check(_lib().pm_profile_read(mode, bm, bn, km, nst, byref(ms), byref(fl), byref(n), 1 if clear else 0), 'pm_profile_read')
     return ms.value, fl.value, n.value

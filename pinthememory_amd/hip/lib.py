@@ -39,7 +39,7 @@ SIGNATURES = {
     'pm_conv_bwd_data': (_i, [_T, _vp, _T, _P, _T, _vp, _sz, _vp]),
     'pm_conv_bwd_weight': (_i, [_T, _T, _vp, _vp, _P, _vp, _sz, _vp]),
     'pm_profile_enable': (_i, [_i]),
-    'pm_profile_read': (_i, [_i, _i, _i, _i, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64), _i]),
+    'pm_profile_read': (_i, [_i, _i, _i, _i, _i, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64), _i]),
     'pm_bn_workspace': (_sz, [_T]),
     'pm_bn_stats': (_i, [_T, _vp, _vp, _sz, _vp]),
     'pm_bn_merge': (_i, [_vp, _i, _i, _vp, _vp]),
@@ -58,6 +58,9 @@ SIGNATURES = {
     'pm_global_avgpool_bwd': (_i, [_T, _T, _i, _vp]),
     'pm_resize_bilinear_fwd': (_i, [_T, _T, _vp]),
     'pm_resize_bilinear_bwd': (_i, [_T, _T, _i, _vp]),
+    'pm_resize_bilinear_hp_fwd': (_i, [_T, _T, _i, _vp]),
+    'pm_softmax_mean_update': (_i, [_T, _vp, _i, _vp]),
+    'pm_argmax_f64': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'pm_nchw_to_nhwc': (_i, [_vp, _i, _T, _vp]),
     'pm_nhwc_to_nchw': (_i, [_T, _vp, _vp]),
     'pm_label_nearest': (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp]),

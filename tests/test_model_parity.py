@@ -297,3 +297,21 @@ def test_config3_bf16_mfma_forward_and_step(env):
     l32 = env['harness'].agg_train_step(net32, opt32, x.cuda(), y.cuda())
     for k in l32:
         assert abs(l16[k].item() - l32[k].item()) < 3e-2 * max(1.0, abs(l32[k].item())), (k, l16[k].item(), l32[k].item())
+
+
+def test_pooled_multiscale_flip_eval_vs_oracle(env):
+    """inference_pool + MeanFusion (eval.py:133-145,304-337) on the GPU vs the CPU restatement."""
+    import torch.nn.functional as F
+    synth = env['synth']
+    args = synth.model_args()
+    ref = synth.load_det_weights(env['o_deeplab'].DeepR50V3PlusD(args, 19, CRIT, CRIT)).eval()
+    net = synth.load_det_weights(env['deepv3plus'].DeepR50V3PlusD(args, 19, CRIT, CRIT)).cuda().eval()
+    x, _ = synth.make_batch(1, (96, 160), seed=5)
+    scales = [F.interpolate(x, scale_factor=s, mode='bilinear', align_corners=False) if s != 1 else x for s in (0.75, 1.0, 1.25)]
+    imgs = [scales, [torch.flip(t, dims=[3]) for t in scales]]
+    p_ref, c_ref = env['o_harness'].inference_pool(ref, imgs, (96, 160))
+    p, c = env['harness'].inference_pool(net, [[t.cuda() for t in f] for f in imgs], (96, 160))
+    assert (p.cpu() - p_ref).abs().max().item() < 2e-4
+    top2 = None
+    agree = (c.cpu() == c_ref).float().mean().item()
+    assert agree > 0.999, agree
