@@ -661,7 +661,7 @@ Plan make_plan(int mode, long M, long Nn, long K) {
   // row tiles of 128) spread evenly over the 256 CUs; a 64-row tile is ~8 % less efficient per FLOP (half the MFMAs per
   // fragment read and per barrier).
   for (int bm = 128; bm >= 64; bm -= 64) {
-    if (bm == 64 && (bn < 64 || M <= 64 * 0)) continue;
+    if (bm == 64 && bn < 64) continue;                            // no 64x32 instantiation (4 waves need >= 2 tiles)
     if (bm == 64 && mode == MODE_WGRAD && M > 64) continue;       // wgrad: 64 rows only for Cout <= 64
     if (bm == 128 && mode == MODE_WGRAD && M <= 64 && bn >= 64) continue;
     const int tiles_m = pm_cdiv(M, bm), tiles_n = pm_cdiv(Nn, bn);
