@@ -2,6 +2,8 @@
 memory is NHWC (`t.permute(0,2,3,1)` is a dense pixel-major view): every call site keeps the reference's shape
 arithmetic (`x.size()[2:]`, `dim=1` channel slices) while every kernel sees coalesced channel vectors.
 Weights enter as Function inputs (never cached pointers) so functional re-wiring of module._parameters works."""
+import os as _os
+
 import torch
 
 from . import kernels as K
@@ -50,6 +52,71 @@ class BNState:
             bn.num_batches_tracked.add_(1)
 
 
+# ---- weight-gradient overlap ------------------------------------------------------------------------------------------
+# wgrad(L) only needs x(L) and dy(L); nothing on the backward critical path (bn_bwd(L-1) -> dgrad(L-1) -> ...) needs its result.
+# It is launched on a side stream so that the HBM-bound BatchNorm-backward kernels and the tile-quantisation tails of the dgrad
+# kernels run under its MFMA work.
+# Safety: the weight enters the conv node through a `_Defer` identity node created at the START of its stage's forward, i.e. with
+# a lower autograd sequence number than every node of that stage. The engine therefore runs `_Defer.backward` -- which makes the
+# main stream wait for the side stream and only then hands the gradient on -- after the whole stage's backward has been
+# launched: AccumulateGrad / DDP hooks / functional-weight graphs never see a gradient that is still being written.
+OVERLAP_WGRAD = _os.environ.get('PM_OVERLAP_WGRAD', '1') == '1'
+_side = {}
+_proxy = {}            # id(weight tensor) -> deferred proxy, valid for the current forward only
+
+
+def _side_stream():
+    dev = torch.cuda.current_device()
+    if dev not in _side:
+        _side[dev] = torch.cuda.Stream(device=dev)
+    return _side[dev]
+
+
+class _Defer(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w):
+        return w.view_as(w)
+
+    @staticmethod
+    def backward(ctx, g):
+        torch.cuda.current_stream().wait_stream(_side_stream())
+        return g
+
+
+def begin_forward():
+    _proxy.clear()
+
+
+def defer_weights(module):
+    """Call right before running `module` (a stage of the network) in training mode with gradients enabled."""
+    if not (OVERLAP_WGRAD and torch.is_grad_enabled()):
+        return
+    for m in module.modules():
+        if isinstance(m, torch.nn.Conv2d) and m.bias is None and m.weight.requires_grad and id(m.weight) not in _proxy:
+            _proxy[id(m.weight)] = _Defer.apply(m.weight)
+
+
+def _w(weight):
+    """(tensor the conv node should take as its weight input, whether its wgrad may run asynchronously)"""
+    p = _proxy.get(id(weight))
+    return (p, True) if p is not None else (weight, False)
+
+
+def _wgrad(x, dy, wshape, geom, want_bias=False, deferred=False):
+    if not deferred:
+        return K.conv_bwd_weight(x, dy, wshape, *geom, want_bias=want_bias)
+    side = _side_stream()
+    ev = torch.cuda.Event()
+    ev.record()
+    with torch.cuda.stream(side):
+        side.wait_event(ev)
+        out = K.conv_bwd_weight(x, dy, wshape, *geom, want_bias=want_bias)
+    x.record_stream(side)
+    dy.record_stream(side)
+    out[0].record_stream(torch.cuda.current_stream())
+    return out
+
+
 def _bn_train_fwd(y, gamma, beta, bn, residual, relu, out=None):
     """Batch statistics (merged across ranks for SyncBN) -> normalise + residual + ReLU. Returns (o, mean, invstd)."""
     c = y.shape[3]
@@ -77,7 +144,7 @@ class _Bottleneck(torch.autograd.Function):
     16 blocks cost 16 nodes instead of ~60."""
 
     @staticmethod
-    def forward(ctx, x, w1, g1, b1, w2, g2, b2, w3, g3, b3, wd, gd, bd, geoms, bns):
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, w3, g3, b3, wd, gd, bd, geoms, bns, deferred):
         xv = nhwc(x)
         k1, k2, k3 = K.krsc(w1), K.krsc(w2), K.krsc(w3)
         y1 = K.conv_fwd(xv, k1, *geoms[0])
@@ -93,33 +160,33 @@ class _Bottleneck(torch.autograd.Function):
             kd = yd = md = idd = None
             res = xv
         out, m3, i3 = _bn_train_fwd(y3, g3, b3, bns[2], res, True)
-        ctx.geoms, ctx.groups, ctx.has_ds = geoms, [b.group for b in bns], wd is not None
+        ctx.geoms, ctx.groups, ctx.has_ds, ctx.deferred = geoms, [b.group for b in bns], wd is not None, deferred
         ctx.save_for_backward(xv, k1, k2, k3, kd, y1, o1, y2, o2, y3, yd, out, m1, i1, m2, i2, m3, i3, md, idd, g1, g2, g3, gd)
         return nchw(out)
 
     @staticmethod
     def backward(ctx, dout):
         xv, k1, k2, k3, kd, y1, o1, y2, o2, y3, yd, out, m1, i1, m2, i2, m3, i3, md, idd, g1, g2, g3, gd = ctx.saved_tensors
-        ge, gr = ctx.geoms, ctx.groups
+        ge, gr, df = ctx.geoms, ctx.groups, ctx.deferred
         dv = _grad_view(dout)
         dy3, dres, dg3, db3 = _bn_train_bwd(dv, out, y3, m3, i3, g3, True, gr[2], True)
-        dw3, _ = K.conv_bwd_weight(o2, dy3, tuple(k3.shape), *ge[2])
+        dw3, _ = _wgrad(o2, dy3, tuple(k3.shape), ge[2], deferred=df[2])
         do2 = K.conv_bwd_data(dy3, k3, tuple(o2.shape), *ge[2])
         dy2, _, dg2, db2 = _bn_train_bwd(do2, o2, y2, m2, i2, g2, True, gr[1], False)
-        dw2, _ = K.conv_bwd_weight(o1, dy2, tuple(k2.shape), *ge[1])
+        dw2, _ = _wgrad(o1, dy2, tuple(k2.shape), ge[1], deferred=df[1])
         do1 = K.conv_bwd_data(dy2, k2, tuple(o1.shape), *ge[1])
         dy1, _, dg1, db1 = _bn_train_bwd(do1, o1, y1, m1, i1, g1, True, gr[0], False)
-        dw1, _ = K.conv_bwd_weight(xv, dy1, tuple(k1.shape), *ge[0])
+        dw1, _ = _wgrad(xv, dy1, tuple(k1.shape), ge[0], deferred=df[0])
         dwd = dgd = dbd = None
         skip = dres
         if ctx.has_ds:
             dyd, _, dgd, dbd = _bn_train_bwd(dres, None, yd, md, idd, gd, False, gr[3], False)
-            dwdk, _ = K.conv_bwd_weight(xv, dyd, tuple(kd.shape), *ge[3])
+            dwdk, _ = _wgrad(xv, dyd, tuple(kd.shape), ge[3], deferred=df[3])
             dwd = dwdk.permute(0, 3, 1, 2)
             skip = K.conv_bwd_data(dyd, kd, tuple(xv.shape), *ge[3]) if ctx.needs_input_grad[0] else None
         dx = nchw(K.conv_bwd_data(dy1, k1, tuple(xv.shape), *ge[0], add=skip)) if ctx.needs_input_grad[0] else None
         p = lambda d: d.permute(0, 3, 1, 2)
-        return dx, p(dw1), dg1, db1, p(dw2), dg2, db2, p(dw3), dg3, db3, dwd, dgd, dbd, None, None
+        return dx, p(dw1), dg1, db1, p(dw2), dg2, db2, p(dw3), dg3, db3, dwd, dgd, dbd, None, None, None
 
 
 class _ConvBnAct(torch.autograd.Function):
@@ -127,12 +194,12 @@ class _ConvBnAct(torch.autograd.Function):
     Replaces e.g. Resnet.py:195-216 conv/bn/relu triples and every Sequential(Conv2d, Norm2d, ReLU) of deepv3plus.py."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, gamma, beta, residual, geom, bn, relu, out):
+    def forward(ctx, x, w, bias, gamma, beta, residual, geom, bn, relu, out, deferred=False):
         stride, pad, dil = geom
         xv, wk = nhwc(x), K.krsc(w)
         rv = nhwc(residual) if residual is not None else None
         ov = nhwc(out) if out is not None else None
-        ctx.geom, ctx.relu, ctx.train = geom, relu, bn.training
+        ctx.geom, ctx.relu, ctx.train, ctx.deferred = geom, relu, bn.training, deferred and bias is None
         if not bn.training:
             scale, shift = K.bn_fold(gamma, beta, bn.running_mean, bn.running_var, bn.eps, bias)
             o = K.conv_fwd(xv, wk, stride, pad, dil, scale=scale, shift=shift, residual=rv, relu=relu, out=ov)
@@ -154,9 +221,9 @@ class _ConvBnAct(torch.autograd.Function):
         dx = nchw(K.conv_bwd_data(dy, wk, tuple(xv.shape), stride, pad, dil)) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dwk, db = K.conv_bwd_weight(xv, dy, tuple(wk.shape), stride, pad, dil, want_bias=ctx.has_bias)
+            dwk, db = _wgrad(xv, dy, tuple(wk.shape), (stride, pad, dil), want_bias=ctx.has_bias, deferred=ctx.deferred)
             dw = dwk.permute(0, 3, 1, 2)
-        return dx, dw, db, dgamma, dbeta, (nchw(dres) if dres is not None else None), None, None, None, None
+        return dx, dw, db, dgamma, dbeta, (nchw(dres) if dres is not None else None), None, None, None, None, None
 
 
 class _Conv(torch.autograd.Function):
@@ -177,7 +244,7 @@ class _Conv(torch.autograd.Function):
         stride, pad, dil = ctx.geom
         dv = _grad_view(dout)
         dx = nchw(K.conv_bwd_data(dv, wk, tuple(xv.shape), stride, pad, dil)) if ctx.needs_input_grad[0] else None
-        dwk, db = K.conv_bwd_weight(xv, dv, tuple(wk.shape), stride, pad, dil, want_bias=ctx.has_bias)
+        dwk, db = _wgrad(xv, dv, tuple(wk.shape), (stride, pad, dil), want_bias=ctx.has_bias)
         return dx, dwk.permute(0, 3, 1, 2), db, None
 
 
@@ -339,7 +406,8 @@ def _geom(conv):
 
 
 def conv_bn_act(x, conv, bn, relu=True, residual=None, out=None):
-    return _ConvBnAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, residual, _geom(conv), BNState(bn), relu, out)
+    w, deferred = _w(conv.weight)
+    return _ConvBnAct.apply(x, w, conv.bias, bn.weight, bn.bias, residual, _geom(conv), BNState(bn), relu, out, deferred)
 
 
 def bottleneck(x, blk):
@@ -348,9 +416,10 @@ def bottleneck(x, blk):
     mods = [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2), (blk.conv3, blk.bn3)] + ([(ds[0], ds[1])] if ds is not None else [])
     geoms = [_geom(c) for c, _ in mods]
     bns = [BNState(b) for _, b in mods]
-    wd, gd, bd = (ds[0].weight, ds[1].weight, ds[1].bias) if ds is not None else (None, None, None)
-    return _Bottleneck.apply(x, blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight, blk.bn2.weight, blk.bn2.bias,
-                             blk.conv3.weight, blk.bn3.weight, blk.bn3.bias, wd, gd, bd, geoms, bns)
+    ws = [_w(c.weight) for c, _ in mods]
+    wd, gd, bd = (ws[3][0], ds[1].weight, ds[1].bias) if ds is not None else (None, None, None)
+    return _Bottleneck.apply(x, ws[0][0], blk.bn1.weight, blk.bn1.bias, ws[1][0], blk.bn2.weight, blk.bn2.bias,
+                             ws[2][0], blk.bn3.weight, blk.bn3.bias, wd, gd, bd, geoms, bns, [d for _, d in ws] + [False])
 
 
 def conv(x, conv_mod):

@@ -81,12 +81,25 @@ class _Base(nn.Module):
         self.layer1, self.layer2, self.layer3, self.layer4 = resnet.layer1, resnet.layer2, resnet.layer3, resnet.layer4
 
     def _trunk(self, x):
+        # per stage: weight proxies first (ops.defer_weights), so each stage's weight gradients are handed to autograd
+        # once that stage's backward has been launched -- the wgrad kernels run on a side stream meanwhile
+        train = self.training
+        ops.begin_forward()
         x = Resnet.stem(self.layer0[0], self.layer0[1], x)      # layer0[0..3]: conv, bn, relu, maxpool
-        x_tuple = self.layer1([x, []])
-        low_level = x_tuple[0]
-        x_tuple = self.layer3(self.layer2(x_tuple))
-        aux_out = x_tuple[0]
-        return low_level, aux_out, self.layer4(x_tuple)[0]
+        x_tuple = [x, []]
+        outs = []
+        layers = [self.layer1, self.layer2, self.layer3, self.layer4]
+        heads = [getattr(self, n) for n in ('aspp', 'bot_aspp', 'bot_fine', 'final1', 'memory') if hasattr(self, n)]
+        # proxies of stage i+1 are created before stage i runs: their gradients are handed over one stage AFTER they were
+        # computed, so the main stream never idles on a just-launched wgrad
+        ahead = [[layers[0], layers[1]], [layers[2]], [layers[3]], heads]
+        for layer, nxt in zip(layers, ahead):
+            if train:
+                for m in nxt:
+                    ops.defer_weights(m)
+            x_tuple = layer(x_tuple)
+            outs.append(x_tuple[0])
+        return outs[0], outs[2], outs[3]
 
     def _make_memory(self):
         if self.args.memory:
