@@ -115,6 +115,12 @@ int pm_resize_bilinear_hp_fwd(const pm_tensor* x, const pm_tensor* y, int flip_w
 int pm_softmax_mean_update(const pm_tensor* logits, double* buffer, int counter, void* stream);
 int pm_argmax_f64(const double* buffer, int n, int h, int w, int c, int64_t* out_cls, double* out_prob /*nullable*/, void* stream);
 
+/* ---- input edge: ToTensor + Normalize(ImageNet) (datasets/gtav.py:284-289) and MaskToTensor
+ * (transforms/transforms.py:95-97) on the GPU: uint8 HWC images -> normalised NHWC4 fp32 (zero 4th channel, the stem's layout),
+ * uint8 label maps -> int64. Cuts the host->device traffic of a batch 4x (images) / 8x (labels). */
+int pm_image_u8_to_nhwc4(const uint8_t* img_nhw3, int64_t pixels, const float* mean3, const float* std3, float* out_nhwc4, void* stream);
+int pm_labels_u8_to_i64(const uint8_t* lab, int64_t n, int64_t* out, void* stream);
+
 /* ---- layout edges ------------------------------------------------------------------------------------------------ */
 int pm_nchw_to_nhwc(const float* x_nchw, int c_src, const pm_tensor* y, void* stream);   /* zero-fills y.c > c_src */
 int pm_nhwc_to_nchw(const pm_tensor* x, float* y_nchw, void* stream);

@@ -168,3 +168,32 @@ extern "C" int pm_sgd_momentum(float* param, const float* grad, float* mbuf, int
                      momentum, wd, first_step);
   return pm_check_launch("sgd_momentum");
 }
+
+// ---- input edge: uint8 images / labels -> the layouts the path consumes ---------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void image_u8_kernel(const uint8_t* __restrict__ img, long pixels, float m0, float m1, float m2, float s0, float s1,
+                                                       float s2, float* __restrict__ out) {
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < pixels; p += (long)gridDim.x * 256) {
+    const uint8_t* q = img + p * 3;
+    // ToTensor: /255 ; Normalize: (x - mean) / std  -- same operation order as torchvision
+    const float4 o = make_float4(((float)q[0] / 255.f - m0) / s0, ((float)q[1] / 255.f - m1) / s1, ((float)q[2] / 255.f - m2) / s2, 0.f);
+    ST4(out + p * 4, o);
+  }
+}
+__global__ __launch_bounds__(256) void labels_u8_kernel(const uint8_t* __restrict__ lab, long n, int64_t* __restrict__ out) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = (int64_t)lab[i];
+}
+}  // namespace
+extern "C" int pm_image_u8_to_nhwc4(const uint8_t* img, int64_t pixels, const float* mean3, const float* std3, float* out, void* stream) {
+  PM_REQUIRE(img && mean3 && std3 && out && pixels >= 0 && pm_aligned16(out), PM_EINVAL, "image_u8_to_nhwc4: bad args");
+  if (pixels == 0) return PM_OK;
+  hipLaunchKernelGGL(image_u8_kernel, dim3((int)std::min<long>((pixels + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)stream, img, (long)pixels, mean3[0],
+                     mean3[1], mean3[2], std3[0], std3[1], std3[2], out);
+  return pm_check_launch("image_u8_to_nhwc4");
+}
+extern "C" int pm_labels_u8_to_i64(const uint8_t* lab, int64_t n, int64_t* out, void* stream) {
+  PM_REQUIRE(lab && out && n >= 0, PM_EINVAL, "labels_u8_to_i64: bad args");
+  if (n == 0) return PM_OK;
+  hipLaunchKernelGGL(labels_u8_kernel, dim3((int)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)stream, lab, (long)n, out);
+  return pm_check_launch("labels_u8_to_i64");
+}

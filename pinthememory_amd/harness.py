@@ -221,3 +221,23 @@ def inference_pool(net, imgs, orisize, no_flip=False):
                 cnt += 1
                 K.softmax_mean_update(up, buf, cnt)
     return K.argmax_f64(buf)
+
+
+# ---- input edge -----------------------------------------------------------------------------------
+def prepare_batch(inputs, gts, aux_gts=None):
+    """train.py:297-307: DomainUniformConcatDataset batches arrive as [B, D, 3, H, W] / [B, D, H, W]; merge the domain axis."""
+    c, h, w = inputs.shape[-3:]
+    x = inputs.reshape(-1, c, h, w).cuda(non_blocking=True)
+    gt = gts.reshape(-1, h, w).cuda(non_blocking=True)
+    aux = gt if aux_gts is None else aux_gts.reshape(-1, h, w).cuda(non_blocking=True)
+    return x, gt, aux
+
+
+def prepare_batch_u8(images_u8, labels_u8):
+    """GPU-side ToTensor + Normalize(ImageNet) + MaskToTensor for uint8 [.., H, W, 3] images and uint8 [.., H, W] label maps:
+    4x / 8x less host->device traffic than the fp32 / int64 tensors the reference's loader ships. Returns the image as a
+    logical-NCHW view of NHWC4 memory (what the stem consumes without another conversion) and int64 labels."""
+    h, w = images_u8.shape[-3:-1]
+    img = K.image_u8_to_nhwc4(images_u8.reshape(-1, h, w, 3).cuda(non_blocking=True).contiguous())
+    lab = K.labels_u8_to_i64(labels_u8.reshape(-1, h, w).cuda(non_blocking=True).contiguous())
+    return ops.nchw(img), lab

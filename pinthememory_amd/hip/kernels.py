@@ -230,6 +230,27 @@ def argmax_f64(buffer):
     return prob, cls
 
 
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)      # datasets/gtav.py:284, eval.py:128
+
+
+def image_u8_to_nhwc4(img_u8, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """uint8 [N,H,W,3] -> normalised fp32 NHWC4 [N,H,W,4] (ToTensor + Normalize, zero 4th channel)."""
+    import ctypes
+    n, h, w, c = img_u8.shape
+    assert c == 3 and img_u8.dtype == torch.uint8 and img_u8.is_contiguous()
+    out = torch.empty((n, h, w, 4), dtype=torch.float32, device=img_u8.device)
+    m, s = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+    check(_lib().pm_image_u8_to_nhwc4(img_u8.data_ptr(), n * h * w, m, s, out.data_ptr(), stream()), 'pm_image_u8_to_nhwc4')
+    return out
+
+
+def labels_u8_to_i64(lab_u8):
+    assert lab_u8.dtype == torch.uint8 and lab_u8.is_contiguous()
+    out = torch.empty(lab_u8.shape, dtype=torch.int64, device=lab_u8.device)
+    check(_lib().pm_labels_u8_to_i64(lab_u8.data_ptr(), lab_u8.numel(), out.data_ptr(), stream()), 'pm_labels_u8_to_i64')
+    return out
+
+
 def nchw_to_nhwc(x, c_pad=None):
     n, c, h, w = x.shape
     x = x.contiguous()

@@ -61,6 +61,8 @@ SIGNATURES = {
     'pm_resize_bilinear_hp_fwd': (_i, [_T, _T, _i, _vp]),
     'pm_softmax_mean_update': (_i, [_T, _vp, _i, _vp]),
     'pm_argmax_f64': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'pm_image_u8_to_nhwc4': (_i, [_vp, _i64, POINTER(c_float), POINTER(c_float), _vp, _vp]),
+    'pm_labels_u8_to_i64': (_i, [_vp, _i64, _vp, _vp]),
     'pm_nchw_to_nhwc': (_i, [_vp, _i, _T, _vp]),
     'pm_nhwc_to_nchw': (_i, [_T, _vp, _vp]),
     'pm_label_nearest': (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp]),

@@ -325,3 +325,15 @@ def test_conv_bf16_operands(K, case):
     w2 = wt.clone().requires_grad_(True)
     F.conv2d(r16(x), w2, None, stride=s, padding=p, dilation=d).backward(r16(dy))
     assert rel(dw.permute(0, 3, 1, 2), w2.grad) < 2e-4
+
+
+def test_input_edge_u8(K):
+    """GPU-side ToTensor + Normalize + MaskToTensor vs the torch formulas of the reference's loader."""
+    g = torch.Generator().manual_seed(3)
+    img = torch.randint(0, 256, (2, 37, 29, 3), generator=g, dtype=torch.uint8)
+    lab = torch.randint(0, 256, (2, 37, 29), generator=g, dtype=torch.uint8)
+    out = K.image_u8_to_nhwc4(img.cuda()).cpu()
+    mean, std = torch.tensor(K.IMAGENET_MEAN), torch.tensor(K.IMAGENET_STD)
+    ref = (img.float() / 255.0 - mean) / std
+    assert (out[..., :3] - ref).abs().max().item() < 1e-6 and out[..., 3].abs().max().item() == 0
+    assert torch.equal(K.labels_u8_to_i64(lab.cuda()).cpu(), lab.long())
