@@ -61,6 +61,11 @@ int pm_conv_bwd_data(const pm_tensor* dy, const float* w_krsc, const pm_tensor* 
 int pm_conv_bwd_weight(const pm_tensor* x, const pm_tensor* dy, float* dw_krsc, float* dbias, const pm_conv_params* p,
                        void* ws, size_t ws_bytes, void* stream);
 
+/* Wide stride-1 3x3 convolutions with pad == dilation (Resnet.py:195 conv2 of layer3/4, deepv3plus.py:72-81 ASPP branches,
+ * :398-404 final1, :455 dsn) run as Winograd F(2x2,3x3) in fp32 by default -- 2.25x fewer MFMA FLOPs, results within a few fp32
+ * ulp of the direct algorithm. pm_set_winograd(0) forces the direct implicit GEMM everywhere (A/B measurements, parity tests). */
+int pm_set_winograd(int on);
+
 /* In-library HIP-event timing of the implicit-GEMM kernel (bench.py's roofline leg). While enabled every conv launch is
  * bracketed by two events on its stream; pm_profile_read sums duration and algorithmic FLOPs (2*M*N*K) of one
  * instantiation conv_igemm_kernel<mode, bm, bn, .., km> (mode 0 fwd / 1 dgrad / 2 wgrad, block tile bm x bn, K-state variant

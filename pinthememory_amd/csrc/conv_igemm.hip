@@ -37,6 +37,7 @@ struct ConvK {
   int kper;               // K range per split (multiple of BK)
   long c_pitch;           // row pitch of C
   long c_split;           // floats between split-K slabs (ksplit > 1 -> C is the workspace)
+  long a_bs, b_bs, c_bs;  // batched launch (gridDim.y > 1, the 16 Winograd points): floats between consecutive A / B / C operands
   int tiles_m, tiles_n;
   unsigned a_bytes, b_bytes;  // extents of the A / B buffers (buffer-descriptor range)
   int kmode;                  // K_FAST / K_MID / K_SMALL: how the gather's K-state advances (see the kernel)
@@ -116,8 +117,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   const int T = a.T_eff;                 // taps iterated by this launch
   const int Treal = a.kh * a.kw;         // tap stride of the KRSC weight layout
 
-  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, (int)a.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.B), 0, (int)a.b_bytes, 0x00020000);
+  const int by = blockIdx.y;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A + by * a.a_bs), 0, (int)a.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.B + by * a.b_bs), 0, (int)a.b_bytes, 0x00020000);
   const int xp4 = (int)a.x_pitch * 4, yp4 = (int)a.y_pitch * 4;
 
   // ---- gather state ---------------------------------------------------------------------------------------------
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   }
 
   // ---- epilogue -------------------------------------------------------------------------------------------------
-  float* Cb = a.C + (a.ksplit > 1 ? (long)z * a.c_split : 0);
+  float* Cb = a.C + by * a.c_bs + (a.ksplit > 1 ? (long)z * a.c_split : 0);
   const bool plain = a.ksplit > 1 || !(a.bias || a.scale || a.residual || a.relu);
   const bool full = m0 + BM <= a.M && n0 + BN <= a.Nn;
   const int rbase = m0 + wm * (BM / WM) + 4 * half, cbase = n0 + wn * (BN / WN) + l31;
@@ -726,17 +728,17 @@ bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 
 template <int MODE>
-int launch(const ConvK& k0, const Plan& p, hipStream_t st) {
+int launch(const ConvK& k0, const Plan& p, hipStream_t st, int batch = 1, double flops = -1.0) {
   ConvK k = k0;
   k.tiles_m = p.tiles_m;
   k.tiles_n = p.tiles_n;
   k.ksplit = p.ksplit;
   k.kper = p.kper;
-  dim3 grid(p.tiles_m * p.tiles_n, 1, p.ksplit);
+  dim3 grid(p.tiles_m * p.tiles_n, batch, p.ksplit);
   ProfRec rec;
   if (g_prof_on) {
     (void)hipEventCreate(&rec.a), (void)hipEventCreate(&rec.b);
-    rec.mode = MODE, rec.bm = p.bm, rec.bn = p.bn, rec.km = (MODE == MODE_WGRAD && k.kmode == K_FAST) ? K_MID : k.kmode, rec.prec = k.prec, rec.nst = (MODE != MODE_WGRAD && k.kmode == K_FAST && p.bn >= 64 && k.kper <= 4 * BK) ? 1 : 2, rec.flops = 2.0 * (double)k.M * (double)k.Nn * (double)k.K;
+    rec.mode = MODE, rec.bm = p.bm, rec.bn = p.bn, rec.km = (MODE == MODE_WGRAD && k.kmode == K_FAST) ? K_MID : k.kmode, rec.prec = k.prec, rec.nst = (MODE != MODE_WGRAD && k.kmode == K_FAST && p.bn >= 64 && k.kper <= 4 * BK) ? 1 : 2, rec.flops = flops >= 0.0 ? flops : 2.0 * (double)k.M * (double)k.Nn * (double)k.K * batch;
     (void)hipEventRecord(rec.a, st);
   }
   constexpr bool akc = MODE != MODE_WGRAD, bkc = MODE == MODE_FWD;
@@ -784,6 +786,63 @@ void fill_geom(ConvK& k, const pm_tensor* x, const pm_tensor* y, const pm_conv_p
   k.sub = k.sub_cy = k.sub_cx = 0, k.Hc = x->h, k.Wc = x->w;
   k.bias = k.scale = k.shift = k.residual = nullptr;
   k.res_pitch = 0, k.relu = 0;
+  k.a_bs = k.b_bs = k.c_bs = 0;
+}
+
+// ---- Winograd F(2x2,3x3) route for the wide stride-1 "same" 3x3 convolutions (transforms: winograd.hip) ------------------------
+// forward:  V = Bt x B ; M[p] = V[p] U[p]^T (16 batched GEMMs on the kernel above) ; y = At M A (+ epilogue)
+// data grad: the same pipeline on dy with the rotated / transposed filter.
+// Taken when the GEMMs are MFMA-bound (both channel counts >= 128: the 4x-expanded V / M streams would otherwise dominate) and the
+// dilation sub-lattices tile the image without much padding (H, W multiples of 2*dil: d = 1, 2, 6, 12 on the 48x48 maps).
+bool g_wino_on = true;
+struct WinoPlan {
+  bool use;
+  pm_wino_geom g;
+  int Kp;
+  size_t v_bytes, m_bytes, u_bytes;
+  Plan pl;
+};
+WinoPlan wino_plan(const pm_tensor* xin, int cout, const pm_conv_params* p) {
+  WinoPlan wp{};
+  if (!g_wino_on || p->kh != 3 || p->kw != 3 || p->stride != 1 || p->pad != p->dil || p->prec == 1) return wp;
+  const int cin = xin->c;
+  if (cin < 128 || cout < 128 || (cout & 3) || (cin & 3)) return wp;
+  wp.g = pm_wino_make_geom(xin->n, xin->h, xin->w, p->dil);
+  const double cover = (double)(2 * wp.g.TY * p->dil) * (double)(2 * wp.g.TX * p->dil) / ((double)xin->h * xin->w);
+  if (cover > 1.15) return wp;
+  wp.Kp = (cin + BK - 1) / BK * BK;
+  if (wp.g.tiles * (long)std::max(wp.Kp, cout) * 4 >= (1ll << 31)) return wp;
+  wp.v_bytes = pm_align_up((size_t)16 * wp.g.tiles * wp.Kp * sizeof(float), 256);
+  wp.m_bytes = pm_align_up((size_t)16 * wp.g.tiles * cout * sizeof(float), 256);
+  wp.u_bytes = pm_align_up((size_t)16 * cout * wp.Kp * sizeof(float), 256);
+  wp.pl.bm = 128, wp.pl.bn = 128;
+  wp.pl.tiles_m = pm_cdiv(wp.g.tiles, 128), wp.pl.tiles_n = pm_cdiv(cout, 128);
+  wp.pl.ksplit = 1, wp.pl.kper = wp.Kp, wp.pl.ws_bytes = 0;
+  wp.use = true;
+  return wp;
+}
+inline size_t wino_ws(const WinoPlan& wp) { return wp.v_bytes + wp.m_bytes + wp.u_bytes; }
+
+int wino_conv(const pm_tensor* xin, const float* w, int w_cout, int w_cin, bool dgrad, const pm_tensor* yout, const WinoPlan& wp,
+              const pm_conv_epilogue& ep, void* ws, hipStream_t st) {
+  float* V = (float*)ws;
+  float* Mo = (float*)((char*)ws + wp.v_bytes);
+  float* U = (float*)((char*)ws + wp.v_bytes + wp.m_bytes);
+  const int cout = yout->c;
+  if (int e = pm_wino_input_xf((const float*)xin->ptr, xin->pitch, xin->c, wp.Kp, wp.g, V, st)) return e;
+  if (int e = pm_wino_filter_xf(w, w_cout, w_cin, wp.Kp, dgrad, U, st)) return e;
+  const pm_tensor xv = {V, 1, 1, (int32_t)wp.g.tiles, wp.Kp, wp.Kp};
+  const pm_tensor yv = {Mo, 1, 1, (int32_t)wp.g.tiles, cout, cout};
+  const pm_conv_params p1 = {1, 1, 1, 0, 1, 0};
+  ConvK k;
+  fill_geom(k, &xv, &yv, &p1);
+  k.A = V, k.B = U, k.C = Mo;
+  k.M = (int)wp.g.tiles, k.Nn = cout, k.K = wp.Kp;
+  k.a_bytes = (unsigned)(wp.g.tiles * wp.Kp * 4), k.b_bytes = (unsigned)((long)cout * wp.Kp * 4), k.kmode = K_FAST;
+  k.c_pitch = cout, k.c_split = 0;
+  k.a_bs = wp.g.tiles * wp.Kp, k.b_bs = (long)cout * wp.Kp, k.c_bs = wp.g.tiles * cout;
+  if (int e = launch<MODE_FWD>(k, wp.pl, st, 16, 2.0 * 16.0 * (double)wp.g.tiles * cout * xin->c)) return e;
+  return pm_wino_output_xf(Mo, cout, wp.g, (float*)yout->ptr, yout->pitch, ep.bias, ep.scale, ep.shift, ep.residual, ep.residual_pitch, ep.relu, st);
 }
 
 void gemm_dims(int which, const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p, long& M, long& Nn, long& K) {
@@ -795,6 +854,10 @@ void gemm_dims(int which, const pm_tensor* x, const pm_tensor* y, const pm_conv_
 
 }  // namespace
 
+extern "C" int pm_set_winograd(int on) {
+  g_wino_on = on != 0;
+  return PM_OK;
+}
 extern "C" int pm_profile_enable(int on) {
   g_prof_on = on != 0;
   return PM_OK;
@@ -830,6 +893,10 @@ extern "C" size_t pm_conv_workspace(const pm_tensor* x, const pm_tensor* y, cons
     }
     return pm_align_up(4 * pm_align_up(tmp, 256) + slab + 256, 256);
   }
+  if (which == MODE_FWD || which == MODE_DGRAD) {
+    const WinoPlan wp = which == MODE_FWD ? wino_plan(x, y->c, p) : wino_plan(y, x->c, p);
+    if (wp.use) return wino_ws(wp);
+  }
   long M, Nn, K;
   gemm_dims(which, x, y, p, M, Nn, K);
   size_t b = make_plan(which, M, Nn, K).ws_bytes;
@@ -841,6 +908,16 @@ extern "C" int pm_conv_fwd(const pm_tensor* x, const float* w, const pm_tensor* 
                            const pm_conv_epilogue* ep, void* ws, size_t ws_bytes, void* stream) {
   if (int e = check_common(x, y, p)) return e;
   PM_REQUIRE(w && pm_aligned16(w), PM_EINVAL, "conv_fwd: weight null or unaligned");
+  {
+    pm_conv_epilogue e1 = {nullptr, nullptr, nullptr, nullptr, 0, 0};
+    if (ep) e1 = *ep;
+    PM_REQUIRE((e1.scale == nullptr) == (e1.shift == nullptr), PM_EINVAL, "conv_fwd: scale and shift go together");
+    const WinoPlan wp = wino_plan(x, y->c, p);
+    if (wp.use) {
+      PM_REQUIRE(ws && ws_bytes >= wino_ws(wp), PM_EWORKSPACE, "conv_fwd(winograd): workspace %zu < %zu", ws_bytes, wino_ws(wp));
+      return wino_conv(x, w, y->c, x->c, false, y, wp, e1, ws, (hipStream_t)stream);
+    }
+  }
   long M, Nn, K;
   gemm_dims(MODE_FWD, x, y, p, M, Nn, K);
   Plan pl = make_plan(MODE_FWD, M, Nn, K);
@@ -920,6 +997,14 @@ extern "C" int pm_conv_bwd_data(const pm_tensor* dy, const float* w, const pm_te
                        (long)(tmp_bytes / sizeof(float)), valid_mask, (float*)dx->ptr, (long)dx->pitch, dx->n, dx->h, dx->w, dx->c, addp,
                        add_pitch);
     return pm_check_launch("dgrad_s2_interleave");
+  }
+  {
+    const WinoPlan wp = wino_plan(dy, dx->c, p);
+    if (wp.use) {
+      PM_REQUIRE(ws && ws_bytes >= wino_ws(wp), PM_EWORKSPACE, "conv_bwd_data(winograd): workspace %zu < %zu", ws_bytes, wino_ws(wp));
+      const pm_conv_epilogue e1 = {nullptr, nullptr, nullptr, addp, add_pitch, 0};
+      return wino_conv(dy, w, dy->c, dx->c, true, dx, wp, e1, ws, st0);
+    }
   }
   long M, Nn, K;
   gemm_dims(MODE_DGRAD, dx, dy, p, M, Nn, K);

@@ -35,6 +35,17 @@ static inline size_t pm_align_up(size_t v, size_t a) { return (v + a - 1) / a * 
 // Vectorisable NHWC view: base 16B-aligned, pitch % 4 == 0.
 static inline bool pm_vec_ok(const pm_tensor* t) { return pm_aligned16(t->ptr) && (t->pitch % 4) == 0; }
 
+// ---- Winograd F(2x2,3x3) transforms (winograd.hip), driven by the conv entry points in conv_igemm.hip -------------------
+struct pm_wino_geom {
+  int N, H, W, d, TY, TX;   // tiles per image = d*d sub-lattices x TY x TX tiles of 2x2 outputs
+  long tiles;
+};
+pm_wino_geom pm_wino_make_geom(int n, int h, int w, int d);
+int pm_wino_input_xf(const float* x, long pitch, int C, int Kp, const pm_wino_geom& g, float* V, hipStream_t st);
+int pm_wino_filter_xf(const float* w, int Cout, int Cin, int Kp, bool dgrad, float* U, hipStream_t st);
+int pm_wino_output_xf(const float* M, int Cout, const pm_wino_geom& g, float* y, long ypitch, const float* bias, const float* scale, const float* shift,
+                      const float* residual, long res_pitch, int relu, hipStream_t st);
+
 // ---- device helpers -------------------------------------------------------------------------------------------
 __device__ __forceinline__ float pm_wave_sum(float v) {
 #pragma unroll

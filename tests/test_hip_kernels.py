@@ -76,6 +76,47 @@ def test_conv_fwd_bwd(K, case):
         assert rel(db, br.grad) < 2e-5
 
 
+WINO_CASES = [
+    # n, cin, h, w, cout, dil   (3x3, stride 1, pad == dil, both channel counts >= 128 -> Winograd F(2x2,3x3) route)
+    (1, 304, 16, 16, 256, 1),
+    (2, 128, 24, 24, 128, 2),
+    (1, 256, 13, 15, 128, 1),      # odd extents: partial edge tiles
+    (1, 128, 36, 36, 160, 6),
+    (1, 2048, 24, 24, 256, 12),
+    (2, 132, 8, 8, 140, 1),        # channel counts that are not multiples of 32 / 128
+]
+
+
+@pytest.mark.parametrize('case', WINO_CASES)
+def test_conv_winograd(K, case):
+    """Winograd route vs an fp64 convolution, next to the direct implicit GEMM on the same inputs: both within fp32 rounding of
+    the truth, and the route is really taken (the results differ from the direct ones in the last bits)."""
+    n, cin, h, w, cout, d = case
+    x = rnd(n, cin, h, w, seed=1)
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=(2.0 / (cin * 9)) ** 0.5)
+    b = rnd(cout, seed=3)
+    xr = x.double().requires_grad_(True)
+    y_ref = F.conv2d(xr, wt.double(), b.double(), padding=d, dilation=d)
+    dy = rnd(*y_ref.shape, seed=4)
+    y_ref.backward(dy.double())
+    add = rnd(n, cin, h, w, seed=5)
+    xg, wg, dyg, addg = nhwc(x), wt.permute(0, 2, 3, 1).contiguous().cuda(), nhwc(dy), nhwc(add)
+    buf = torch.zeros(n, h, w, cout + 64, device='cuda')
+    res = {}
+    for wino in (True, False):
+        K.set_winograd(wino)
+        try:
+            y = K.conv_fwd(xg, wg, 1, d, d, bias=b.cuda(), out=buf[..., 32:32 + cout])
+            res[wino] = (nchw(y).clone(), nchw(K.conv_bwd_data(dyg, wg, tuple(xg.shape), 1, d, d, add=addg)))
+        finally:
+            K.set_winograd(True)
+        assert buf[..., :32].abs().max().item() == 0 and buf[..., 32 + cout:].abs().max().item() == 0
+    for wino in (True, False):
+        assert rel(res[wino][0], y_ref.detach()) < 2e-5, wino
+        assert rel(res[wino][1], xr.grad + add.double()) < 2e-5, wino
+    assert not torch.equal(res[True][0], res[False][0])
+
+
 def test_conv_epilogue_and_slices(K):
     """eval-mode fold (scale/shift), residual, relu, and writing into a channel slice of a wider concat buffer."""
     x, wt = rnd(2, 64, 12, 12, seed=1), rnd(32, 64, 3, 3, seed=2, scale=0.05)
