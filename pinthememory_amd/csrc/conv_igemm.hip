@@ -802,8 +802,9 @@ struct WinoPlan {
   size_t v_bytes, m_bytes, u_bytes;
   Plan pl;
 };
-WinoPlan wino_plan(const pm_tensor* xin, int cout, const pm_conv_params* p) {
+WinoPlan wino_plan(const pm_tensor* xin, int cout, const pm_conv_params* p, bool wgrad = false) {
   WinoPlan wp{};
+  if (wgrad && (long)xin->c * cout < 256 * 256) return wp;   // two transforms + slabs per GEMM: pays from 256 x 256 channels up
   if (!g_wino_on || p->kh != 3 || p->kw != 3 || p->stride != 1 || p->pad != p->dil || p->prec == 1) return wp;
   const int cin = xin->c;
   if (cin < 128 || cout < 128 || (cout & 3) || (cin & 3)) return wp;
@@ -843,6 +844,47 @@ int wino_conv(const pm_tensor* xin, const float* w, int w_cout, int w_cin, bool 
   k.a_bs = wp.g.tiles * wp.Kp, k.b_bs = (long)cout * wp.Kp, k.c_bs = wp.g.tiles * cout;
   if (int e = launch<MODE_FWD>(k, wp.pl, st, 16, 2.0 * 16.0 * (double)wp.g.tiles * cout * xin->c)) return e;
   return pm_wino_output_xf(Mo, cout, wp.g, (float*)yout->ptr, yout->pitch, ep.bias, ep.scale, ep.shift, ep.residual, ep.residual_pitch, ep.relu, st);
+}
+
+// weight gradient: dU[p] = Z[p]^T V[p] (16 batched wgrad GEMMs, K = tiles, split-K into slabs) ; dw = Gt (sum of slabs) G
+struct WinoWgradPlan {
+  Plan pl;
+  size_t slab_bytes;
+};
+WinoWgradPlan wino_wgrad_plan(const WinoPlan& wp, int cout) {
+  WinoWgradPlan q{};
+  q.pl.bm = 128, q.pl.bn = 128;
+  q.pl.tiles_m = pm_cdiv(cout, 128), q.pl.tiles_n = pm_cdiv(wp.Kp, 128);
+  const long ksteps = (wp.g.tiles + BK - 1) / BK;
+  const long per_split = (long)q.pl.tiles_m * q.pl.tiles_n * 16;
+  long ks = std::max<long>(1, std::min<long>((768 + per_split / 2) / per_split, ksteps / 8));   // ~3 rounds of 256 CUs, >= 8 K-steps per block
+  const long steps_per = (ksteps + ks - 1) / ks;
+  ks = (ksteps + steps_per - 1) / steps_per;
+  q.pl.ksplit = (int)ks, q.pl.kper = (int)(steps_per * BK), q.pl.ws_bytes = 0;
+  q.slab_bytes = pm_align_up((size_t)ks * 16 * cout * wp.Kp * sizeof(float), 256);
+  return q;
+}
+inline size_t wino_wgrad_ws(const WinoPlan& wp, const WinoWgradPlan& q) { return wp.v_bytes + wp.m_bytes + q.slab_bytes; }
+
+int wino_wgrad(const pm_tensor* x, const pm_tensor* dy, float* dw, const WinoPlan& wp, const WinoWgradPlan& q, void* ws, hipStream_t st) {
+  float* V = (float*)ws;
+  float* Z = (float*)((char*)ws + wp.v_bytes);
+  float* slab = (float*)((char*)ws + wp.v_bytes + wp.m_bytes);
+  const int cout = dy->c;
+  if (int e = pm_wino_input_xf((const float*)x->ptr, x->pitch, x->c, wp.Kp, wp.g, V, st)) return e;
+  if (int e = pm_wino_dy_xf((const float*)dy->ptr, dy->pitch, cout, wp.g, Z, st)) return e;
+  const pm_tensor xv = {V, 1, 1, (int32_t)wp.g.tiles, wp.Kp, wp.Kp};
+  const pm_tensor zv = {Z, 1, 1, (int32_t)wp.g.tiles, cout, cout};
+  const pm_conv_params p1 = {1, 1, 1, 0, 1, 0};
+  ConvK k;
+  fill_geom(k, &xv, &zv, &p1);
+  k.A = Z, k.B = V, k.C = slab;
+  k.M = cout, k.Nn = wp.Kp, k.K = (int)wp.g.tiles;
+  k.a_bytes = (unsigned)(wp.g.tiles * cout * 4), k.b_bytes = (unsigned)(wp.g.tiles * wp.Kp * 4), k.kmode = K_MID;
+  k.c_pitch = wp.Kp, k.c_split = (long)16 * cout * wp.Kp;
+  k.a_bs = wp.g.tiles * cout, k.b_bs = wp.g.tiles * wp.Kp, k.c_bs = (long)cout * wp.Kp;
+  if (int e = launch<MODE_WGRAD>(k, q.pl, st, 16, 2.0 * 16.0 * (double)wp.g.tiles * cout * x->c)) return e;
+  return pm_wino_dw_xf(slab, q.pl.ksplit, cout, x->c, wp.Kp, dw, st);
 }
 
 void gemm_dims(int which, const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p, long& M, long& Nn, long& K) {
@@ -896,6 +938,11 @@ extern "C" size_t pm_conv_workspace(const pm_tensor* x, const pm_tensor* y, cons
   if (which == MODE_FWD || which == MODE_DGRAD) {
     const WinoPlan wp = which == MODE_FWD ? wino_plan(x, y->c, p) : wino_plan(y, x->c, p);
     if (wp.use) return wino_ws(wp);
+  }
+  const size_t bias_part = pm_align_up((size_t)pm_cdiv(pm_pixels(y), 2048) * y->c * sizeof(float), 256);
+  if (which == MODE_WGRAD) {
+    const WinoPlan wp = wino_plan(x, y->c, p, true);
+    if (wp.use) return pm_align_up(wino_wgrad_ws(wp, wino_wgrad_plan(wp, y->c)), 256) + bias_part;
   }
   long M, Nn, K;
   gemm_dims(which, x, y, p, M, Nn, K);
@@ -1038,13 +1085,20 @@ extern "C" int pm_conv_bwd_weight(const pm_tensor* x, const pm_tensor* dy, float
   Plan pl = make_plan(MODE_WGRAD, M, Nn, K);
   const size_t need = pm_conv_workspace(x, dy, p, MODE_WGRAD);
   PM_REQUIRE(need <= ws_bytes && ws, PM_EWORKSPACE, "conv_bwd_weight: workspace %zu < %zu", ws_bytes, need);
+  const WinoPlan wp = wino_plan(x, dy->c, p, true);
+  if (wp.use) {
+    const WinoWgradPlan q = wino_wgrad_plan(wp, dy->c);
+    if (int e = wino_wgrad(x, dy, dw, wp, q, ws, (hipStream_t)stream)) return e;
+    pl.ws_bytes = wino_wgrad_ws(wp, q);     // the bias partials follow the Winograd buffers
+  }
   ConvK k;
   fill_geom(k, x, dy, p);
   k.A = (const float*)dy->ptr, k.B = (const float*)x->ptr;
   k.M = (int)M, k.Nn = (int)Nn, k.K = (int)K;
   k.a_bytes = (unsigned)(pm_pixels(dy) * dy->pitch * 4), k.b_bytes = (unsigned)(pm_pixels(x) * x->pitch * 4), k.kmode = dy->w >= BK ? 1 : 2;
   hipStream_t st = (hipStream_t)stream;
-  if (pl.ksplit > 1) {
+  if (wp.use) {
+  } else if (pl.ksplit > 1) {
     k.C = (float*)ws, k.c_pitch = Nn, k.c_split = M * Nn;
     if (int e = launch<MODE_WGRAD>(k, pl, st)) return e;
     const int nb = (int)std::min<long>((M * Nn + 255) / 256, 4096);

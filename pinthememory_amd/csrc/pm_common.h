@@ -46,6 +46,9 @@ int pm_wino_filter_xf(const float* w, int Cout, int Cin, int Kp, bool dgrad, flo
 int pm_wino_output_xf(const float* M, int Cout, const pm_wino_geom& g, float* y, long ypitch, const float* bias, const float* scale, const float* shift,
                       const float* residual, long res_pitch, int relu, hipStream_t st);
 
+int pm_wino_dy_xf(const float* dy, long pitch, int Cout, const pm_wino_geom& g, float* Z, hipStream_t st);
+int pm_wino_dw_xf(const float* slab, int ks, int Cout, int Cin, int Kp, float* dw, hipStream_t st);
+
 // ---- device helpers -------------------------------------------------------------------------------------------
 __device__ __forceinline__ float pm_wave_sum(float v) {
 #pragma unroll

@@ -162,7 +162,88 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restric
   }
 }
 
+// Weight gradient, step 1: Z = A dY At -- the 2x2 output-gradient tile scattered to the 16 transform points (pixels outside the
+// image contribute 0).  dU[p][co][ci] = sum_tiles Z[p][tile][co] * V[p][tile][ci] is then a batched wgrad GEMM.
+__global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, long yp, int Cout, const pm_wino_geom g, float* __restrict__ Z) {
+  const int cg = Cout >> 2;
+  const long total = g.tiles * cg, plane = g.tiles * (long)Cout;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long tile = i / cg;
+    const int c = (int)(i - tile * cg) * 4;
+    const TileId t = decode_tile(tile, g);
+    float4 q[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int yy = t.ry + g.d * (2 * t.ty + a);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int xx = t.rx + g.d * (2 * t.tx + b);
+        q[a][b] = (yy < g.H && xx < g.W) ? PM_LD4(dy + ((long)(t.n * g.H + yy) * g.W + xx) * yp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 r[4][2];   // A dY: rows (y0, y0 + y1, y0 - y1, -y1)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      r[0][b] = q[0][b];
+      r[1][b] = f4add(q[0][b], q[1][b]);
+      r[2][b] = f4sub(q[0][b], q[1][b]);
+      r[3][b] = f4sub(zero, q[1][b]);
+    }
+    float* out = Z + tile * Cout + c;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {   // (A dY) At
+      PM_ST4(out + (a * 4 + 0) * plane, r[a][0]);
+      PM_ST4(out + (a * 4 + 1) * plane, f4add(r[a][0], r[a][1]));
+      PM_ST4(out + (a * 4 + 2) * plane, f4sub(r[a][0], r[a][1]));
+      PM_ST4(out + (a * 4 + 3) * plane, f4sub(zero, r[a][1]));
+    }
+  }
+}
+
+// Weight gradient, step 3: fixed-order sum of the split-K slabs [ks][16][Cout][Kp] and dw = Gt dU G -> KRSC [Cout][3][3][Cin].
+__global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ slab, int ks, int Cout, int Cin, int Kp, float* __restrict__ dw) {
+  const long total = (long)Cout * Cin, plane = (long)Cout * Kp;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int co = (int)(i / Cin), ci = (int)(i - (long)co * Cin);
+    const float* in = slab + (long)co * Kp + ci;
+    float u[4][4];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      float acc = 0.f;
+      for (int z = 0; z < ks; ++z) acc += in[((long)z * 16 + p) * plane];
+      u[p >> 2][p & 3] = acc;
+    }
+    float h[3][4];   // Gt dU
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      h[0][b] = u[0][b] + 0.5f * (u[1][b] + u[2][b]);
+      h[1][b] = 0.5f * (u[1][b] - u[2][b]);
+      h[2][b] = 0.5f * (u[1][b] + u[2][b]) + u[3][b];
+    }
+    float* out = dw + (long)co * 9 * Cin + ci;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {   // (Gt dU) G
+      out[(a * 3 + 0) * (long)Cin] = h[a][0] + 0.5f * (h[a][1] + h[a][2]);
+      out[(a * 3 + 1) * (long)Cin] = 0.5f * (h[a][1] - h[a][2]);
+      out[(a * 3 + 2) * (long)Cin] = 0.5f * (h[a][1] + h[a][2]) + h[a][3];
+    }
+  }
+}
+
 }  // namespace
+
+int pm_wino_dy_xf(const float* dy, long pitch, int Cout, const pm_wino_geom& g, float* Z, hipStream_t st) {
+  const long total = g.tiles * (Cout / 4);
+  hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 1 << 20)), dim3(256), 0, st, dy, pitch, Cout, g, Z);
+  return pm_check_launch("wino_dy");
+}
+
+int pm_wino_dw_xf(const float* slab, int ks, int Cout, int Cin, int Kp, float* dw, hipStream_t st) {
+  const long total = (long)Cout * Cin;
+  hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 1 << 16)), dim3(256), 0, st, slab, ks, Cout, Cin, Kp, dw);
+  return pm_check_launch("wino_dw");
+}
 
 pm_wino_geom pm_wino_make_geom(int n, int h, int w, int d) {
   pm_wino_geom g;

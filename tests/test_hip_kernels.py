@@ -95,8 +95,8 @@ def test_conv_winograd(K, case):
     x = rnd(n, cin, h, w, seed=1)
     wt = rnd(cout, cin, 3, 3, seed=2, scale=(2.0 / (cin * 9)) ** 0.5)
     b = rnd(cout, seed=3)
-    xr = x.double().requires_grad_(True)
-    y_ref = F.conv2d(xr, wt.double(), b.double(), padding=d, dilation=d)
+    xr, wr, br = x.double().requires_grad_(True), wt.double().requires_grad_(True), b.double().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, br, padding=d, dilation=d)
     dy = rnd(*y_ref.shape, seed=4)
     y_ref.backward(dy.double())
     add = rnd(n, cin, h, w, seed=5)
@@ -107,13 +107,16 @@ def test_conv_winograd(K, case):
         K.set_winograd(wino)
         try:
             y = K.conv_fwd(xg, wg, 1, d, d, bias=b.cuda(), out=buf[..., 32:32 + cout])
-            res[wino] = (nchw(y).clone(), nchw(K.conv_bwd_data(dyg, wg, tuple(xg.shape), 1, d, d, add=addg)))
+            dw, db = K.conv_bwd_weight(xg, dyg, tuple(wg.shape), 1, d, d, want_bias=True)
+            res[wino] = (nchw(y).clone(), nchw(K.conv_bwd_data(dyg, wg, tuple(xg.shape), 1, d, d, add=addg)), dw.permute(0, 3, 1, 2).cpu(), db.cpu())
         finally:
             K.set_winograd(True)
         assert buf[..., :32].abs().max().item() == 0 and buf[..., 32 + cout:].abs().max().item() == 0
     for wino in (True, False):
         assert rel(res[wino][0], y_ref.detach()) < 2e-5, wino
         assert rel(res[wino][1], xr.grad + add.double()) < 2e-5, wino
+        assert rel(res[wino][2], wr.grad) < 5e-5, wino
+        assert rel(res[wino][3], br.grad) < 2e-5, wino
     assert not torch.equal(res[True][0], res[False][0])
 
 
