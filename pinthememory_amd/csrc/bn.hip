@@ -45,22 +45,28 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
   }
 }
 
-// Second stage: 32 channels x 8 lanes per block; each lane sums a strided subset of the block partials in double, the 8
-// lane sums are combined in fixed order (deterministic, ~10 us instead of a 512-long serial chain per channel).
+// Second stage: 8 channels x 32 lanes per block; each lane sums a strided subset of the block partials in double, the 32
+// lane sums are combined in fixed order (deterministic; a 512-long serial chain per channel would cost ~100 us of pure latency).
+constexpr int FC = 8, FL = 32;
 __device__ __forceinline__ void final_sums(const float* __restrict__ part, int nb, int C, int c, int lane, double& s1, double& s2) {
-  __shared__ double red[8][32][2];
+  __shared__ double red[FL][FC][2];
   double a = 0.0, b = 0.0;
   if (c < C)
-    for (int i = lane; i < nb; i += 8) a += (double)part[((long)i * C + c) * 2], b += (double)part[((long)i * C + c) * 2 + 1];
-  red[lane][threadIdx.x & 31][0] = a, red[lane][threadIdx.x & 31][1] = b;
+    for (int i = lane; i < nb; i += FL) {
+      const float2 v = *reinterpret_cast<const float2*>(part + ((long)i * C + c) * 2);
+      a += (double)v.x, b += (double)v.y;
+    }
+  red[lane][threadIdx.x & (FC - 1)][0] = a, red[lane][threadIdx.x & (FC - 1)][1] = b;
   __syncthreads();
   s1 = s2 = 0.0;
+  if (lane == 0) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) s1 += red[i][threadIdx.x & 31][0], s2 += red[i][threadIdx.x & 31][1];
+    for (int i = 0; i < FL; ++i) s1 += red[i][threadIdx.x & (FC - 1)][0], s2 += red[i][threadIdx.x & (FC - 1)][1];
+  }
 }
 
 __global__ __launch_bounds__(256) void bn_stats_final(const float* __restrict__ part, int nb, const float* __restrict__ x, long P, int C, float* __restrict__ moments) {
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), lane = threadIdx.x >> 5;
+  const int c = blockIdx.x * FC + (threadIdx.x & (FC - 1)), lane = threadIdx.x / FC;
   double s1, s2;
   final_sums(part, nb, C, c, lane, s1, s2);
   if (lane != 0 || c >= C) return;
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
   }
 }
 __global__ __launch_bounds__(256) void bn_bwd_final(const float* __restrict__ part, int nb, int C, float* __restrict__ sums) {
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), lane = threadIdx.x >> 5;
+  const int c = blockIdx.x * FC + (threadIdx.x & (FC - 1)), lane = threadIdx.x / FC;
   double s1, s2;
   final_sums(part, nb, C, c, lane, s1, s2);
   if (lane != 0 || c >= C) return;
@@ -175,7 +181,7 @@ extern "C" int pm_bn_stats(const pm_tensor* x, float* moments, void* ws, size_t 
   const int rows = chunk_rows(P), nb = pm_cdiv(P, rows);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_stats_partial, dim3(nb, pm_cdiv(x->c, CB)), dim3(256), 0, st, (const float*)x->ptr, (long)x->pitch, P, x->c, rows, (float*)ws);
-  hipLaunchKernelGGL(bn_stats_final, dim3(pm_cdiv(x->c, 32)), dim3(256), 0, st, (const float*)ws, nb, (const float*)x->ptr, P, x->c, moments);
+  hipLaunchKernelGGL(bn_stats_final, dim3(pm_cdiv(x->c, FC)), dim3(256), 0, st, (const float*)ws, nb, (const float*)x->ptr, P, x->c, moments);
   return pm_check_launch("bn_stats");
 }
 
@@ -242,7 +248,7 @@ extern "C" int pm_bn_bwd_reduce(const pm_tensor* dy, const pm_tensor* y, const p
   else
     hipLaunchKernelGGL(bn_bwd_partial<false>, grid, dim3(256), 0, st, (const float*)dy->ptr, (long)dy->pitch, (const float*)nullptr, 0l,
                        (const float*)x->ptr, (long)x->pitch, mean, invstd, P, x->c, rows, (float*)ws);
-  hipLaunchKernelGGL(bn_bwd_final, dim3(pm_cdiv(x->c, 32)), dim3(256), 0, st, (const float*)ws, nb, x->c, sums);
+  hipLaunchKernelGGL(bn_bwd_final, dim3(pm_cdiv(x->c, FC)), dim3(256), 0, st, (const float*)ws, nb, x->c, sums);
   return pm_check_launch("bn_bwd_reduce");
 }
 

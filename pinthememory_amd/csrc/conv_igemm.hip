@@ -9,6 +9,7 @@
 // 256 threads = 4 waves; each wave owns TMxTN MFMA tiles of 32x32; LDS double-buffered, next K-slab prefetched to
 // registers while the current one feeds the matrix pipe (one barrier per K-step).
 // Replaces nn.Conv2d fwd/bwd of /root/reference/network/Resnet.py:145-150,404,453-457, deepv3plus.py:72-81,398-424.
+#include <stdlib.h>
 #include <algorithm>
 #include <type_traits>
 #include <vector>
@@ -84,8 +85,8 @@ enum { K_FAST = 0, K_MID = 1, K_SMALL = 2 };
 // PREC 0: operands stay fp32 -> v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 157 TF). PREC 1: the fp32 tiles staged in LDS are
 // rounded to bf16 (RNE, v_cvt_pk_bf16_f32) as the fragments are read -> v_mfma_f32_32x32x16_bf16 with fp32 accumulation (2.5 PF):
 // BASELINE configs[2]. Gathers, LDS layout and epilogue are shared; storage stays fp32.
-// NST: LDS stages. 2 = double-buffered (default). 1 = single buffer for short reductions (<= 4 K-steps: the 64->256 / 128->512
-// expansion 1x1s), halving the LDS footprint so that three blocks share a CU and cover each other's load / store phases.
+// NST: LDS stages. 2 = double-buffered (default). 1 = single buffer for short reductions (<= 16 K-steps: the 1x1 convolutions and the
+// Winograd GEMMs with <= 512 input channels), halving the LDS footprint so that three blocks share a CU and cover each other's load / store phases.
 template <int MODE, int BM, int BN, int WM, int WN, int KM, int PREC, int NST>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   constexpr bool A_KC = (MODE != MODE_WGRAD);  // A tile stored [BM][LDK] (k contiguous) else [BK][BM]
@@ -698,11 +699,19 @@ void launch_nst(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
   (void)attr_set;
   hipLaunchKernelGGL((conv_igemm_kernel<MODE, BM, BN, WM, WN, KM, PREC, NST>), grid, dim3(256), smem / (NST == 1 ? 2 : 1), st, k);
 }
+// longest reduction (in K-steps per block) that takes the single-stage variant; PM_NST1_STEPS overrides it for tuning runs
+inline int nst1_max_steps() {
+  static const int v = [] {
+    const char* e = getenv("PM_NST1_STEPS");
+    return e ? atoi(e) : 16;
+  }();
+  return v;
+}
 template <int MODE, int BM, int BN, int WM, int WN, int KM, int PREC>
 void launch_prec(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
   // single-stage variant only where it is used: fast-path fwd / dgrad with a short reduction per block
   if constexpr (KM == K_FAST && MODE != MODE_WGRAD && BN >= 64) {
-    if (k.kper <= 4 * BK) return launch_nst<MODE, BM, BN, WM, WN, KM, PREC, 1>(k, grid, smem, st);
+    if (k.kper <= nst1_max_steps() * BK) return launch_nst<MODE, BM, BN, WM, WN, KM, PREC, 1>(k, grid, smem, st);
   }
   launch_nst<MODE, BM, BN, WM, WN, KM, PREC, 2>(k, grid, smem, st);
 }
@@ -738,7 +747,7 @@ int launch(const ConvK& k0, const Plan& p, hipStream_t st, int batch = 1, double
   ProfRec rec;
   if (g_prof_on) {
     (void)hipEventCreate(&rec.a), (void)hipEventCreate(&rec.b);
-    rec.mode = MODE, rec.bm = p.bm, rec.bn = p.bn, rec.km = (MODE == MODE_WGRAD && k.kmode == K_FAST) ? K_MID : k.kmode, rec.prec = k.prec, rec.nst = (MODE != MODE_WGRAD && k.kmode == K_FAST && p.bn >= 64 && k.kper <= 4 * BK) ? 1 : 2, rec.flops = flops >= 0.0 ? flops : 2.0 * (double)k.M * (double)k.Nn * (double)k.K * batch;
+    rec.mode = MODE, rec.bm = p.bm, rec.bn = p.bn, rec.km = (MODE == MODE_WGRAD && k.kmode == K_FAST) ? K_MID : k.kmode, rec.prec = k.prec, rec.nst = (MODE != MODE_WGRAD && k.kmode == K_FAST && p.bn >= 64 && k.kper <= nst1_max_steps() * BK) ? 1 : 2, rec.flops = flops >= 0.0 ? flops : 2.0 * (double)k.M * (double)k.Nn * (double)k.K * batch;
     (void)hipEventRecord(rec.a, st);
   }
   constexpr bool akc = MODE != MODE_WGRAD, bkc = MODE == MODE_FWD;
