@@ -61,10 +61,12 @@ int pm_conv_bwd_data(const pm_tensor* dy, const float* w_krsc, const pm_tensor* 
 int pm_conv_bwd_weight(const pm_tensor* x, const pm_tensor* dy, float* dw_krsc, float* dbias, const pm_conv_params* p,
                        void* ws, size_t ws_bytes, void* stream);
 
-/* Wide stride-1 3x3 convolutions with pad == dilation (Resnet.py:195 conv2 of layer3/4, deepv3plus.py:72-81 ASPP branches,
- * :398-404 final1, :455 dsn) run as Winograd F(2x2,3x3) in fp32 by default -- 2.25x fewer MFMA FLOPs, results within a few fp32
- * ulp of the direct algorithm. pm_set_winograd(0) forces the direct implicit GEMM everywhere (A/B measurements, parity tests). */
-int pm_set_winograd(int on);
+/* Wide stride-1 3x3 convolutions with pad == dilation (Resnet.py:195 conv2 of layer2/3/4, deepv3plus.py:72-81 ASPP branches,
+ * :398-404 final1, :455 dsn) run as Winograd convolutions in fp32: F(4x4,3x3) (4x fewer MFMA FLOPs) where the image tiles by
+ * 4*dilation, else F(2x2,3x3) (2.25x fewer), else direct. Results stay within fp32 rounding of an fp64 convolution (max error
+ * ~3e-6 of the output scale for F(4x4), ~4e-7 for F(2x2); the direct MFMA chain: ~5e-7).
+ * mode: 0 = direct implicit GEMM everywhere, 2 = F(2x2) only, 4 = prefer F(4x4) (default). */
+int pm_set_winograd(int mode);
 
 /* In-library HIP-event timing of the implicit-GEMM kernel (bench.py's roofline leg). While enabled every conv launch is
  * bracketed by two events on its stream; pm_profile_read sums duration and algorithmic FLOPs (2*M*N*K) of one

@@ -798,33 +798,39 @@ void fill_geom(ConvK& k, const pm_tensor* x, const pm_tensor* y, const pm_conv_p
   k.a_bs = k.b_bs = k.c_bs = 0;
 }
 
-// ---- Winograd F(2x2,3x3) route for the wide stride-1 "same" 3x3 convolutions (transforms: winograd.hip) ------------------------
-// forward:  V = Bt x B ; M[p] = V[p] U[p]^T (16 batched GEMMs on the kernel above) ; y = At M A (+ epilogue)
+// ---- Winograd F(m x m, 3x3) route for the wide stride-1 "same" 3x3 convolutions (transforms: winograd.hip) ---------------------
+// forward:  V = Bt x B ; M[p] = V[p] U[p]^T (P = (m+2)^2 batched GEMMs on the kernel above) ; y = At M A (+ epilogue)
 // data grad: the same pipeline on dy with the rotated / transposed filter.
-// Taken when the GEMMs are MFMA-bound (both channel counts >= 128: the 4x-expanded V / M streams would otherwise dominate) and the
-// dilation sub-lattices tile the image without much padding (H, W multiples of 2*dil: d = 1, 2, 6, 12 on the 48x48 maps).
-bool g_wino_on = true;
+// Taken when the GEMMs are MFMA-bound (both channel counts >= 128: the expanded V / M streams would otherwise dominate) and the
+// dilation sub-lattices tile the image without much padding: m = 4 when H, W are multiples of 4*dil (d = 1, 2, 6, 12 on the 48x48
+// maps, d = 1 on 192x192), else m = 2, else the direct algorithm.
+int g_wino_mode = 4;   // 0 off, 2 F(2x2) only, 4 prefer F(4x4)
 struct WinoPlan {
   bool use;
   pm_wino_geom g;
-  int Kp;
+  int Kp, P;
   size_t v_bytes, m_bytes, u_bytes;
   Plan pl;
 };
 WinoPlan wino_plan(const pm_tensor* xin, int cout, const pm_conv_params* p, bool wgrad = false) {
   WinoPlan wp{};
   if (wgrad && (long)xin->c * cout < 256 * 256) return wp;   // two transforms + slabs per GEMM: pays from 256 x 256 channels up
-  if (!g_wino_on || p->kh != 3 || p->kw != 3 || p->stride != 1 || p->pad != p->dil || p->prec == 1) return wp;
+  if (g_wino_mode == 0 || p->kh != 3 || p->kw != 3 || p->stride != 1 || p->pad != p->dil || p->prec == 1) return wp;
   const int cin = xin->c;
   if (cin < 128 || cout < 128 || (cout & 3) || (cin & 3)) return wp;
-  wp.g = pm_wino_make_geom(xin->n, xin->h, xin->w, p->dil);
-  const double cover = (double)(2 * wp.g.TY * p->dil) * (double)(2 * wp.g.TX * p->dil) / ((double)xin->h * xin->w);
-  if (cover > 1.15) return wp;
+  int m = 0;
+  for (int cand = g_wino_mode; cand >= 2 && !m; cand -= 2) {
+    const pm_wino_geom g = pm_wino_make_geom(xin->n, xin->h, xin->w, p->dil, cand);
+    const double cover = (double)(cand * g.TY * p->dil) * (double)(cand * g.TX * p->dil) / ((double)xin->h * xin->w);
+    if (cover <= 1.15) m = cand, wp.g = g;
+  }
+  if (!m) return wp;
+  wp.P = (m + 2) * (m + 2);
   wp.Kp = (cin + BK - 1) / BK * BK;
   if (wp.g.tiles * (long)std::max(wp.Kp, cout) * 4 >= (1ll << 31)) return wp;
-  wp.v_bytes = pm_align_up((size_t)16 * wp.g.tiles * wp.Kp * sizeof(float), 256);
-  wp.m_bytes = pm_align_up((size_t)16 * wp.g.tiles * cout * sizeof(float), 256);
-  wp.u_bytes = pm_align_up((size_t)16 * cout * wp.Kp * sizeof(float), 256);
+  wp.v_bytes = pm_align_up((size_t)wp.P * wp.g.tiles * wp.Kp * sizeof(float), 256);
+  wp.m_bytes = pm_align_up((size_t)wp.P * wp.g.tiles * cout * sizeof(float), 256);
+  wp.u_bytes = pm_align_up((size_t)wp.P * cout * wp.Kp * sizeof(float), 256);
   wp.pl.bm = 128, wp.pl.bn = 128;
   wp.pl.tiles_m = pm_cdiv(wp.g.tiles, 128), wp.pl.tiles_n = pm_cdiv(cout, 128);
   wp.pl.ksplit = 1, wp.pl.kper = wp.Kp, wp.pl.ws_bytes = 0;
@@ -840,7 +846,7 @@ int wino_conv(const pm_tensor* xin, const float* w, int w_cout, int w_cin, bool 
   float* U = (float*)((char*)ws + wp.v_bytes + wp.m_bytes);
   const int cout = yout->c;
   if (int e = pm_wino_input_xf((const float*)xin->ptr, xin->pitch, xin->c, wp.Kp, wp.g, V, st)) return e;
-  if (int e = pm_wino_filter_xf(w, w_cout, w_cin, wp.Kp, dgrad, U, st)) return e;
+  if (int e = pm_wino_filter_xf(w, w_cout, w_cin, wp.Kp, dgrad, wp.g.m, U, st)) return e;
   const pm_tensor xv = {V, 1, 1, (int32_t)wp.g.tiles, wp.Kp, wp.Kp};
   const pm_tensor yv = {Mo, 1, 1, (int32_t)wp.g.tiles, cout, cout};
   const pm_conv_params p1 = {1, 1, 1, 0, 1, 0};
@@ -851,11 +857,11 @@ int wino_conv(const pm_tensor* xin, const float* w, int w_cout, int w_cin, bool 
   k.a_bytes = (unsigned)(wp.g.tiles * wp.Kp * 4), k.b_bytes = (unsigned)((long)cout * wp.Kp * 4), k.kmode = K_FAST;
   k.c_pitch = cout, k.c_split = 0;
   k.a_bs = wp.g.tiles * wp.Kp, k.b_bs = (long)cout * wp.Kp, k.c_bs = wp.g.tiles * cout;
-  if (int e = launch<MODE_FWD>(k, wp.pl, st, 16, 2.0 * 16.0 * (double)wp.g.tiles * cout * xin->c)) return e;
+  if (int e = launch<MODE_FWD>(k, wp.pl, st, wp.P, 2.0 * wp.P * (double)wp.g.tiles * cout * xin->c)) return e;
   return pm_wino_output_xf(Mo, cout, wp.g, (float*)yout->ptr, yout->pitch, ep.bias, ep.scale, ep.shift, ep.residual, ep.residual_pitch, ep.relu, st);
 }
 
-// weight gradient: dU[p] = Z[p]^T V[p] (16 batched wgrad GEMMs, K = tiles, split-K into slabs) ; dw = Gt (sum of slabs) G
+// weight gradient: dU[p] = Z[p]^T V[p] (P batched wgrad GEMMs, K = tiles, split-K into slabs) ; dw = Gt (sum of slabs) G
 struct WinoWgradPlan {
   Plan pl;
   size_t slab_bytes;
@@ -865,12 +871,12 @@ WinoWgradPlan wino_wgrad_plan(const WinoPlan& wp, int cout) {
   q.pl.bm = 128, q.pl.bn = 128;
   q.pl.tiles_m = pm_cdiv(cout, 128), q.pl.tiles_n = pm_cdiv(wp.Kp, 128);
   const long ksteps = (wp.g.tiles + BK - 1) / BK;
-  const long per_split = (long)q.pl.tiles_m * q.pl.tiles_n * 16;
+  const long per_split = (long)q.pl.tiles_m * q.pl.tiles_n * wp.P;
   long ks = std::max<long>(1, std::min<long>((768 + per_split / 2) / per_split, ksteps / 8));   // ~3 rounds of 256 CUs, >= 8 K-steps per block
   const long steps_per = (ksteps + ks - 1) / ks;
   ks = (ksteps + steps_per - 1) / steps_per;
   q.pl.ksplit = (int)ks, q.pl.kper = (int)(steps_per * BK), q.pl.ws_bytes = 0;
-  q.slab_bytes = pm_align_up((size_t)ks * 16 * cout * wp.Kp * sizeof(float), 256);
+  q.slab_bytes = pm_align_up((size_t)ks * wp.P * cout * wp.Kp * sizeof(float), 256);
   return q;
 }
 inline size_t wino_wgrad_ws(const WinoPlan& wp, const WinoWgradPlan& q) { return wp.v_bytes + wp.m_bytes + q.slab_bytes; }
@@ -890,10 +896,10 @@ int wino_wgrad(const pm_tensor* x, const pm_tensor* dy, float* dw, const WinoPla
   k.A = Z, k.B = V, k.C = slab;
   k.M = cout, k.Nn = wp.Kp, k.K = (int)wp.g.tiles;
   k.a_bytes = (unsigned)(wp.g.tiles * cout * 4), k.b_bytes = (unsigned)(wp.g.tiles * wp.Kp * 4), k.kmode = K_MID;
-  k.c_pitch = wp.Kp, k.c_split = (long)16 * cout * wp.Kp;
+  k.c_pitch = wp.Kp, k.c_split = (long)wp.P * cout * wp.Kp;
   k.a_bs = wp.g.tiles * cout, k.b_bs = wp.g.tiles * wp.Kp, k.c_bs = (long)cout * wp.Kp;
-  if (int e = launch<MODE_WGRAD>(k, q.pl, st, 16, 2.0 * 16.0 * (double)wp.g.tiles * cout * x->c)) return e;
-  return pm_wino_dw_xf(slab, q.pl.ksplit, cout, x->c, wp.Kp, dw, st);
+  if (int e = launch<MODE_WGRAD>(k, q.pl, st, wp.P, 2.0 * wp.P * (double)wp.g.tiles * cout * x->c)) return e;
+  return pm_wino_dw_xf(slab, q.pl.ksplit, cout, x->c, wp.Kp, wp.g.m, dw, st);
 }
 
 void gemm_dims(int which, const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p, long& M, long& Nn, long& K) {
@@ -905,8 +911,9 @@ void gemm_dims(int which, const pm_tensor* x, const pm_tensor* y, const pm_conv_
 
 }  // namespace
 
-extern "C" int pm_set_winograd(int on) {
-  g_wino_on = on != 0;
+extern "C" int pm_set_winograd(int mode) {
+  PM_REQUIRE(mode == 0 || mode == 2 || mode == 4, PM_EINVAL, "pm_set_winograd: mode %d (0 off, 2 F(2x2,3x3), 4 prefer F(4x4,3x3))", mode);
+  g_wino_mode = mode;
   return PM_OK;
 }
 extern "C" int pm_profile_enable(int on) {

@@ -35,19 +35,18 @@ static inline size_t pm_align_up(size_t v, size_t a) { return (v + a - 1) / a * 
 // Vectorisable NHWC view: base 16B-aligned, pitch % 4 == 0.
 static inline bool pm_vec_ok(const pm_tensor* t) { return pm_aligned16(t->ptr) && (t->pitch % 4) == 0; }
 
-// ---- Winograd F(2x2,3x3) transforms (winograd.hip), driven by the conv entry points in conv_igemm.hip -------------------
+// ---- Winograd F(m x m, 3x3) transforms, m = 2 / 4 (winograd.hip), driven by the conv entry points in conv_igemm.hip ------------
 struct pm_wino_geom {
-  int N, H, W, d, TY, TX;   // tiles per image = d*d sub-lattices x TY x TX tiles of 2x2 outputs
+  int N, H, W, d, m, TY, TX;   // tiles per image = d*d sub-lattices x TY x TX tiles of m x m outputs
   long tiles;
 };
-pm_wino_geom pm_wino_make_geom(int n, int h, int w, int d);
+pm_wino_geom pm_wino_make_geom(int n, int h, int w, int d, int m);
 int pm_wino_input_xf(const float* x, long pitch, int C, int Kp, const pm_wino_geom& g, float* V, hipStream_t st);
-int pm_wino_filter_xf(const float* w, int Cout, int Cin, int Kp, bool dgrad, float* U, hipStream_t st);
+int pm_wino_filter_xf(const float* w, int Cout, int Cin, int Kp, bool dgrad, int m, float* U, hipStream_t st);
 int pm_wino_output_xf(const float* M, int Cout, const pm_wino_geom& g, float* y, long ypitch, const float* bias, const float* scale, const float* shift,
                       const float* residual, long res_pitch, int relu, hipStream_t st);
-
 int pm_wino_dy_xf(const float* dy, long pitch, int Cout, const pm_wino_geom& g, float* Z, hipStream_t st);
-int pm_wino_dw_xf(const float* slab, int ks, int Cout, int Cin, int Kp, float* dw, hipStream_t st);
+int pm_wino_dw_xf(const float* slab, int ks, int Cout, int Cin, int Kp, int m, float* dw, hipStream_t st);
 
 // ---- device helpers -------------------------------------------------------------------------------------------
 __device__ __forceinline__ float pm_wave_sum(float v) {

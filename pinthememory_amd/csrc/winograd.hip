@@ -1,125 +1,235 @@
-// Winograd F(2x2, 3x3) transforms for the stride-1 "same" 3x3 convolutions (pad == dilation) of the trunk / ASPP / decoder.
+// Winograd F(m x m, 3x3) transforms, m = 2 or 4, for the stride-1 "same" 3x3 convolutions (pad == dilation) of the trunk / ASPP /
+// decoder.
 //
-//   Y = At [ (G g Gt) .* (Bt d B) ] A          (Lavin & Gray; correlation form, fp32 throughout)
+//   Y = At [ (G g Gt) .* (Bt d B) ] A          (Lavin & Gray; correlation form, fp32 throughout; points 0, +-1 (, +-2), inf)
 //
-// The element-wise product over channels is 16 independent GEMMs [tiles x Cin] x [Cin x Cout], which run on the implicit-GEMM kernel
-// of conv_igemm.hip as a batched 1x1 convolution (blockIdx.y = transform point): 16 multiplies per 2x2 output tile instead of 36,
-// i.e. 2.25x fewer MFMA FLOPs than the direct algorithm.  The three transforms here are pure HBM streaming kernels:
-//   input   x  [N,H,W,C]       -> V [16][tiles][Kp]   (Kp = C rounded up to 32 so that the GEMM's K-state stays wave-uniform)
-//   filter  w  [Cout,3,3,Cin]  -> U [16][Cout][Kp]    (or the 180-degree-rotated, channel-transposed filter for the data gradient)
-//   output  M  [16][tiles][Cout] -> y [N,H,W,Cout]    (+ the fused epilogue: bias / affine / residual / ReLU)
+// The element-wise product over channels is P = (m+2)^2 independent GEMMs [tiles x Cin] x [Cin x Cout], which run on the
+// implicit-GEMM kernel of conv_igemm.hip as a batched 1x1 convolution (blockIdx.y = transform point): 16 multiplies per 2x2 output
+// tile (2.25x fewer MFMA FLOPs than the direct algorithm) or 36 per 4x4 tile (4x fewer).  The transforms here are pure HBM
+// streaming kernels:
+//   input   x  [N,H,W,C]        -> V [P][tiles][Kp]   (Kp = C rounded up to 32 so that the GEMM's K-state stays wave-uniform)
+//   filter  w  [Cout,3,3,Cin]   -> U [P][Cout][Kp]    (or the 180-degree-rotated, channel-transposed filter for the data gradient)
+//   output  M  [P][tiles][Cout] -> y [N,H,W,Cout]     (+ the fused epilogue: bias / affine / residual / ReLU)
+//   weight gradient: Z = A dY At [P][tiles][Cout];  dU[p] = Z[p]^T V[p] (batched wgrad GEMM, split-K slabs);  dw = Gt (sum dU) G
 // A dilated convolution (d > 1) is d*d independent undilated convolutions on the sub-lattices (y % d, x % d); the tile index
-// enumerates (image, sub-lattice, tile row, tile column) and the transforms address pixels as  r + d * (2 t + a - 1).
+// enumerates (image, sub-lattice, tile row, tile column) and the transforms address pixels as  r + d * (m t + a - 1).
 #include "pm_common.h"
 
 namespace {
 
-__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+// ---- transform matrices as compile-time functions (every use is fully unrolled, so zero coefficients vanish) ---------------------
+enum { W_BT = 0, W_AT = 1, W_G = 2, W_A = 3, W_GT = 4 };   // W_A = At^T, W_GT = G^T
+
+template <int MT>
+__host__ __device__ constexpr float wino_bt(int i, int j) {
+  if (MT == 2) {
+    constexpr float t[4][4] = {{1, 0, -1, 0}, {0, 1, 1, 0}, {0, -1, 1, 0}, {0, 1, 0, -1}};
+    return t[i & 3][j & 3];
+  }
+  constexpr float t[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0}, {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+  return t[i][j];
+}
+template <int MT>
+__host__ __device__ constexpr float wino_at(int i, int j) {
+  if (MT == 2) {
+    constexpr float t[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
+    return t[i & 1][j & 3];
+  }
+  constexpr float t[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+  return t[i][j];
+}
+template <int MT>
+__host__ __device__ constexpr float wino_g(int i, int j) {
+  if (MT == 2) {
+    constexpr float t[4][3] = {{1, 0, 0}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0, 0, 1}};
+    return t[i & 3][j];
+  }
+  constexpr float t[6][3] = {{1.f / 4, 0, 0},          {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                             {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6},  {0, 0, 1}};
+  return t[i][j];
+}
+template <int MT, int WHICH>
+__host__ __device__ constexpr float wino_coef(int r, int c) {
+  return WHICH == W_BT ? wino_bt<MT>(r, c) : WHICH == W_AT ? wino_at<MT>(r, c) : WHICH == W_G ? wino_g<MT>(r, c) : WHICH == W_A ? wino_at<MT>(c, r) : wino_g<MT>(c, r);
+}
+
+template <int W>
+struct Vec {
+  float v[W];
+};
+template <int W>
+__device__ __forceinline__ Vec<W> vzero() {
+  Vec<W> r;
+#pragma unroll
+  for (int i = 0; i < W; ++i) r.v[i] = 0.f;
+  return r;
+}
+template <int W>
+__device__ __forceinline__ Vec<W> vload(const float* p) {
+  Vec<W> r;
+  if constexpr (W == 4) {
+    const float4 q = PM_LD4(p);
+    r.v[0] = q.x, r.v[1] = q.y, r.v[2] = q.z, r.v[3] = q.w;
+  } else if constexpr (W == 2) {
+    const float2 q = *reinterpret_cast<const float2*>(p);
+    r.v[0] = q.x, r.v[1] = q.y;
+  } else {
+    r.v[0] = *p;
+  }
+  return r;
+}
+template <int W>
+__device__ __forceinline__ void vstore(float* p, const Vec<W>& r) {
+  if constexpr (W == 4) PM_ST4(p, make_float4(r.v[0], r.v[1], r.v[2], r.v[3]));
+  else if constexpr (W == 2) *reinterpret_cast<float2*>(p) = make_float2(r.v[0], r.v[1]);
+  else *p = r.v[0];
+}
+
+// out[r] = sum_c coef(r, c) * in[c], r < R, c < C: constants folded, +-1 become adds, zeros disappear
+template <int MT, int WHICH, int R, int C, int W>
+__device__ __forceinline__ void mat_apply(const Vec<W> (&in)[C], Vec<W> (&out)[R]) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    Vec<W> acc = vzero<W>();
+    bool first = true;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float k = wino_coef<MT, WHICH>(r, c);
+      if (k == 0.f) continue;
+#pragma unroll
+      for (int i = 0; i < W; ++i) {
+        if (first) acc.v[i] = k == 1.f ? in[c].v[i] : (k == -1.f ? -in[c].v[i] : k * in[c].v[i]);
+        else if (k == 1.f) acc.v[i] += in[c].v[i];
+        else if (k == -1.f) acc.v[i] -= in[c].v[i];
+        else acc.v[i] = fmaf(k, in[c].v[i], acc.v[i]);
+      }
+      first = false;
+    }
+    out[r] = acc;
+  }
+}
 
 struct TileId {
   int n, ry, rx, ty, tx;
 };
-__device__ __forceinline__ TileId decode_tile(long tile, const pm_wino_geom& g) {
+__device__ __forceinline__ TileId decode_tile(unsigned tile, const pm_wino_geom& g) {
   TileId t;
-  t.tx = (int)(tile % g.TX);
-  long q = tile / g.TX;
-  t.ty = (int)(q % g.TY);
-  q /= g.TY;
-  t.rx = (int)(q % g.d);
-  q /= g.d;
-  t.ry = (int)(q % g.d);
-  t.n = (int)(q / g.d);
+  t.tx = (int)(tile % (unsigned)g.TX);
+  unsigned q = tile / (unsigned)g.TX;
+  t.ty = (int)(q % (unsigned)g.TY);
+  q /= (unsigned)g.TY;
+  t.rx = (int)(q % (unsigned)g.d);
+  q /= (unsigned)g.d;
+  t.ry = (int)(q % (unsigned)g.d);
+  t.n = (int)(q / (unsigned)g.d);
   return t;
 }
 
-__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, long xp, int C, int Kp, const pm_wino_geom g,
-                                                         float* __restrict__ V) {
-  const int kg = Kp >> 2;
-  const long total = g.tiles * kg, plane = g.tiles * (long)Kp;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long tile = i / kg;
-    const int c = (int)(i - tile * kg) * 4;
+// thread -> (tile, W channels); W = 4 floats for m = 2, 2 floats for m = 4 (36 live values per lane)
+template <int MT, int W>
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, long xp, int C, int Kp, const pm_wino_geom g, float* __restrict__ V) {
+  constexpr int A = MT + 2;
+  const unsigned kg = Kp / W;
+  const unsigned total = (unsigned)g.tiles * kg;
+  const long plane = g.tiles * (long)Kp;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const unsigned tile = i / kg;
+    const int c = (int)(i - tile * kg) * W;
     const TileId t = decode_tile(tile, g);
     const bool cok = c < C;
-    float4 dm[4][4];
+    Vec<W> tt[A][A];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int yy = t.ry + g.d * (2 * t.ty + a - 1);
-      const bool yok = cok && (unsigned)yy < (unsigned)g.H;
+    for (int b = 0; b < A; ++b) {   // Bt d, one patch column at a time
+      const int xx = t.rx + g.d * (MT * t.tx + b - 1);
+      const bool xok = cok && (unsigned)xx < (unsigned)g.W;
+      Vec<W> col[A], o[A];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int xx = t.rx + g.d * (2 * t.tx + b - 1);
-        dm[a][b] = (yok && (unsigned)xx < (unsigned)g.W) ? PM_LD4(x + ((long)(t.n * g.H + yy) * g.W + xx) * xp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int a = 0; a < A; ++a) {
+        const int yy = t.ry + g.d * (MT * t.ty + a - 1);
+        col[a] = (xok && (unsigned)yy < (unsigned)g.H) ? vload<W>(x + ((long)(t.n * g.H + yy) * g.W + xx) * xp + c) : vzero<W>();
       }
-    }
-    float4 tt[4][4];
+      mat_apply<MT, W_BT>(col, o);
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {   // Bt d
-      tt[0][b] = f4sub(dm[0][b], dm[2][b]);
-      tt[1][b] = f4add(dm[1][b], dm[2][b]);
-      tt[2][b] = f4sub(dm[2][b], dm[1][b]);
-      tt[3][b] = f4sub(dm[1][b], dm[3][b]);
+      for (int a = 0; a < A; ++a) tt[a][b] = o[a];
     }
-    float* out = V + tile * Kp + c;
+    float* out = V + (long)tile * Kp + c;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {   // (Bt d) B
-      PM_ST4(out + (a * 4 + 0) * plane, f4sub(tt[a][0], tt[a][2]));
-      PM_ST4(out + (a * 4 + 1) * plane, f4add(tt[a][1], tt[a][2]));
-      PM_ST4(out + (a * 4 + 2) * plane, f4sub(tt[a][2], tt[a][1]));
-      PM_ST4(out + (a * 4 + 3) * plane, f4sub(tt[a][1], tt[a][3]));
+    for (int a = 0; a < A; ++a) {   // (Bt d) B
+      Vec<W> o[A];
+      mat_apply<MT, W_BT>(tt[a], o);
+#pragma unroll
+      for (int b = 0; b < A; ++b) vstore<W>(out + (a * A + b) * plane, o[b]);
     }
   }
 }
 
+template <int MT, int W>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, int Cout, const pm_wino_geom g, float* __restrict__ y, long yp,
                                                           const float* __restrict__ bias, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, const float* __restrict__ residual, long rp, int relu) {
-  const int cg = Cout >> 2;
-  const long total = g.tiles * cg, plane = g.tiles * (long)Cout;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long tile = i / cg;
-    const int c = (int)(i - tile * cg) * 4;
+  constexpr int A = MT + 2;
+  const unsigned cg = Cout / W;
+  const unsigned total = (unsigned)g.tiles * cg;
+  const long plane = g.tiles * (long)Cout;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const unsigned tile = i / cg;
+    const int c = (int)(i - tile * cg) * W;
     const TileId t = decode_tile(tile, g);
-    const float* in = M + tile * Cout + c;
-    float4 s[2][4];
+    const float* in = M + (long)tile * Cout + c;
+    Vec<W> s[MT][A];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {   // At m
-      const float4 m0 = PM_LD4(in + (0 + b) * plane), m1 = PM_LD4(in + (4 + b) * plane), m2 = PM_LD4(in + (8 + b) * plane),
-                   m3 = PM_LD4(in + (12 + b) * plane);
-      s[0][b] = f4add(f4add(m0, m1), m2);
-      s[1][b] = f4sub(f4sub(m1, m2), m3);
+    for (int b = 0; b < A; ++b) {   // At m
+      Vec<W> col[A], o[MT];
+#pragma unroll
+      for (int a = 0; a < A; ++a) col[a] = vload<W>(in + (a * A + b) * plane);
+      mat_apply<MT, W_AT>(col, o);
+#pragma unroll
+      for (int a = 0; a < MT; ++a) s[a][b] = o[a];
     }
-    float4 bi = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = bi;
-    if (bias) bi = PM_LD4(bias + c);
-    if (scale) sc = PM_LD4(scale + c), sh = PM_LD4(shift + c);
+    Vec<W> bi = vzero<W>(), sc = vzero<W>(), sh = vzero<W>();
+    if (bias) bi = vload<W>(bias + c);
+    if (scale) sc = vload<W>(scale + c), sh = vload<W>(shift + c);
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int yy = t.ry + g.d * (2 * t.ty + a);
+    for (int a = 0; a < MT; ++a) {
+      const int yy = t.ry + g.d * (MT * t.ty + a);
+      Vec<W> o[MT];
+      mat_apply<MT, W_AT>(s[a], o);   // (At m) A
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int xx = t.rx + g.d * (2 * t.tx + b);
+      for (int b = 0; b < MT; ++b) {
+        const int xx = t.rx + g.d * (MT * t.tx + b);
         if (yy >= g.H || xx >= g.W) continue;
-        float4 v = b == 0 ? f4add(f4add(s[a][0], s[a][1]), s[a][2]) : f4sub(f4sub(s[a][1], s[a][2]), s[a][3]);   // (At m) A
         const long pix = (long)(t.n * g.H + yy) * g.W + xx;
-        if (bias || scale) {
-          v.x = (v.x + bi.x) * sc.x + sh.x, v.y = (v.y + bi.y) * sc.y + sh.y;
-          v.z = (v.z + bi.z) * sc.z + sh.z, v.w = (v.w + bi.w) * sc.w + sh.w;
+        Vec<W> v = o[b];
+        if (bias) {
+#pragma unroll
+          for (int q = 0; q < W; ++q) v.v[q] += bi.v[q];
         }
-        if (residual) v = f4add(v, PM_LD4(residual + pix * rp + c));
-        if (relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
-        PM_ST4(y + pix * yp + c, v);
+        if (scale) {
+#pragma unroll
+          for (int q = 0; q < W; ++q) v.v[q] = v.v[q] * sc.v[q] + sh.v[q];
+        }
+        if (residual) {
+          const Vec<W> rr = vload<W>(residual + pix * rp + c);
+#pragma unroll
+          for (int q = 0; q < W; ++q) v.v[q] += rr.v[q];
+        }
+        if (relu) {
+#pragma unroll
+          for (int q = 0; q < W; ++q) v.v[q] = fmaxf(v.v[q], 0.f);
+        }
+        vstore<W>(y + pix * yp + c, v);
       }
     }
   }
 }
 
 // U = G g Gt for a 32 (rows of the GEMM's B) x 32 (its K) block of filters, staged through LDS so that both the KRSC read and the
-// [16][rows][Kp] write are coalesced for either orientation:
+// [P][rows][Kp] write are coalesced for either orientation:
 //   forward   rows = Cout, k = Cin,  g(ky,kx) = w[row][ky][kx][k]
 //   data grad rows = Cin,  k = Cout, g(ky,kx) = w[k][2-ky][2-kx][row]      (180-degree rotation, channels transposed)
-template <bool DGRAD>
+template <int MT, bool DGRAD>
 __global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restrict__ w, int Cout, int Cin, int Kp, float* __restrict__ U) {
+  constexpr int A = MT + 2;
   __shared__ float sg[9][32][33];   // [tap][co_local][ci_local]
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int R = DGRAD ? Cin : Cout;      // GEMM rows
@@ -137,140 +247,149 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restric
   for (int j = ty; j < 32; j += 8) {   // thread -> (row r0 + j, k = k0 + tx): coalesced over k
     const int row = r0 + j, k = k0 + tx;
     if (row >= R || k >= Kp) continue;
-    float gq[3][3];
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) gq[ky][kx] = DGRAD ? sg[(2 - ky) * 3 + (2 - kx)][tx][j] : sg[ky * 3 + kx][j][tx];
-    float gg[4][3];
+    const bool kok = k < Kr;
+    Vec<1> gg[A][3];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {   // G g
-      gg[0][kx] = gq[0][kx];
-      gg[1][kx] = 0.5f * (gq[0][kx] + gq[1][kx] + gq[2][kx]);
-      gg[2][kx] = 0.5f * (gq[0][kx] - gq[1][kx] + gq[2][kx]);
-      gg[3][kx] = gq[2][kx];
+      Vec<1> col[3], o[A];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) col[ky].v[0] = DGRAD ? sg[(2 - ky) * 3 + (2 - kx)][tx][j] : sg[ky * 3 + kx][j][tx];
+      mat_apply<MT, W_G>(col, o);
+#pragma unroll
+      for (int a = 0; a < A; ++a) gg[a][kx] = o[a];
     }
     float* out = U + (long)row * Kp + k;
-    const bool kok = k < Kr;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {      // (G g) Gt
-      out[(a * 4 + 0) * plane] = kok ? gg[a][0] : 0.f;
-      out[(a * 4 + 1) * plane] = kok ? 0.5f * (gg[a][0] + gg[a][1] + gg[a][2]) : 0.f;
-      out[(a * 4 + 2) * plane] = kok ? 0.5f * (gg[a][0] - gg[a][1] + gg[a][2]) : 0.f;
-      out[(a * 4 + 3) * plane] = kok ? gg[a][2] : 0.f;
+    for (int a = 0; a < A; ++a) {      // (G g) Gt
+      Vec<1> o[A];
+      mat_apply<MT, W_G>(gg[a], o);
+#pragma unroll
+      for (int b = 0; b < A; ++b) out[(a * A + b) * plane] = kok ? o[b].v[0] : 0.f;
     }
   }
 }
 
-// Weight gradient, step 1: Z = A dY At -- the 2x2 output-gradient tile scattered to the 16 transform points (pixels outside the
+// Weight gradient, step 1: Z = A dY At -- the m x m output-gradient tile scattered to the P transform points (pixels outside the
 // image contribute 0).  dU[p][co][ci] = sum_tiles Z[p][tile][co] * V[p][tile][ci] is then a batched wgrad GEMM.
+template <int MT, int W>
 __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, long yp, int Cout, const pm_wino_geom g, float* __restrict__ Z) {
-  const int cg = Cout >> 2;
-  const long total = g.tiles * cg, plane = g.tiles * (long)Cout;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long tile = i / cg;
-    const int c = (int)(i - tile * cg) * 4;
+  constexpr int A = MT + 2;
+  const unsigned cg = Cout / W;
+  const unsigned total = (unsigned)g.tiles * cg;
+  const long plane = g.tiles * (long)Cout;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const unsigned tile = i / cg;
+    const int c = (int)(i - tile * cg) * W;
     const TileId t = decode_tile(tile, g);
-    float4 q[2][2];
+    Vec<W> r[A][MT];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int yy = t.ry + g.d * (2 * t.ty + a);
+    for (int b = 0; b < MT; ++b) {   // A dY
+      const int xx = t.rx + g.d * (MT * t.tx + b);
+      Vec<W> col[MT], o[A];
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int xx = t.rx + g.d * (2 * t.tx + b);
-        q[a][b] = (yy < g.H && xx < g.W) ? PM_LD4(dy + ((long)(t.n * g.H + yy) * g.W + xx) * yp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int a = 0; a < MT; ++a) {
+        const int yy = t.ry + g.d * (MT * t.ty + a);
+        col[a] = (yy < g.H && xx < g.W) ? vload<W>(dy + ((long)(t.n * g.H + yy) * g.W + xx) * yp + c) : vzero<W>();
       }
-    }
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 r[4][2];   // A dY: rows (y0, y0 + y1, y0 - y1, -y1)
+      mat_apply<MT, W_A>(col, o);
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      r[0][b] = q[0][b];
-      r[1][b] = f4add(q[0][b], q[1][b]);
-      r[2][b] = f4sub(q[0][b], q[1][b]);
-      r[3][b] = f4sub(zero, q[1][b]);
+      for (int a = 0; a < A; ++a) r[a][b] = o[a];
     }
-    float* out = Z + tile * Cout + c;
+    float* out = Z + (long)tile * Cout + c;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {   // (A dY) At
-      PM_ST4(out + (a * 4 + 0) * plane, r[a][0]);
-      PM_ST4(out + (a * 4 + 1) * plane, f4add(r[a][0], r[a][1]));
-      PM_ST4(out + (a * 4 + 2) * plane, f4sub(r[a][0], r[a][1]));
-      PM_ST4(out + (a * 4 + 3) * plane, f4sub(zero, r[a][1]));
+    for (int a = 0; a < A; ++a) {   // (A dY) At
+      Vec<W> o[A];
+      mat_apply<MT, W_A>(r[a], o);
+#pragma unroll
+      for (int b = 0; b < A; ++b) vstore<W>(out + (a * A + b) * plane, o[b]);
     }
   }
 }
 
-// Weight gradient, step 3: fixed-order sum of the split-K slabs [ks][16][Cout][Kp] and dw = Gt dU G -> KRSC [Cout][3][3][Cin].
+// Weight gradient, step 3: fixed-order sum of the split-K slabs [ks][P][Cout][Kp] and dw = Gt dU G -> KRSC [Cout][3][3][Cin].
+template <int MT>
 __global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ slab, int ks, int Cout, int Cin, int Kp, float* __restrict__ dw) {
+  constexpr int A = MT + 2, P = A * A;
   const long total = (long)Cout * Cin, plane = (long)Cout * Kp;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int co = (int)(i / Cin), ci = (int)(i - (long)co * Cin);
     const float* in = slab + (long)co * Kp + ci;
-    float u[4][4];
+    Vec<1> h[3][A];
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {
-      float acc = 0.f;
-      for (int z = 0; z < ks; ++z) acc += in[((long)z * 16 + p) * plane];
-      u[p >> 2][p & 3] = acc;
-    }
-    float h[3][4];   // Gt dU
+    for (int b = 0; b < A; ++b) {   // Gt dU
+      Vec<1> col[A], o[3];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      h[0][b] = u[0][b] + 0.5f * (u[1][b] + u[2][b]);
-      h[1][b] = 0.5f * (u[1][b] - u[2][b]);
-      h[2][b] = 0.5f * (u[1][b] + u[2][b]) + u[3][b];
+      for (int a = 0; a < A; ++a) {
+        float acc = 0.f;
+        for (int z = 0; z < ks; ++z) acc += in[((long)z * P + a * A + b) * plane];
+        col[a].v[0] = acc;
+      }
+      mat_apply<MT, W_GT>(col, o);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) h[k][b] = o[k];
     }
     float* out = dw + (long)co * 9 * Cin + ci;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {   // (Gt dU) G
-      out[(a * 3 + 0) * (long)Cin] = h[a][0] + 0.5f * (h[a][1] + h[a][2]);
-      out[(a * 3 + 1) * (long)Cin] = 0.5f * (h[a][1] - h[a][2]);
-      out[(a * 3 + 2) * (long)Cin] = 0.5f * (h[a][1] + h[a][2]) + h[a][3];
+    for (int k = 0; k < 3; ++k) {   // (Gt dU) G
+      Vec<1> o[3];
+      mat_apply<MT, W_GT>(h[k], o);
+#pragma unroll
+      for (int l = 0; l < 3; ++l) out[(k * 3 + l) * (long)Cin] = o[l].v[0];
     }
   }
 }
 
+inline unsigned nblocks(long total) { return (unsigned)std::min<long>((total + 255) / 256, 1 << 20); }
+
 }  // namespace
 
-int pm_wino_dy_xf(const float* dy, long pitch, int Cout, const pm_wino_geom& g, float* Z, hipStream_t st) {
-  const long total = g.tiles * (Cout / 4);
-  hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 1 << 20)), dim3(256), 0, st, dy, pitch, Cout, g, Z);
-  return pm_check_launch("wino_dy");
-}
-
-int pm_wino_dw_xf(const float* slab, int ks, int Cout, int Cin, int Kp, float* dw, hipStream_t st) {
-  const long total = (long)Cout * Cin;
-  hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 1 << 16)), dim3(256), 0, st, slab, ks, Cout, Cin, Kp, dw);
-  return pm_check_launch("wino_dw");
-}
-
-pm_wino_geom pm_wino_make_geom(int n, int h, int w, int d) {
+pm_wino_geom pm_wino_make_geom(int n, int h, int w, int d, int m) {
   pm_wino_geom g;
-  g.N = n, g.H = h, g.W = w, g.d = d;
-  g.TY = (pm_cdiv(h, d) + 1) / 2, g.TX = (pm_cdiv(w, d) + 1) / 2;
+  g.N = n, g.H = h, g.W = w, g.d = d, g.m = m;
+  g.TY = (pm_cdiv(h, d) + m - 1) / m, g.TX = (pm_cdiv(w, d) + m - 1) / m;
   g.tiles = (long)n * d * d * g.TY * g.TX;
   return g;
 }
 
 int pm_wino_input_xf(const float* x, long pitch, int C, int Kp, const pm_wino_geom& g, float* V, hipStream_t st) {
-  const long total = g.tiles * (Kp / 4);
-  hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 1 << 20)), dim3(256), 0, st, x, pitch, C, Kp, g, V);
+  if (g.m == 4) hipLaunchKernelGGL((wino_input_kernel<4, 2>), dim3(nblocks(g.tiles * (Kp / 2))), dim3(256), 0, st, x, pitch, C, Kp, g, V);
+  else hipLaunchKernelGGL((wino_input_kernel<2, 4>), dim3(nblocks(g.tiles * (Kp / 4))), dim3(256), 0, st, x, pitch, C, Kp, g, V);
   return pm_check_launch("wino_input");
 }
 
-int pm_wino_filter_xf(const float* w, int Cout, int Cin, int Kp, bool dgrad, float* U, hipStream_t st) {
+int pm_wino_filter_xf(const float* w, int Cout, int Cin, int Kp, bool dgrad, int m, float* U, hipStream_t st) {
   const int R = dgrad ? Cin : Cout;
   dim3 grid(Kp / 32, pm_cdiv(R, 32));
-  if (dgrad) hipLaunchKernelGGL(wino_filter_kernel<true>, grid, dim3(256), 0, st, w, Cout, Cin, Kp, U);
-  else hipLaunchKernelGGL(wino_filter_kernel<false>, grid, dim3(256), 0, st, w, Cout, Cin, Kp, U);
+  if (m == 4) {
+    if (dgrad) hipLaunchKernelGGL((wino_filter_kernel<4, true>), grid, dim3(256), 0, st, w, Cout, Cin, Kp, U);
+    else hipLaunchKernelGGL((wino_filter_kernel<4, false>), grid, dim3(256), 0, st, w, Cout, Cin, Kp, U);
+  } else {
+    if (dgrad) hipLaunchKernelGGL((wino_filter_kernel<2, true>), grid, dim3(256), 0, st, w, Cout, Cin, Kp, U);
+    else hipLaunchKernelGGL((wino_filter_kernel<2, false>), grid, dim3(256), 0, st, w, Cout, Cin, Kp, U);
+  }
   return pm_check_launch("wino_filter");
 }
 
 int pm_wino_output_xf(const float* M, int Cout, const pm_wino_geom& g, float* y, long ypitch, const float* bias, const float* scale, const float* shift,
                       const float* residual, long res_pitch, int relu, hipStream_t st) {
-  const long total = g.tiles * (Cout / 4);
-  hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 1 << 20)), dim3(256), 0, st, M, Cout, g, y, ypitch, bias, scale,
-                     shift, residual, res_pitch, relu);
+  if (g.m == 4)
+    hipLaunchKernelGGL((wino_output_kernel<4, 2>), dim3(nblocks(g.tiles * (Cout / 2))), dim3(256), 0, st, M, Cout, g, y, ypitch, bias, scale, shift, residual,
+                       res_pitch, relu);
+  else
+    hipLaunchKernelGGL((wino_output_kernel<2, 4>), dim3(nblocks(g.tiles * (Cout / 4))), dim3(256), 0, st, M, Cout, g, y, ypitch, bias, scale, shift, residual,
+                       res_pitch, relu);
   return pm_check_launch("wino_output");
+}
+
+int pm_wino_dy_xf(const float* dy, long pitch, int Cout, const pm_wino_geom& g, float* Z, hipStream_t st) {
+  if (g.m == 4) hipLaunchKernelGGL((wino_dy_kernel<4, 2>), dim3(nblocks(g.tiles * (Cout / 2))), dim3(256), 0, st, dy, pitch, Cout, g, Z);
+  else hipLaunchKernelGGL((wino_dy_kernel<2, 4>), dim3(nblocks(g.tiles * (Cout / 4))), dim3(256), 0, st, dy, pitch, Cout, g, Z);
+  return pm_check_launch("wino_dy");
+}
+
+int pm_wino_dw_xf(const float* slab, int ks, int Cout, int Cin, int Kp, int m, float* dw, hipStream_t st) {
+  const unsigned nb = (unsigned)std::min<long>(((long)Cout * Cin + 255) / 256, 1 << 16);
+  if (m == 4) hipLaunchKernelGGL(wino_dw_kernel<4>, dim3(nb), dim3(256), 0, st, slab, ks, Cout, Cin, Kp, dw);
+  else hipLaunchKernelGGL(wino_dw_kernel<2>, dim3(nb), dim3(256), 0, st, slab, ks, Cout, Cin, Kp, dw);
+  return pm_check_launch("wino_dw");
 }

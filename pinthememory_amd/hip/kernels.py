@@ -364,9 +364,10 @@ def sgd_momentum(param, grad, buf, lr, momentum, wd, first):
     check(_lib().pm_sgd_momentum(param.data_ptr(), grad.data_ptr(), buf.data_ptr(), param.numel(), lr, momentum, wd, 1 if first else 0, stream()), 'pm_sgd_momentum')
 
 
-def set_winograd(on):
-    """Winograd F(2x2,3x3) for the wide stride-1 3x3 convs (default on); off = direct implicit GEMM everywhere."""
-    check(_lib().pm_set_winograd(1 if on else 0), 'pm_set_winograd')
+def set_winograd(mode):
+    """Winograd route of the wide stride-1 3x3 convs: 4 / True = prefer F(4x4,3x3) (default), 2 = F(2x2,3x3) only, 0 / False = direct."""
+    mode = 4 if mode is True else (0 if mode is False else int(mode))
+    check(_lib().pm_set_winograd(mode), 'pm_set_winograd')
 
 
 def profile_enable(on):

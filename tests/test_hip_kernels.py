@@ -84,13 +84,16 @@ WINO_CASES = [
     (1, 128, 36, 36, 160, 6),
     (1, 2048, 24, 24, 256, 12),
     (2, 132, 8, 8, 140, 1),        # channel counts that are not multiples of 32 / 128
+    (1, 128, 48, 48, 128, 6),      # F(4x4) on the dilation sub-lattices (8x8 each)
+    (1, 256, 48, 44, 128, 12),     # 4x4 / 4x3.67 sub-lattices: one F(4x4) tile each
 ]
 
 
 @pytest.mark.parametrize('case', WINO_CASES)
 def test_conv_winograd(K, case):
-    """Winograd route vs an fp64 convolution, next to the direct implicit GEMM on the same inputs: both within fp32 rounding of
-    the truth, and the route is really taken (the results differ from the direct ones in the last bits)."""
+    """Winograd routes (4 = prefer F(4x4,3x3), 2 = F(2x2,3x3)) vs an fp64 convolution, next to the direct implicit GEMM (0) on the
+    same inputs: all within fp32 rounding of the truth, and the route is really taken (results differ from the direct ones in the
+    last bits)."""
     n, cin, h, w, cout, d = case
     x = rnd(n, cin, h, w, seed=1)
     wt = rnd(cout, cin, 3, 3, seed=2, scale=(2.0 / (cin * 9)) ** 0.5)
@@ -103,7 +106,7 @@ def test_conv_winograd(K, case):
     xg, wg, dyg, addg = nhwc(x), wt.permute(0, 2, 3, 1).contiguous().cuda(), nhwc(dy), nhwc(add)
     buf = torch.zeros(n, h, w, cout + 64, device='cuda')
     res = {}
-    for wino in (True, False):
+    for wino in (4, 2, 0):
         K.set_winograd(wino)
         try:
             y = K.conv_fwd(xg, wg, 1, d, d, bias=b.cuda(), out=buf[..., 32:32 + cout])
@@ -112,12 +115,12 @@ def test_conv_winograd(K, case):
         finally:
             K.set_winograd(True)
         assert buf[..., :32].abs().max().item() == 0 and buf[..., 32 + cout:].abs().max().item() == 0
-    for wino in (True, False):
+    for wino in (4, 2, 0):
         assert rel(res[wino][0], y_ref.detach()) < 2e-5, wino
         assert rel(res[wino][1], xr.grad + add.double()) < 2e-5, wino
         assert rel(res[wino][2], wr.grad) < 5e-5, wino
         assert rel(res[wino][3], br.grad) < 2e-5, wino
-    assert not torch.equal(res[True][0], res[False][0])
+    assert not torch.equal(res[4][0], res[0][0]) and not torch.equal(res[2][0], res[0][0])
 
 
 def test_conv_epilogue_and_slices(K):

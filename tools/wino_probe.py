@@ -30,15 +30,15 @@ for name, n, cin, h, w, cout, d in SHAPES:
     dy = torch.randn(n, h, w, cout, device='cuda')
     fl = 2.0 * n * h * w * cout * cin * 9
     r = dict(name=name, gflop=fl / 1e9)
-    for wino in (False, True):
+    for wino in (0, 2, 4):
         K.set_winograd(wino)
         r['fwd_ms_%d' % wino] = bench(lambda: K.conv_fwd(x, wt, 1, d, d))
         r['dgrad_ms_%d' % wino] = bench(lambda: K.conv_bwd_data(dy, wt, tuple(x.shape), 1, d, d))
         r['wgrad_ms_%d' % wino] = bench(lambda: K.conv_bwd_weight(x, dy, tuple(wt.shape), 1, d, d))
-    K.set_winograd(True)
+    K.set_winograd(4)
     rows.append(r)
-    print('%-30s %6.1f GF fwd %6.3f -> %6.3f ms (x%.2f) | dgrad %6.3f -> %6.3f (x%.2f) | wgrad %6.3f -> %6.3f (x%.2f)' % (
-        name, fl / 1e9, r['fwd_ms_0'], r['fwd_ms_1'], r['fwd_ms_0'] / r['fwd_ms_1'], r['dgrad_ms_0'], r['dgrad_ms_1'], r['dgrad_ms_0'] / r['dgrad_ms_1'],
-        r['wgrad_ms_0'], r['wgrad_ms_1'], r['wgrad_ms_0'] / r['wgrad_ms_1']), flush=True)
+    print('%-30s %6.1f GF direct/F2/F4 ms: fwd %6.3f %6.3f %6.3f | dgrad %6.3f %6.3f %6.3f | wgrad %6.3f %6.3f %6.3f' % (
+        name, fl / 1e9, r['fwd_ms_0'], r['fwd_ms_2'], r['fwd_ms_4'], r['dgrad_ms_0'], r['dgrad_ms_2'], r['dgrad_ms_4'],
+        r['wgrad_ms_0'], r['wgrad_ms_2'], r['wgrad_ms_4']), flush=True)
 os.makedirs('gpurun_out', exist_ok=True)
 json.dump(rows, open('gpurun_out/wino_probe.json', 'w'), indent=1)
