@@ -88,12 +88,16 @@ int pm_bn_finalize(const float* moments, int c, float eps, float* mean, float* i
 /* y = relu?( (x-mean)*invstd*gamma + beta + residual? ) */
 int pm_bn_apply(const pm_tensor* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                 const pm_tensor* residual /*nullable*/, int relu, const pm_tensor* y, void* stream);
-/* backward: dyz = dy * (relu ? y>0 : 1). sums[2*C] = sum(dyz) | sum(dyz * xhat). */
-int pm_bn_bwd_reduce(const pm_tensor* dy, const pm_tensor* y /*nullable if !relu*/, const pm_tensor* x, const float* mean,
-                     const float* invstd, int relu, float* sums, void* ws, size_t ws_bytes, void* stream);
+/* backward: dyz = dy * mask, sums[2*C] = sum(dyz) | sum(dyz * xhat).  relu: 0 no activation (mask = 1); 1 mask = y > 0 read from the
+ * forward output (BN + residual + ReLU, Resnet.py:207-216); 2 mask rebuilt from x with gamma / beta (BN + ReLU without a residual:
+ * one tensor less to read).  gmask (nullable, relu != 0): dyz is also stored there -- it is the gradient of the residual branch, and
+ * pm_bn_bwd_apply can then take it as `dy` with relu = 0 instead of re-reading dy and y. */
+int pm_bn_bwd_reduce(const pm_tensor* dy, const pm_tensor* y /*relu == 1 only*/, const pm_tensor* x, const float* mean, const float* invstd,
+                     const float* gamma /*relu == 2 only*/, const float* beta /*relu == 2 only*/, int relu, const pm_tensor* gmask /*nullable*/,
+                     float* sums, void* ws, size_t ws_bytes, void* stream);
 /* dx = gamma*invstd*(dyz - sum_dy/count - xhat*sum_dy_xhat/count); dres = dyz (nullable); count = global element count */
-int pm_bn_bwd_apply(const pm_tensor* dy, const pm_tensor* y, const pm_tensor* x, const float* mean, const float* invstd,
-                    const float* gamma, const float* sums, float count, int relu, const pm_tensor* dx,
+int pm_bn_bwd_apply(const pm_tensor* dy, const pm_tensor* y /*relu == 1 only*/, const pm_tensor* x, const float* mean, const float* invstd,
+                    const float* gamma, const float* beta /*relu == 2 only*/, const float* sums, float count, int relu, const pm_tensor* dx,
                     const pm_tensor* dres /*nullable*/, void* stream);
 /* eval-mode fold: scale = gamma/sqrt(running_var+eps); shift = beta - running_mean*scale + (conv_bias ? conv_bias*scale : 0) */
 int pm_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var, const float* conv_bias,

@@ -10,6 +10,13 @@ namespace {
 constexpr int CB = 64;    // channels per block
 constexpr int RL = 16;    // row lanes per block (256 threads = 16 float4 groups x 16 rows)
 
+// y = (x - mean) * invstd * gamma + beta, evaluated the same way in the forward pass and wherever the backward pass rebuilds the
+// ReLU mask from x (two explicit FMAs: bit-identical in both places whatever the compiler would contract).
+__device__ __forceinline__ float bn_affine(float v, float mu, float is, float ga, float be) {
+  const float s = is * ga;
+  return fmaf(v, s, fmaf(-mu, s, be));
+}
+
 inline int chunk_rows(long P) {  // pixels per block: aim for ~2048 blocks total, >= 64 rows each
   long r = (P + 511) / 512;
   r = std::max<long>(r, 64);
@@ -88,11 +95,15 @@ __global__ void bn_finalize_kernel(const float* __restrict__ moments, int C, flo
   if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (m2 / (n - 1.f));
 }
 
-// backward reductions: partial[blk][c][2] = sum(dyz), sum(dyz * xhat)
-template <bool RELU>
+// backward reductions: partial[blk][c][2] = sum(dyz), sum(dyz * xhat), dyz = dy masked by the ReLU of the forward pass.
+// RELU 0: no activation. 1: mask = y > 0 read from the forward output (needed when a residual was added before the ReLU).
+// 2: mask rebuilt from x (y = relu(bn(x)), no residual) -- one tensor less to read. GOUT: also store dyz (the gradient of the
+// residual branch), so that the apply pass reads one tensor (dyz) instead of two (dy, y).
+template <int RELU, bool GOUT>
 __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ dy, long dpitch, const float* __restrict__ y, long ypitch,
                                                       const float* __restrict__ x, long xpitch, const float* __restrict__ mean,
-                                                      const float* __restrict__ invstd, long P, int C, int rows, float* __restrict__ part) {
+                                                      const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float* __restrict__ gout, long gpitch, long P, int C, int rows, float* __restrict__ part) {
   __shared__ float sm[RL][CB][2];
   const int g = threadIdx.x & 15, r = threadIdx.x >> 4;
   const int c = blockIdx.y * CB + g * 4;
@@ -100,13 +111,19 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
   float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
   if (c < C) {
     const float4 mu = PM_LD4(mean + c), is = PM_LD4(invstd + c);
+    float4 ga = make_float4(0.f, 0.f, 0.f, 0.f), be = ga;
+    if (RELU == 2) ga = PM_LD4(gamma + c), be = PM_LD4(beta + c);
     for (long p = p0 + r; p < p1; p += RL) {
       float4 d = PM_LD4(dy + p * dpitch + c);
       const float4 v = PM_LD4(x + p * xpitch + c);
-      if (RELU) {
+      if (RELU == 1) {
         const float4 o = PM_LD4(y + p * ypitch + c);
         d.x = o.x > 0.f ? d.x : 0.f, d.y = o.y > 0.f ? d.y : 0.f, d.z = o.z > 0.f ? d.z : 0.f, d.w = o.w > 0.f ? d.w : 0.f;
+      } else if (RELU == 2) {
+        d.x = bn_affine(v.x, mu.x, is.x, ga.x, be.x) > 0.f ? d.x : 0.f, d.y = bn_affine(v.y, mu.y, is.y, ga.y, be.y) > 0.f ? d.y : 0.f;
+        d.z = bn_affine(v.z, mu.z, is.z, ga.z, be.z) > 0.f ? d.z : 0.f, d.w = bn_affine(v.w, mu.w, is.w, ga.w, be.w) > 0.f ? d.w : 0.f;
       }
+      if (GOUT) PM_ST4(gout + p * gpitch + c, d);
       s1[0] += d.x, s1[1] += d.y, s1[2] += d.z, s1[3] += d.w;
       s2[0] += d.x * ((v.x - mu.x) * is.x), s2[1] += d.y * ((v.y - mu.y) * is.y);
       s2[2] += d.z * ((v.z - mu.z) * is.z), s2[3] += d.w * ((v.w - mu.w) * is.w);
@@ -220,8 +237,8 @@ extern "C" int pm_bn_apply(const pm_tensor* x, const float* mean, const float* i
   const long a = x->pitch, b = res ? res->pitch : 0, c = y->pitch;
   return pm_ew_launch(true, pm_pixels(x), x->c, (hipStream_t)stream, "bn_apply", [=] __device__(long p, int ch) {
     const float4 v = PM_LD4(px + p * a + ch), mu = PM_LD4(mean + ch), is = PM_LD4(invstd + ch), ga = PM_LD4(gamma + ch), be = PM_LD4(beta + ch);
-    const float s0 = is.x * ga.x, s1 = is.y * ga.y, s2 = is.z * ga.z, s3 = is.w * ga.w;
-    float4 o = make_float4(v.x * s0 + (be.x - mu.x * s0), v.y * s1 + (be.y - mu.y * s1), v.z * s2 + (be.z - mu.z * s2), v.w * s3 + (be.w - mu.w * s3));
+    float4 o = make_float4(bn_affine(v.x, mu.x, is.x, ga.x, be.x), bn_affine(v.y, mu.y, is.y, ga.y, be.y), bn_affine(v.z, mu.z, is.z, ga.z, be.z),
+                           bn_affine(v.w, mu.w, is.w, ga.w, be.w));
     if (pr) {
       const float4 q = PM_LD4(pr + p * b + ch);
       o.x += q.x, o.y += q.y, o.z += q.z, o.w += q.w;
@@ -231,38 +248,51 @@ extern "C" int pm_bn_apply(const pm_tensor* x, const float* mean, const float* i
   });
 }
 
-extern "C" int pm_bn_bwd_reduce(const pm_tensor* dy, const pm_tensor* y, const pm_tensor* x, const float* mean, const float* invstd, int relu,
-                                float* sums, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int pm_bn_bwd_reduce(const pm_tensor* dy, const pm_tensor* y, const pm_tensor* x, const float* mean, const float* invstd, const float* gamma,
+                                const float* beta, int relu, const pm_tensor* gmask, float* sums, void* ws, size_t ws_bytes, void* stream) {
   if (int e = check_bn(dy, "bn_bwd_reduce")) return e;
   if (int e = check_bn(x, "bn_bwd_reduce")) return e;
   PM_REQUIRE(pm_same_shape(dy, x) && mean && invstd && sums, PM_EINVAL, "bn_bwd_reduce: bad args");
-  PM_REQUIRE(!relu || (y && pm_vec4(y) && pm_same_shape(y, x)), PM_EINVAL, "bn_bwd_reduce: relu needs the forward output");
+  PM_REQUIRE(relu >= 0 && relu <= 2, PM_EINVAL, "bn_bwd_reduce: relu mode %d (0 none, 1 mask from y, 2 mask rebuilt from x)", relu);
+  PM_REQUIRE(relu != 1 || (y && pm_vec4(y) && pm_same_shape(y, x)), PM_EINVAL, "bn_bwd_reduce: relu mode 1 needs the forward output");
+  PM_REQUIRE(relu != 2 || (gamma && beta), PM_EINVAL, "bn_bwd_reduce: relu mode 2 needs gamma and beta");
+  PM_REQUIRE(!gmask || (relu != 0 && pm_vec4(gmask) && pm_same_shape(gmask, x)), PM_EINVAL, "bn_bwd_reduce: gmask needs a ReLU mode and the shape of x");
   PM_REQUIRE(ws && ws_bytes >= pm_bn_workspace(x), PM_EWORKSPACE, "bn_bwd_reduce: workspace too small");
   const long P = pm_pixels(x);
   const int rows = chunk_rows(P), nb = pm_cdiv(P, rows);
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(nb, pm_cdiv(x->c, CB));
-  if (relu)
-    hipLaunchKernelGGL(bn_bwd_partial<true>, grid, dim3(256), 0, st, (const float*)dy->ptr, (long)dy->pitch, (const float*)y->ptr, (long)y->pitch,
-                       (const float*)x->ptr, (long)x->pitch, mean, invstd, P, x->c, rows, (float*)ws);
-  else
-    hipLaunchKernelGGL(bn_bwd_partial<false>, grid, dim3(256), 0, st, (const float*)dy->ptr, (long)dy->pitch, (const float*)nullptr, 0l,
-                       (const float*)x->ptr, (long)x->pitch, mean, invstd, P, x->c, rows, (float*)ws);
+  const float *pdy = (const float*)dy->ptr, *py = relu == 1 ? (const float*)y->ptr : nullptr, *px = (const float*)x->ptr;
+  const long yp = relu == 1 ? y->pitch : 0;
+  float* pg = gmask ? (float*)gmask->ptr : nullptr;
+  const long gp = gmask ? gmask->pitch : 0;
+#define PM_BN_BWD_PARTIAL(R, G)                                                                                                                         \
+  hipLaunchKernelGGL((bn_bwd_partial<R, G>), grid, dim3(256), 0, st, pdy, (long)dy->pitch, py, yp, px, (long)x->pitch, mean, invstd, gamma, beta, pg, gp, P, \
+                     x->c, rows, (float*)ws)
+  if (relu == 0) PM_BN_BWD_PARTIAL(0, false);
+  else if (relu == 1 && gmask) PM_BN_BWD_PARTIAL(1, true);
+  else if (relu == 1) PM_BN_BWD_PARTIAL(1, false);
+  else if (gmask) PM_BN_BWD_PARTIAL(2, true);
+  else PM_BN_BWD_PARTIAL(2, false);
+#undef PM_BN_BWD_PARTIAL
   hipLaunchKernelGGL(bn_bwd_final, dim3(pm_cdiv(x->c, FC)), dim3(256), 0, st, (const float*)ws, nb, x->c, sums);
   return pm_check_launch("bn_bwd_reduce");
 }
 
 extern "C" int pm_bn_bwd_apply(const pm_tensor* dy, const pm_tensor* y, const pm_tensor* x, const float* mean, const float* invstd, const float* gamma,
-                               const float* sums, float count, int relu, const pm_tensor* dx, const pm_tensor* dres, void* stream) {
+                               const float* beta, const float* sums, float count, int relu, const pm_tensor* dx, const pm_tensor* dres, void* stream) {
   if (int e = check_bn(dy, "bn_bwd_apply")) return e;
   if (int e = check_bn(x, "bn_bwd_apply")) return e;
   if (int e = check_bn(dx, "bn_bwd_apply")) return e;
   PM_REQUIRE(pm_same_shape(dy, x) && pm_same_shape(dx, x) && mean && invstd && gamma && sums && count > 0.f, PM_EINVAL, "bn_bwd_apply: bad args");
-  PM_REQUIRE(!relu || (y && pm_vec4(y) && pm_same_shape(y, x)), PM_EINVAL, "bn_bwd_apply: relu needs the forward output");
+  PM_REQUIRE(relu >= 0 && relu <= 2, PM_EINVAL, "bn_bwd_apply: relu mode %d (0 none, 1 mask from y, 2 mask rebuilt from x)", relu);
+  PM_REQUIRE(relu != 1 || (y && pm_vec4(y) && pm_same_shape(y, x)), PM_EINVAL, "bn_bwd_apply: relu mode 1 needs the forward output");
+  PM_REQUIRE(relu != 2 || beta, PM_EINVAL, "bn_bwd_apply: relu mode 2 needs beta");
   PM_REQUIRE(!dres || (pm_vec4(dres) && pm_same_shape(dres, x)), PM_EINVAL, "bn_bwd_apply: dres shape mismatch");
-  const float *pd = (const float*)dy->ptr, *po = relu ? (const float*)y->ptr : nullptr, *px = (const float*)x->ptr;
+  const float *pd = (const float*)dy->ptr, *po = relu == 1 ? (const float*)y->ptr : nullptr, *px = (const float*)x->ptr;
   float *pdx = (float*)dx->ptr, *pdr = dres ? (float*)dres->ptr : nullptr;
-  const long a = dy->pitch, b = relu ? y->pitch : 0, c = x->pitch, d = dx->pitch, e2 = dres ? dres->pitch : 0;
+  const long a = dy->pitch, b = relu == 1 ? y->pitch : 0, c = x->pitch, d = dx->pitch, e2 = dres ? dres->pitch : 0;
+  const bool from_x = relu == 2;
   const int C = x->c;
   const float inv_n = 1.f / count;
   return pm_ew_launch(true, pm_pixels(x), C, (hipStream_t)stream, "bn_bwd_apply", [=] __device__(long p, int ch) {
@@ -271,8 +301,13 @@ extern "C" int pm_bn_bwd_apply(const pm_tensor* dy, const pm_tensor* y, const pm
       const float4 o = PM_LD4(po + p * b + ch);
       g.x = o.x > 0.f ? g.x : 0.f, g.y = o.y > 0.f ? g.y : 0.f, g.z = o.z > 0.f ? g.z : 0.f, g.w = o.w > 0.f ? g.w : 0.f;
     }
-    if (pdr) PM_ST4(pdr + p * e2 + ch, g);
     const float4 v = PM_LD4(px + p * c + ch), mu = PM_LD4(mean + ch), is = PM_LD4(invstd + ch), ga = PM_LD4(gamma + ch);
+    if (from_x) {
+      const float4 be = PM_LD4(beta + ch);
+      g.x = bn_affine(v.x, mu.x, is.x, ga.x, be.x) > 0.f ? g.x : 0.f, g.y = bn_affine(v.y, mu.y, is.y, ga.y, be.y) > 0.f ? g.y : 0.f;
+      g.z = bn_affine(v.z, mu.z, is.z, ga.z, be.z) > 0.f ? g.z : 0.f, g.w = bn_affine(v.w, mu.w, is.w, ga.w, be.w) > 0.f ? g.w : 0.f;
+    }
+    if (pdr) PM_ST4(pdr + p * e2 + ch, g);
     const float4 s1 = PM_LD4(sums + ch), s2 = PM_LD4(sums + C + ch);
     float4 r;
     r.x = (g.x - s1.x * inv_n - (v.x - mu.x) * is.x * (s2.x * inv_n)) * (is.x * ga.x);

@@ -563,6 +563,59 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
 }
 
 // split-K combine: C[row][col] = epilogue( sum_z ws[z][row][col] ), fixed z order (deterministic).
+// Vectorised split-K reduce: thread -> 4 consecutive outputs, ZL lanes share the slabs of one output group (lane l sums
+// z = l, l + ZL, ...; the ZL partial sums are combined in lane order through LDS), so that a 256-way split over a small dw is not
+// a 256-long serial chain of dependent loads. Fixed association order -> deterministic.
+template <int ZL>
+__global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const float* __restrict__ ws, int ksplit, long slab, int M, int Nn,
+                                                                float* __restrict__ C, long c_pitch, const float* bias,
+                                                                const float* scale, const float* shift, const float* residual,
+                                                                long res_pitch, int relu) {
+  constexpr int GP = 256 / ZL;   // output groups per block
+  __shared__ float4 red[ZL > 1 ? ZL : 1][GP];
+  const int gl = threadIdx.x % GP, zl = threadIdx.x / GP;
+  const long groups = (long)M * Nn / 4;
+  for (long g0 = (long)blockIdx.x * GP; g0 < groups; g0 += (long)gridDim.x * GP) {
+    const long grp = g0 + gl;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (grp < groups)
+      for (int z = zl; z < ksplit; z += ZL) {
+        const float4 q = PM_LD4(ws + (long)z * slab + grp * 4);
+        v.x += q.x, v.y += q.y, v.z += q.z, v.w += q.w;
+      }
+    if constexpr (ZL > 1) {
+      red[zl][gl] = v;
+      __syncthreads();
+      if (zl == 0) {
+#pragma unroll
+        for (int l = 1; l < ZL; ++l) {
+          const float4 q = red[l][gl];
+          v.x += q.x, v.y += q.y, v.z += q.z, v.w += q.w;
+        }
+      }
+    }
+    if (zl == 0 && grp < groups) {
+      const long i = grp * 4;
+      const int row = (int)(i / Nn), col = (int)(i - (long)row * Nn);
+      if (bias) {
+        const float4 b = PM_LD4(bias + col);
+        v.x += b.x, v.y += b.y, v.z += b.z, v.w += b.w;
+      }
+      if (scale) {
+        const float4 sc = PM_LD4(scale + col), sh = PM_LD4(shift + col);
+        v.x = v.x * sc.x + sh.x, v.y = v.y * sc.y + sh.y, v.z = v.z * sc.z + sh.z, v.w = v.w * sc.w + sh.w;
+      }
+      if (residual) {
+        const float4 r = PM_LD4(residual + (long)row * res_pitch + col);
+        v.x += r.x, v.y += r.y, v.z += r.z, v.w += r.w;
+      }
+      if (relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+      PM_ST4(C + (long)row * c_pitch + col, v);
+    }
+    if constexpr (ZL > 1) __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, long slab, int M, int Nn,
                                                             float* __restrict__ C, long c_pitch, const float* bias,
                                                             const float* scale, const float* shift, const float* residual,
@@ -578,6 +631,31 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     if (relu) v = fmaxf(v, 0.f);
     C[(long)row * c_pitch + col] = v;
   }
+}
+
+int splitk_reduce(const float* ws, int ksplit, long M, long Nn, float* C, long c_pitch, const float* bias, const float* scale, const float* shift,
+                  const float* residual, long res_pitch, int relu, hipStream_t st) {
+  const long total = M * Nn;
+  const bool vec = (Nn % 4 == 0) && (c_pitch % 4 == 0) && (res_pitch % 4 == 0) && pm_aligned16(ws) && pm_aligned16(C) &&
+                   (!bias || pm_aligned16(bias)) && (!scale || (pm_aligned16(scale) && pm_aligned16(shift))) && (!residual || pm_aligned16(residual));
+  if (!vec) {
+    const int nb = (int)std::min<long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, ws, ksplit, total, (int)M, (int)Nn, C, c_pitch, bias, scale, shift, residual,
+                       res_pitch, relu);
+  } else {
+    const long groups = total / 4;
+    // enough lanes per output group that the whole GPU has work: small outputs with many slabs take 16 lanes
+    const int zl = (ksplit >= 32 && groups < (1 << 18)) ? 16 : (ksplit >= 8 && groups < (1 << 20) ? 4 : 1);
+    const int gp = 256 / zl;
+    const int nb = (int)std::min<long>((groups + gp - 1) / gp, 8192);
+    if (zl == 16)
+      hipLaunchKernelGGL(splitk_reduce_vec_kernel<16>, dim3(nb), dim3(256), 0, st, ws, ksplit, total, (int)M, (int)Nn, C, c_pitch, bias, scale, shift, residual, res_pitch, relu);
+    else if (zl == 4)
+      hipLaunchKernelGGL(splitk_reduce_vec_kernel<4>, dim3(nb), dim3(256), 0, st, ws, ksplit, total, (int)M, (int)Nn, C, c_pitch, bias, scale, shift, residual, res_pitch, relu);
+    else
+      hipLaunchKernelGGL(splitk_reduce_vec_kernel<1>, dim3(nb), dim3(256), 0, st, ws, ksplit, total, (int)M, (int)Nn, C, c_pitch, bias, scale, shift, residual, res_pitch, relu);
+  }
+  return pm_check_launch("splitk_reduce");
 }
 
 // column sum of dy for the conv bias gradient: one block per 64 channels x pixel chunk, fixed-order second stage.
@@ -997,10 +1075,8 @@ extern "C" int pm_conv_fwd(const pm_tensor* x, const float* w, const pm_tensor* 
   if (pl.ksplit > 1) {
     k.C = (float*)ws, k.c_pitch = Nn, k.c_split = M * Nn;
     if (int e = launch<MODE_FWD>(k, pl, st)) return e;
-    const int nb = (int)std::min<long>((M * Nn + 255) / 256, 4096);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, (const float*)ws, pl.ksplit, M * Nn, (int)M, (int)Nn, (float*)y->ptr,
-                       (long)y->pitch, e0.bias, e0.scale, e0.shift, e0.residual, (long)e0.residual_pitch, e0.relu);
-    return pm_check_launch("splitk_reduce");
+    return splitk_reduce((const float*)ws, pl.ksplit, M, Nn, (float*)y->ptr, (long)y->pitch, e0.bias, e0.scale, e0.shift, e0.residual,
+                         (long)e0.residual_pitch, e0.relu, st);
   }
   k.C = (float*)y->ptr, k.c_pitch = y->pitch, k.c_split = 0;
   k.bias = e0.bias, k.scale = e0.scale, k.shift = e0.shift, k.residual = e0.residual, k.res_pitch = e0.residual_pitch, k.relu = e0.relu;
@@ -1046,9 +1122,7 @@ extern "C" int pm_conv_bwd_data(const pm_tensor* dy, const float* w, const pm_te
       if (pl.ksplit > 1) {
         k.C = slab, k.c_pitch = dx->c, k.c_split = c.M * dx->c;
         if (int e = launch<MODE_DGRAD>(k, pl, st0)) return e;
-        const int nb = (int)std::min<long>((c.M * dx->c + 255) / 256, 4096);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st0, (const float*)slab, pl.ksplit, c.M * dx->c, (int)c.M, dx->c, out, (long)dx->c,
-                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0l, 0);
+        if (int e = splitk_reduce(slab, pl.ksplit, c.M, dx->c, out, (long)dx->c, nullptr, nullptr, nullptr, nullptr, 0l, 0, st0)) return e;
       } else {
         k.C = out, k.c_pitch = dx->c, k.c_split = 0;
         if (int e = launch<MODE_DGRAD>(k, pl, st0)) return e;
@@ -1082,10 +1156,7 @@ extern "C" int pm_conv_bwd_data(const pm_tensor* dy, const float* w, const pm_te
   if (pl.ksplit > 1) {
     k.C = (float*)ws, k.c_pitch = Nn, k.c_split = M * Nn;
     if (int e = launch<MODE_DGRAD>(k, pl, st)) return e;
-    const int nb = (int)std::min<long>((M * Nn + 255) / 256, 4096);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, (const float*)ws, pl.ksplit, M * Nn, (int)M, (int)Nn, (float*)dx->ptr,
-                       (long)dx->pitch, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, addp, add_pitch, 0);
-    return pm_check_launch("splitk_reduce");
+    return splitk_reduce((const float*)ws, pl.ksplit, M, Nn, (float*)dx->ptr, (long)dx->pitch, nullptr, nullptr, nullptr, addp, add_pitch, 0, st);
   }
   k.C = (float*)dx->ptr, k.c_pitch = dx->pitch, k.c_split = 0;
   k.residual = addp, k.res_pitch = add_pitch;
@@ -1117,10 +1188,7 @@ extern "C" int pm_conv_bwd_weight(const pm_tensor* x, const pm_tensor* dy, float
   } else if (pl.ksplit > 1) {
     k.C = (float*)ws, k.c_pitch = Nn, k.c_split = M * Nn;
     if (int e = launch<MODE_WGRAD>(k, pl, st)) return e;
-    const int nb = (int)std::min<long>((M * Nn + 255) / 256, 4096);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, st, (const float*)ws, pl.ksplit, M * Nn, (int)M, (int)Nn, dw, (long)Nn,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0l, 0);
-    if (int e = pm_check_launch("splitk_reduce")) return e;
+    if (int e = splitk_reduce((const float*)ws, pl.ksplit, M, Nn, dw, (long)Nn, nullptr, nullptr, nullptr, nullptr, 0l, 0, st)) return e;
   } else {
     k.C = dw, k.c_pitch = Nn, k.c_split = 0;
     if (int e = launch<MODE_WGRAD>(k, pl, st)) return e;

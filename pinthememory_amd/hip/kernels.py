@@ -129,26 +129,31 @@ def bn_apply(x, mean, invstd, gamma, beta, residual=None, relu=False, out=None):
     return y
 
 
-def bn_bwd_reduce(dy, y, x, mean, invstd, relu):
+def bn_bwd_reduce(dy, y, x, mean, invstd, relu, gamma=None, beta=None, want_gmask=False):
+    """relu: 0 / False none, 1 / True mask from the forward output y, 2 mask rebuilt from x (needs gamma, beta). -> (sums, dy * mask or None)"""
+    relu = int(relu)
     c = x.shape[3]
     sums = torch.empty(2 * c, dtype=torch.float32, device=x.device)
     xd = tdesc(x)
     lib = _lib()
     nb = lib.pm_bn_workspace(byref(xd))
     ws = workspace(nb, x.device)
-    yd = tdesc(y) if relu else None
-    check(lib.pm_bn_bwd_reduce(byref(tdesc(dy)), byref(yd) if yd else None, byref(xd), mean.data_ptr(), invstd.data_ptr(), 1 if relu else 0,
-                               sums.data_ptr(), ptr(ws), nb, stream()), 'pm_bn_bwd_reduce')
-    return sums
+    yd = tdesc(y) if relu == 1 else None
+    gm = torch.empty(x.shape, dtype=torch.float32, device=x.device) if want_gmask else None
+    gd = tdesc(gm) if want_gmask else None
+    check(lib.pm_bn_bwd_reduce(byref(tdesc(dy)), byref(yd) if yd else None, byref(xd), mean.data_ptr(), invstd.data_ptr(), ptr(gamma), ptr(beta), relu,
+                               byref(gd) if gd else None, sums.data_ptr(), ptr(ws), nb, stream()), 'pm_bn_bwd_reduce')
+    return sums, gm
 
 
-def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, count, relu, want_dres):
+def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, count, relu, want_dres, beta=None):
+    relu = int(relu)
     dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     dres = torch.empty(x.shape, dtype=torch.float32, device=x.device) if want_dres else None
-    yd = tdesc(y) if relu else None
+    yd = tdesc(y) if relu == 1 else None
     dr = tdesc(dres) if want_dres else None
     check(_lib().pm_bn_bwd_apply(byref(tdesc(dy)), byref(yd) if yd else None, byref(tdesc(x)), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
-                                 sums.data_ptr(), float(count), 1 if relu else 0, byref(tdesc(dx)), byref(dr) if dr else None, stream()), 'pm_bn_bwd_apply')
+                                 ptr(beta), sums.data_ptr(), float(count), relu, byref(tdesc(dx)), byref(dr) if dr else None, stream()), 'pm_bn_bwd_apply')
     return dx, dres
 
 

@@ -127,14 +127,22 @@ def _bn_train_fwd(y, gamma, beta, bn, residual, relu, out=None):
     return K.bn_apply(y, mean, invstd, gamma, beta, residual=residual, relu=relu, out=out), mean, invstd
 
 
-def _bn_train_bwd(dv, o, y, mean, invstd, gamma, relu, group, want_dres):
-    """-> (dy, dres, dgamma, dbeta): gradient of the conv output, of the residual input, and of the affine parameters."""
+def _bn_train_bwd(dv, o, y, mean, invstd, gamma, beta, relu, group, want_dres, has_res):
+    """-> (dy, dres, dgamma, dbeta): gradient of the conv output, of the residual input, and of the affine parameters.
+    ReLU mask: rebuilt from the conv output when no residual entered the activation (the forward output is not read at all);
+    otherwise taken from the forward output once, in the reduce pass, which then hands the masked gradient (= dres) to the apply pass."""
     c = y.shape[3]
-    sums = K.bn_bwd_reduce(dv, o, y, mean, invstd, relu)
+    mode = 0 if not relu else (1 if has_res else 2)
+    hand_over = mode == 1 and want_dres
+    sums, gm = K.bn_bwd_reduce(dv, o, y, mean, invstd, mode, gamma, beta, want_gmask=hand_over)
     if group is not None:
         sums = D.all_reduce_sum(sums, group)
     count = float(y.shape[0] * y.shape[1] * y.shape[2]) * (D.group_size(group) if group is not None else 1)
-    dy, dres = K.bn_bwd_apply(dv, o, y, mean, invstd, gamma, sums, count, relu, want_dres)
+    if hand_over:
+        dy, _ = K.bn_bwd_apply(gm, None, y, mean, invstd, gamma, sums, count, 0, False)
+        dres = gm
+    else:
+        dy, dres = K.bn_bwd_apply(dv, o, y, mean, invstd, gamma, sums, count, mode, want_dres, beta)
     return dy, dres, sums[c:], sums[:c]
 
 
@@ -161,26 +169,26 @@ class _Bottleneck(torch.autograd.Function):
             res = xv
         out, m3, i3 = _bn_train_fwd(y3, g3, b3, bns[2], res, True)
         ctx.geoms, ctx.groups, ctx.has_ds, ctx.deferred = geoms, [b.group for b in bns], wd is not None, deferred
-        ctx.save_for_backward(xv, k1, k2, k3, kd, y1, o1, y2, o2, y3, yd, out, m1, i1, m2, i2, m3, i3, md, idd, g1, g2, g3, gd)
+        ctx.save_for_backward(xv, k1, k2, k3, kd, y1, o1, y2, o2, y3, yd, out, m1, i1, m2, i2, m3, i3, md, idd, g1, g2, g3, gd, b1, b2, b3)
         return nchw(out)
 
     @staticmethod
     def backward(ctx, dout):
-        xv, k1, k2, k3, kd, y1, o1, y2, o2, y3, yd, out, m1, i1, m2, i2, m3, i3, md, idd, g1, g2, g3, gd = ctx.saved_tensors
+        xv, k1, k2, k3, kd, y1, o1, y2, o2, y3, yd, out, m1, i1, m2, i2, m3, i3, md, idd, g1, g2, g3, gd, b1, b2, b3 = ctx.saved_tensors
         ge, gr, df = ctx.geoms, ctx.groups, ctx.deferred
         dv = _grad_view(dout)
-        dy3, dres, dg3, db3 = _bn_train_bwd(dv, out, y3, m3, i3, g3, True, gr[2], True)
+        dy3, dres, dg3, db3 = _bn_train_bwd(dv, out, y3, m3, i3, g3, b3, True, gr[2], True, True)
         dw3, _ = _wgrad(o2, dy3, tuple(k3.shape), ge[2], deferred=df[2])
         do2 = K.conv_bwd_data(dy3, k3, tuple(o2.shape), *ge[2])
-        dy2, _, dg2, db2 = _bn_train_bwd(do2, o2, y2, m2, i2, g2, True, gr[1], False)
+        dy2, _, dg2, db2 = _bn_train_bwd(do2, o2, y2, m2, i2, g2, b2, True, gr[1], False, False)
         dw2, _ = _wgrad(o1, dy2, tuple(k2.shape), ge[1], deferred=df[1])
         do1 = K.conv_bwd_data(dy2, k2, tuple(o1.shape), *ge[1])
-        dy1, _, dg1, db1 = _bn_train_bwd(do1, o1, y1, m1, i1, g1, True, gr[0], False)
+        dy1, _, dg1, db1 = _bn_train_bwd(do1, o1, y1, m1, i1, g1, b1, True, gr[0], False, False)
         dw1, _ = _wgrad(xv, dy1, tuple(k1.shape), ge[0], deferred=df[0])
         dwd = dgd = dbd = None
         skip = dres
         if ctx.has_ds:
-            dyd, _, dgd, dbd = _bn_train_bwd(dres, None, yd, md, idd, gd, False, gr[3], False)
+            dyd, _, dgd, dbd = _bn_train_bwd(dres, None, yd, md, idd, gd, None, False, gr[3], False, False)
             dwdk, _ = _wgrad(xv, dyd, tuple(kd.shape), ge[3], deferred=df[3])
             dwd = dwdk.permute(0, 3, 1, 2)
             skip = K.conv_bwd_data(dyd, kd, tuple(xv.shape), *ge[3]) if ctx.needs_input_grad[0] else None
@@ -207,17 +215,17 @@ class _ConvBnAct(torch.autograd.Function):
         y = K.conv_fwd(xv, wk, stride, pad, dil, bias=bias)
         o, mean, invstd = _bn_train_fwd(y, gamma, beta, bn, rv, relu, ov)
         ctx.group, ctx.has_bias, ctx.has_res = bn.group, bias is not None, residual is not None
-        ctx.save_for_backward(xv, wk, y, o, mean, invstd, gamma)
+        ctx.save_for_backward(xv, wk, y, o, mean, invstd, gamma, beta)
         return nchw(o)
 
     @staticmethod
     def backward(ctx, dout):
         if not ctx.train:
             raise NotImplementedError('backward through eval-mode (frozen-statistics) BatchNorm is not implemented in the HIP path')
-        xv, wk, y, o, mean, invstd, gamma = ctx.saved_tensors
+        xv, wk, y, o, mean, invstd, gamma, beta = ctx.saved_tensors
         stride, pad, dil = ctx.geom
         dv = _grad_view(dout)
-        dy, dres, dgamma, dbeta = _bn_train_bwd(dv, o, y, mean, invstd, gamma, ctx.relu, ctx.group, ctx.has_res and ctx.needs_input_grad[5])
+        dy, dres, dgamma, dbeta = _bn_train_bwd(dv, o, y, mean, invstd, gamma, beta, ctx.relu, ctx.group, ctx.has_res and ctx.needs_input_grad[5], ctx.has_res)
         dx = nchw(K.conv_bwd_data(dy, wk, tuple(xv.shape), stride, pad, dil)) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):

@@ -171,12 +171,20 @@ def test_batchnorm_train(K, shape, relu, res):
     y = K.bn_apply(xg, mean, invstd, g, b, residual=nhwc(r) if res else None, relu=relu)
     assert rel(nchw(y), y_ref.detach()) < 1e-5
     dyg = nhwc(dy)
-    sums = K.bn_bwd_reduce(dyg, y, xg, mean, invstd, relu)
+    sums, _ = K.bn_bwd_reduce(dyg, y, xg, mean, invstd, relu)
     dx, dres = K.bn_bwd_apply(dyg, y, xg, mean, invstd, g, sums, n * h * w, relu, res)
     assert rel(sums[:c], bn.bias.grad) < 2e-5 and rel(sums[c:], bn.weight.grad) < 2e-5
     assert rel(nchw(dx), xr.grad) < 5e-5
     if res:
         assert rel(nchw(dres), rr.grad) < 1e-6
+    if relu and not res:     # mask rebuilt from x instead of read from y: the same bits
+        sums2, _ = K.bn_bwd_reduce(dyg, None, xg, mean, invstd, 2, g, b)
+        dx2, _ = K.bn_bwd_apply(dyg, None, xg, mean, invstd, g, sums2, n * h * w, 2, False, b)
+        assert torch.equal(sums2, sums) and torch.equal(dx2, dx)
+    if relu and res:         # reduce pass hands the masked gradient (= dres) to the apply pass
+        sums3, gm = K.bn_bwd_reduce(dyg, y, xg, mean, invstd, 1, want_gmask=True)
+        dx3, _ = K.bn_bwd_apply(gm, None, xg, mean, invstd, g, sums3, n * h * w, 0, False)
+        assert torch.equal(sums3, sums) and torch.equal(dx3, dx) and torch.equal(gm, dres)
 
 
 def test_pool_and_resize(K):
