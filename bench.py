@@ -132,6 +132,8 @@ def main():
             step()
         torch.cuda.synchronize()
         K.profile_enable(False)
+        if os.environ.get('PM_PROFILE_DUMP'):
+            K.profile_dump(os.environ['PM_PROFILE_DUMP'])
         # dominant kernel = the conv_igemm_kernel instantiation with the largest total time in the serialised pass
         best = None
         for mode in (0, 1, 2):

@@ -73,6 +73,7 @@ int pm_set_winograd(int mode);
  * instantiation conv_igemm_kernel<mode, bm, bn, .., km> (mode 0 fwd / 1 dgrad / 2 wgrad, block tile bm x bn, K-state variant
  * km 0 fast / 1 mid / 2 small, nst LDS stages 1 / 2; negative = any) and optionally clears the records. */
 int pm_profile_enable(int on);
+int pm_profile_dump(const char* csv_path);   /* one line per recorded launch: mode,bm,bn,km,nst,prec,M,N,K,batch,ksplit,ms,gflop */
 int pm_profile_read(int mode, int bm, int bn, int km, int nst, double* total_ms, double* total_flops, int64_t* launches, int clear);
 
 /* ---- K4 BatchNorm2d (mynn.py:8-14 -> nn.BatchNorm2d / SyncBatchNorm, eps 1e-5, momentum 0.1) -------------------
@@ -143,9 +144,11 @@ int pm_label_nearest(const int64_t* lab, int n, int H, int W, int64_t* out, int 
 size_t pm_upsample_ce_workspace(int n, int H, int W);
 int pm_upsample_ce_fwd(const pm_tensor* logits, float inv_temp, const int64_t* labels, int H, int W, float* loss_out,
                        void* ws, size_t ws_bytes, void* stream);
-/* dlogits (+)= gscale * d(mean CE)/dlogits ; gscale is a device scalar pointer (upstream grad), may be NULL (=1) */
+/* dlogits = gscale * d(mean CE)/dlogits ; gscale is a device scalar pointer (upstream grad), may be NULL (=1).
+ * Two separable gather passes through a [n,H,w,C] fp32 workspace (no atomics, deterministic). */
+size_t pm_upsample_ce_bwd_workspace(const pm_tensor* logits, int H, int W);
 int pm_upsample_ce_bwd(const pm_tensor* logits, float inv_temp, const int64_t* labels, int H, int W, const float* loss_out,
-                       const float* gscale, const pm_tensor* dlogits, void* stream);
+                       const float* gscale, const pm_tensor* dlogits, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- K7 memory read (memory.py:317-336 + get_score :167-189) ---------------------------------------------------
  * x: [N rows of d=256] (NHWC feature map); mem [m<=32][d]; writes qr = [qhat | P_m.M] (2d channels, input of

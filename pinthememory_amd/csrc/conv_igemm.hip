@@ -138,10 +138,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   if constexpr (MODE == MODE_FWD || MODE == MODE_DGRAD) {
     const int rh = (MODE == MODE_FWD) ? a.Ho : (a.sub ? a.Hc : a.H), rw = (MODE == MODE_FWD) ? a.Wo : (a.sub ? a.Wc : a.W);
     const int cdim = (MODE == MODE_FWD) ? a.Cin : a.Cout;
+    const bool pointwise = FAST && a.kh * a.kw == 1 && a.stride == 1 && a.pad == 0 && !a.sub;
 #pragma unroll
     for (int i = 0; i < A_N; ++i) {
       const int m = m0 + r + 32 * i;
-      if (m < a.M) {
+      if (pointwise) {   // 1x1 / stride 1 / no padding (and every Winograd GEMM): pixel m of the operand, no index decomposition
+        a_y0[i] = a_x0[i] = m < a.M ? 0 : -(1 << 28);
+        a_base[i] = m < a.M ? m * (MODE == MODE_FWD ? xp4 : yp4) + (FAST ? g * 16 : 0) : 0;
+      } else if (m < a.M) {
         const int img = m / (rh * rw), rem = m - img * (rh * rw);
         const int py = rem / rw, px = rem - py * rw;
         if constexpr (MODE == MODE_FWD) {
@@ -809,6 +813,7 @@ void launch_one(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
 struct ProfRec {
   hipEvent_t a, b;
   int mode, bm, bn, km, prec, nst;
+  int M, Nn, K, batch, ksplit;
   double flops;
 };
 bool g_prof_on = false;
@@ -825,7 +830,7 @@ int launch(const ConvK& k0, const Plan& p, hipStream_t st, int batch = 1, double
   ProfRec rec;
   if (g_prof_on) {
     (void)hipEventCreate(&rec.a), (void)hipEventCreate(&rec.b);
-    rec.mode = MODE, rec.bm = p.bm, rec.bn = p.bn, rec.km = (MODE == MODE_WGRAD && k.kmode == K_FAST) ? K_MID : k.kmode, rec.prec = k.prec, rec.nst = (MODE != MODE_WGRAD && k.kmode == K_FAST && p.bn >= 64 && k.kper <= nst1_max_steps() * BK) ? 1 : 2, rec.flops = flops >= 0.0 ? flops : 2.0 * (double)k.M * (double)k.Nn * (double)k.K * batch;
+    rec.mode = MODE, rec.bm = p.bm, rec.bn = p.bn, rec.km = (MODE == MODE_WGRAD && k.kmode == K_FAST) ? K_MID : k.kmode, rec.prec = k.prec, rec.nst = (MODE != MODE_WGRAD && k.kmode == K_FAST && p.bn >= 64 && k.kper <= nst1_max_steps() * BK) ? 1 : 2, rec.M = k.M, rec.Nn = k.Nn, rec.K = k.K, rec.batch = batch, rec.ksplit = p.ksplit, rec.flops = flops >= 0.0 ? flops : 2.0 * (double)k.M * (double)k.Nn * (double)k.K * batch;
     (void)hipEventRecord(rec.a, st);
   }
   constexpr bool akc = MODE != MODE_WGRAD, bkc = MODE == MODE_FWD;
@@ -1016,6 +1021,21 @@ extern "C" int pm_profile_read(int mode, int bm, int bn, int km, int nst, double
   if (total_ms) *total_ms = ms;
   if (total_flops) *total_flops = fl;
   if (launches) *launches = n;
+  return PM_OK;
+}
+
+// One CSV line per recorded launch (tuning aid): mode,bm,bn,km,nst,prec,M,N,K,batch,ksplit,ms,gflop
+extern "C" int pm_profile_dump(const char* path) {
+  PM_REQUIRE(path, PM_EINVAL, "pm_profile_dump: null path");
+  FILE* f = fopen(path, "w");
+  PM_REQUIRE(f, PM_EINVAL, "pm_profile_dump: cannot open %s", path);
+  fprintf(f, "mode,bm,bn,km,nst,prec,M,N,K,batch,ksplit,ms,gflop\n");
+  for (const ProfRec& r : g_prof) {
+    float t = 0.f;
+    if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+    fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.5f,%.4f\n", r.mode, r.bm, r.bn, r.km, r.nst, r.prec, r.M, r.Nn, r.K, r.batch, r.ksplit, t, r.flops * 1e-9);
+  }
+  fclose(f);
   return PM_OK;
 }
 

@@ -4,7 +4,9 @@
 // WITHOUT materialising the [B,19,H,W] upsampled logits (358 MB at bs=8, 768^2): the low-res logits stay L2-resident
 // and each hi-res pixel interpolates its 19 classes in registers. HBM-bound on the int64 labels (37.7 MB).
 // Forward: block partial (sum, count) -> fixed-order final reduce (deterministic).
-// Backward: GATHER per low-res pixel (one wave each, lanes over the hi-res support) -- no atomics, deterministic.
+// Backward: the transposed bilinear operator is separable, so the gradient is gathered in two passes without atomics
+// (deterministic): (1) per hi-res row, softmax - onehot of every hi-res pixel once (staged in LDS) reduced over its columns to the
+// low-res columns -> T[n][H][w][C]; (2) per low-res pixel, T reduced over the supporting hi-res rows.
 #include "pm_common.h"
 
 namespace {
@@ -90,7 +92,7 @@ __global__ void ce_final_kernel(const float* __restrict__ part, int nb, float* _
   }
 }
 
-__device__ __forceinline__ void support(float scale, int i, int out, int& lo, int& hi) {
+__host__ __device__ __forceinline__ void support(float scale, int i, int out, int& lo, int& hi) {   // hi-res indices that can touch low-res index i
   if (scale <= 0.f) {
     lo = 0, hi = out - 1;
     return;
@@ -101,52 +103,93 @@ __device__ __forceinline__ void support(float scale, int i, int out, int& lo, in
 }
 __device__ __forceinline__ float tap_weight(const pm_lerp& l, int i) { return (l.i0 == i ? l.w0 : 0.f) + (l.i1 == i ? l.w1 : 0.f); }
 
-// one wave per low-res pixel; lanes sweep the hi-res support window; 19 partial sums per lane, wave-reduced at the end
+// pass 1: block = (low-res column segment [x0, x0 + XW), hi-res row Y, image b). Phase A: one thread per hi-res pixel of the
+// segment's support computes softmax - onehot (0 for ignored pixels) into LDS. Phase B: one thread per (low-res column, class) sums
+// its supporting hi-res columns in ascending order.
 template <int C_>
-__global__ __launch_bounds__(256) void ce_bwd_kernel(const CEGeom g, const float* __restrict__ loss_out, const float* __restrict__ gscale,
-                                                     float* __restrict__ dl, long dlp, int accumulate) {
+__global__ __launch_bounds__(256) void ce_bwd_rows_kernel(const CEGeom g, int XW, float* __restrict__ T) {
+  extern __shared__ float G[];
   const int C = C_ > 0 ? C_ : g.C;
-  const int lane = threadIdx.x & 63;
-  const long npix = (long)g.n * g.h * g.w;
-  const float cnt = loss_out[1];
-  const float gs = (gscale ? gscale[0] : 1.f) * g.inv_temp / cnt;
-  for (long lp = (long)blockIdx.x * 4 + (threadIdx.x >> 6); lp < npix; lp += (long)gridDim.x * 4) {
-    const int x = (int)(lp % g.w), y = (int)((lp / g.w) % g.h), b = (int)(lp / ((long)g.w * g.h));
-    int ylo, yhi, xlo, xhi;
-    support(g.sy, y, g.H, ylo, yhi);
-    support(g.sx, x, g.W, xlo, xhi);
-    const int wx = xhi - xlo + 1, wtot = (yhi - ylo + 1) * wx;
-    float acc[C_ > 0 ? C_ : MAXC];
-#pragma unroll
-    for (int c = 0; c < (C_ > 0 ? C_ : MAXC); ++c) acc[c] = 0.f;
-    for (int j = lane; j < wtot; j += 64) {
-      const int Y = ylo + j / wx, X = xlo + j % wx;
-      const pm_lerp ly = pm_ac_lerp(g.sy, Y, g.h), lx = pm_ac_lerp(g.sx, X, g.w);
-      const float wgt = tap_weight(ly, y) * tap_weight(lx, x);
-      if (wgt == 0.f) continue;
-      const int64_t lab = g.labels[((long)b * g.H + Y) * g.W + X];
-      if (lab == 255) continue;
-      float v[C_ > 0 ? C_ : MAXC];
-      interp_logits<C_>(g, b, ly, lx, v);
-      float mx = -INFINITY;
+  const int CP = C | 1;   // odd pitch: conflict-free LDS rows
+  const int x0 = blockIdx.x * XW, x1 = min(g.w, x0 + XW);
+  const int Y = blockIdx.y, b = blockIdx.z;
+  int Xlo, Xhi, tmp;
+  support(g.sx, x0, g.W, Xlo, tmp);
+  support(g.sx, x1 - 1, g.W, tmp, Xhi);
+  const int nX = Xhi - Xlo + 1;
+  const pm_lerp ly = pm_ac_lerp(g.sy, Y, g.h);
+  for (int j = threadIdx.x; j < nX; j += 256) {
+    const int X = Xlo + j;
+    const int64_t lab = g.labels[((long)b * g.H + Y) * g.W + X];
+    float* out = G + j * CP;
+    if (lab == 255) {
 #pragma unroll
       for (int c = 0; c < (C_ > 0 ? C_ : MAXC); ++c)
-        if (c < C) mx = fmaxf(mx, v[c]);
-      float se = 0.f;
-#pragma unroll
-      for (int c = 0; c < (C_ > 0 ? C_ : MAXC); ++c)
-        if (c < C) v[c] = expf(v[c] - mx), se += v[c];
-      const float inv = wgt / se;
-#pragma unroll
-      for (int c = 0; c < (C_ > 0 ? C_ : MAXC); ++c)
-        if (c < C) acc[c] += v[c] * inv - (c == (int)lab ? wgt : 0.f);
+        if (c < C) out[c] = 0.f;
+      continue;
     }
+    const pm_lerp lx = pm_ac_lerp(g.sx, X, g.w);
+    float v[C_ > 0 ? C_ : MAXC];
+    interp_logits<C_>(g, b, ly, lx, v);
+    float mx = -INFINITY;
 #pragma unroll
     for (int c = 0; c < (C_ > 0 ? C_ : MAXC); ++c)
-      if (c < C) {
-        const float s = pm_wave_sum(acc[c]) * gs;
-        if (lane == 0) dl[lp * dlp + c] = accumulate ? dl[lp * dlp + c] + s : s;
-      }
+      if (c < C) mx = fmaxf(mx, v[c]);
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < (C_ > 0 ? C_ : MAXC); ++c)
+      if (c < C) v[c] = expf(v[c] - mx), se += v[c];
+    const float inv = 1.f / se;
+#pragma unroll
+    for (int c = 0; c < (C_ > 0 ? C_ : MAXC); ++c)
+      if (c < C) out[c] = v[c] * inv - (c == (int)lab ? 1.f : 0.f);
+  }
+  __syncthreads();
+  const int nout = (x1 - x0) * C;
+  for (int o = threadIdx.x; o < nout; o += 256) {
+    const int xl = o / C, c = o - xl * C, x = x0 + xl;
+    int lo, hi;
+    support(g.sx, x, g.W, lo, hi);
+    float acc = 0.f;
+    for (int X = lo; X <= hi; ++X) acc += tap_weight(pm_ac_lerp(g.sx, X, g.w), x) * G[(X - Xlo) * CP + c];
+    T[(((long)b * g.H + Y) * g.w + x) * C + c] = acc;
+  }
+}
+
+// pass 2: thread per (low-res pixel, class): supporting hi-res rows in ascending order, then the loss scale
+__global__ __launch_bounds__(256) void ce_bwd_cols_kernel(const CEGeom g, const float* __restrict__ T, const float* __restrict__ loss_out,
+                                                          const float* __restrict__ gscale, float* __restrict__ dl, long dlp) {
+  const int C = g.C;
+  const long total = (long)g.n * g.h * g.w * C;
+  const float gs = (gscale ? gscale[0] : 1.f) * g.inv_temp / loss_out[1];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    long q = i / C;
+    const int x = (int)(q % g.w);
+    q /= g.w;
+    const int y = (int)(q % g.h), b = (int)(q / g.h);
+    int lo, hi;
+    support(g.sy, y, g.H, lo, hi);
+    float acc = 0.f;
+    for (int Y = lo; Y <= hi; ++Y) acc += tap_weight(pm_ac_lerp(g.sy, Y, g.h), y) * T[(((long)b * g.H + Y) * g.w + x) * C + c];
+    dl[((long)(b * g.h + y) * g.w + x) * dlp + c] = acc * gs;
+  }
+}
+
+// low-res columns per pass-1 block: ~256 hi-res columns of support, LDS bounded by 60 KB
+inline int bwd_seg(const CEGeom& g, int& max_nx) {
+  int xw = g.sx > 0.f ? std::max(1, std::min(g.w, (int)(256.f * g.sx))) : g.w;
+  const int cp = g.C | 1;
+  for (;;) {
+    max_nx = 0;
+    for (int x0 = 0; x0 < g.w; x0 += xw) {
+      int lo, hi, tmp;
+      support(g.sx, x0, g.W, lo, tmp);
+      support(g.sx, std::min(g.w, x0 + xw) - 1, g.W, tmp, hi);
+      max_nx = std::max(max_nx, hi - lo + 1);
+    }
+    if ((size_t)max_nx * cp * sizeof(float) <= 60 * 1024 || xw == 1) return xw;
+    xw = std::max(1, xw / 2);
   }
 }
 
@@ -178,15 +221,28 @@ extern "C" int pm_upsample_ce_fwd(const pm_tensor* logits, float inv_temp, const
   return pm_check_launch("upsample_ce_fwd");
 }
 
+extern "C" size_t pm_upsample_ce_bwd_workspace(const pm_tensor* logits, int H, int W) {
+  (void)W;
+  return pm_align_up((size_t)logits->n * H * logits->w * logits->c * sizeof(float), 256);
+}
+
 extern "C" int pm_upsample_ce_bwd(const pm_tensor* logits, float inv_temp, const int64_t* labels, int H, int W, const float* loss_out, const float* gscale,
-                                  const pm_tensor* dlogits, void* stream) {
+                                  const pm_tensor* dlogits, void* ws, size_t ws_bytes, void* stream) {
   CEGeom g;
   if (int e = fill(g, logits, inv_temp, labels, H, W, "upsample_ce_bwd")) return e;
   PM_REQUIRE(loss_out && dlogits && dlogits->ptr && pm_same_shape(logits, dlogits), PM_EINVAL, "upsample_ce_bwd: bad args");
-  const long npix = (long)g.n * g.h * g.w;
-  const int nb = (int)std::min<long>((npix + 3) / 4, 256 * 64);
+  PM_REQUIRE(ws && ws_bytes >= pm_upsample_ce_bwd_workspace(logits, H, W), PM_EWORKSPACE, "upsample_ce_bwd: workspace too small");
+  PM_REQUIRE(H <= 65535 && g.n <= 65535, PM_EUNSUPPORTED, "upsample_ce_bwd: H or batch > 65535");
+  int max_nx = 0;
+  const int xw = bwd_seg(g, max_nx);
+  const size_t lds = (size_t)max_nx * (g.C | 1) * sizeof(float);
+  PM_REQUIRE(lds <= 64 * 1024, PM_EUNSUPPORTED, "upsample_ce_bwd: one low-res column is supported by %d hi-res columns (LDS)", max_nx);
   hipStream_t st = (hipStream_t)stream;
-  if (g.C == 19) hipLaunchKernelGGL(ce_bwd_kernel<19>, dim3(nb), dim3(256), 0, st, g, loss_out, gscale, (float*)dlogits->ptr, (long)dlogits->pitch, 0);
-  else hipLaunchKernelGGL(ce_bwd_kernel<0>, dim3(nb), dim3(256), 0, st, g, loss_out, gscale, (float*)dlogits->ptr, (long)dlogits->pitch, 0);
+  dim3 grid(pm_cdiv(g.w, xw), H, g.n);
+  if (g.C == 19) hipLaunchKernelGGL(ce_bwd_rows_kernel<19>, grid, dim3(256), lds, st, g, xw, (float*)ws);
+  else hipLaunchKernelGGL(ce_bwd_rows_kernel<0>, grid, dim3(256), lds, st, g, xw, (float*)ws);
+  const long total = (long)g.n * g.h * g.w * g.C;
+  hipLaunchKernelGGL(ce_bwd_cols_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 1 << 20)), dim3(256), 0, st, g, (const float*)ws, loss_out, gscale,
+                     (float*)dlogits->ptr, (long)dlogits->pitch);
   return pm_check_launch("upsample_ce_bwd");
 }

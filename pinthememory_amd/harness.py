@@ -37,6 +37,8 @@ def memory_only_forward(net, x, gts):
     m.memory._mem(feat)
     m.memory.m_items = m.memory.m_items.detach()
     m.memory.write(feat, gts, True)
+    from .hip import ops
+    ops.flush_bn_counters()
 
 
 def agg_train_step(net, opt, x, gts, aux_gts=None, sched=None, buckets=None, truncate_second_forward=False):

@@ -293,7 +293,10 @@ def upsample_ce_fwd(logits, labels, inv_temp=1.0):
 def upsample_ce_bwd(logits, labels, loss_out, gscale, inv_temp=1.0):
     n, H, W = labels.shape
     dl = new(tuple(logits.shape), logits, pitch_pad=(logits.stride(2) != logits.shape[3]))   # same pitch as the logits
-    check(_lib().pm_upsample_ce_bwd(byref(tdesc(logits)), inv_temp, labels.data_ptr(), H, W, loss_out.data_ptr(), ptr(gscale), byref(tdesc(dl)), stream()),
+    lib, ld = _lib(), tdesc(logits)
+    nb = lib.pm_upsample_ce_bwd_workspace(byref(ld), H, W)
+    ws = workspace(nb, logits.device)
+    check(lib.pm_upsample_ce_bwd(byref(ld), inv_temp, labels.data_ptr(), H, W, loss_out.data_ptr(), ptr(gscale), byref(tdesc(dl)), ptr(ws), nb, stream()),
           'pm_upsample_ce_bwd')
     return dl
 
@@ -377,6 +380,10 @@ def set_winograd(mode):
 
 def profile_enable(on):
     check(_lib().pm_profile_enable(1 if on else 0), 'pm_profile_enable')
+
+
+def profile_dump(path):
+    check(_lib().pm_profile_dump(str(path).encode()), 'pm_profile_dump')
 
 
 def profile_read(mode=-1, bm=-1, bn=-1, km=-1, nst=-1, clear=False):

@@ -40,6 +40,7 @@ SIGNATURES = {
     'pm_conv_bwd_weight': (_i, [_T, _T, _vp, _vp, _P, _vp, _sz, _vp]),
     'pm_set_winograd': (_i, [_i]),
     'pm_profile_enable': (_i, [_i]),
+    'pm_profile_dump': (_i, [ctypes.c_char_p]),
     'pm_profile_read': (_i, [_i, _i, _i, _i, _i, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64), _i]),
     'pm_bn_workspace': (_sz, [_T]),
     'pm_bn_stats': (_i, [_T, _vp, _vp, _sz, _vp]),
@@ -69,7 +70,8 @@ SIGNATURES = {
     'pm_label_nearest': (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp]),
     'pm_upsample_ce_workspace': (_sz, [_i, _i, _i]),
     'pm_upsample_ce_fwd': (_i, [_T, _f, _vp, _i, _i, _vp, _vp, _sz, _vp]),
-    'pm_upsample_ce_bwd': (_i, [_T, _f, _vp, _i, _i, _vp, _vp, _T, _vp]),
+    'pm_upsample_ce_bwd_workspace': (_sz, [_T, _i, _i]),
+    'pm_upsample_ce_bwd': (_i, [_T, _f, _vp, _i, _i, _vp, _vp, _T, _vp, _sz, _vp]),
     'pm_mem_read_fwd': (_i, [_T, _vp, _i, _vp, _T, _vp, _vp, _vp]),
     'pm_mem_colsoftmax_workspace': (_sz, [_i64, _i]),
     'pm_mem_colsoftmax': (_i, [_vp, _vp, _i64, _i, _vp, _vp, _sz, _vp]),

@@ -49,7 +49,18 @@ class BNState:
         # nn.SyncBatchNorm (train.py:95 convert_sync_batchnorm) -> exchange statistics over RCCL
         self.group = D.bn_group(bn)
         if bn.training and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+            _nbt_pending.append(bn.num_batches_tracked)
+
+
+# num_batches_tracked += 1 of every BN layer that ran in training mode: one multi-tensor launch per forward pass (flush_bn_counters,
+# called where the networks' forward ends) instead of 65 single-element kernels.
+_nbt_pending = []
+
+
+def flush_bn_counters():
+    if _nbt_pending:
+        torch._foreach_add_(_nbt_pending, 1)
+        _nbt_pending.clear()
 
 
 # ---- weight-gradient overlap ------------------------------------------------------------------------------------------
@@ -84,6 +95,7 @@ class _Defer(torch.autograd.Function):
 
 
 def begin_forward():
+    flush_bn_counters()      # backstop for callers that drive sub-modules directly
     _proxy.clear()
 
 

@@ -70,6 +70,8 @@ class _AtrousSpatialPyramidPoolingModule(nn.Module):
 
 class _Base(nn.Module):
     def _adopt_trunk(self, trunk):
+        # the BN layers' num_batches_tracked counters are bumped in one multi-tensor launch when forward() returns
+        self.register_forward_hook(lambda mod, inp, out: ops.flush_bn_counters())
         if trunk == 'resnet-50':
             resnet = Resnet.resnet50(wt_layer=self.args.wt_layer)
         elif trunk == 'resnet-101':

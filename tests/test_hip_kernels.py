@@ -239,9 +239,11 @@ def test_layout_and_labels(K):
     assert torch.equal(K.label_nearest(lab.cuda(), (9, 7)).cpu(), ref)
 
 
-@pytest.mark.parametrize('hw,HW,temp', [((12, 12), (48, 48), 1.0), ((6, 6), (96, 96), 0.5), ((16, 16), (16, 16), 1.0), ((5, 7), (33, 29), 2.0)])
-def test_upsample_ce(K, hw, HW, temp):
-    n, C = 2, 19
+@pytest.mark.parametrize('hw,HW,temp,C', [((12, 12), (48, 48), 1.0, 19), ((6, 6), (96, 96), 0.5, 19), ((16, 16), (16, 16), 1.0, 19), ((5, 7), (33, 29), 2.0, 19),
+                                          ((1, 1), (8, 8), 1.0, 19), ((24, 24), (384, 384), 0.07, 19), ((9, 9), (4, 6), 1.0, 19), ((7, 5), (30, 41), 1.0, 8),
+                                          ((192, 48), (768, 192), 1.0, 19)])
+def test_upsample_ce(K, hw, HW, temp, C):
+    n = 2
     lg = rnd(n, C, *hw, seed=1) * 3
     g = torch.Generator().manual_seed(2)
     lab = torch.randint(0, C, (n, *HW), generator=g)
