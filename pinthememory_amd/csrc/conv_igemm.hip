@@ -740,13 +740,22 @@ struct Plan {
 Plan make_plan(int mode, long M, long Nn, long K) {
   Plan best_p{};
   double best = 1e30;
-  const int bn = Nn > 64 ? 128 : (Nn > 32 ? 64 : 32);
+  static const int force_bm = getenv("PM_FORCE_BM") ? atoi(getenv("PM_FORCE_BM")) : 0;   // tuning runs only
+  static const int force_bn = getenv("PM_FORCE_BN") ? atoi(getenv("PM_FORCE_BN")) : 0;
+  static const int wide_k = getenv("PM_WIDE_K") ? atoi(getenv("PM_WIDE_K")) : 0;
+  // 128 x 256 tile (the whole 256-wide output row panel from one pass over A) for the short-K expansion 1x1s: HBM-bound, so
+  // halving the A re-reads and prologues per output byte is what counts
+  const bool wide = mode != MODE_WGRAD && Nn % 256 == 0 && K <= wide_k && K % BK == 0;
+  int bn = Nn > 64 ? 128 : (Nn > 32 ? 64 : 32);
+  if (wide) bn = 256;
+  if (force_bn && mode != MODE_WGRAD) bn = force_bn;
   const long ksteps = (K + BK - 1) / BK;
   // candidate row tiles: 128 always; 64 halves the tile so that problems with few / awkward tile counts (the 48x48 maps: 144
   // row tiles of 128) spread evenly over the 256 CUs; a 64-row tile is ~8 % less efficient per FLOP (half the MFMAs per
   // fragment read and per barrier).
   for (int bm = 128; bm >= 64; bm -= 64) {
-    if (bm == 64 && bn < 64) continue;                            // no 64x32 instantiation (4 waves need >= 2 tiles)
+    if (bm == 64 && (bn < 64 || bn == 256)) continue;             // no 64x32 / 64x256 instantiation
+    if (force_bm && mode != MODE_WGRAD && bm != force_bm && !(force_bm == 64 && bn < 64)) continue;
     if (bm == 64 && mode == MODE_WGRAD && M > 64) continue;       // wgrad: 64 rows only for Cout <= 64
     if (bm == 128 && mode == MODE_WGRAD && M <= 64 && bn >= 64) continue;
     const int tiles_m = pm_cdiv(M, bm), tiles_n = pm_cdiv(Nn, bn);
@@ -835,7 +844,9 @@ int launch(const ConvK& k0, const Plan& p, hipStream_t st, int batch = 1, double
   }
   constexpr bool akc = MODE != MODE_WGRAD, bkc = MODE == MODE_FWD;
   auto smem = [&](int bm, int bn) { return (size_t)2 * ((akc ? bm * LDK : BK * bm) + (bkc ? bn * LDK : BK * bn)) * sizeof(float); };
-  if (p.bm == 64) {
+  if (p.bn == 256) {
+    if constexpr (MODE != MODE_WGRAD) launch_nst<MODE, 128, 256, 2, 2, K_FAST, 0, 1>(k, grid, smem(128, 256), st);
+  } else if (p.bm == 64) {
     if (p.bn == 128) launch_one<MODE, 64, 128, 2, 2>(k, grid, smem(64, 128), st);
     else launch_one<MODE, 64, 64, 2, 2>(k, grid, smem(64, 64), st);
   } else if (p.bn == 128) {
@@ -885,8 +896,8 @@ void fill_geom(ConvK& k, const pm_tensor* x, const pm_tensor* y, const pm_conv_p
 // forward:  V = Bt x B ; M[p] = V[p] U[p]^T (P = (m+2)^2 batched GEMMs on the kernel above) ; y = At M A (+ epilogue)
 // data grad: the same pipeline on dy with the rotated / transposed filter.
 // Taken when the GEMMs are MFMA-bound (both channel counts >= 128: the expanded V / M streams would otherwise dominate) and the
-// dilation sub-lattices tile the image without much padding: m = 4 when H, W are multiples of 4*dil (d = 1, 2, 6, 12 on the 48x48
-// maps, d = 1 on 192x192), else m = 2, else the direct algorithm.
+// dilation sub-lattices tile the image without too much padding: the m in {4, 2} with the fewest multiplies per output, if that is
+// below 0.6 of the direct algorithm's (m = 4 for d = 1, 2, 6, 12, 18 on the 48x48 maps and d = 1 on 192x192).
 int g_wino_mode = 4;   // 0 off, 2 F(2x2) only, 4 prefer F(4x4)
 struct WinoPlan {
   bool use;
@@ -901,11 +912,16 @@ WinoPlan wino_plan(const pm_tensor* xin, int cout, const pm_conv_params* p, bool
   if (g_wino_mode == 0 || p->kh != 3 || p->kw != 3 || p->stride != 1 || p->pad != p->dil || p->prec == 1) return wp;
   const int cin = xin->c;
   if (cin < 128 || cout < 128 || (cout & 3) || (cin & 3)) return wp;
+  // multiplies per output relative to the direct algorithm: (m+2)^2 / (9 m^2) x the padding of the sub-lattices to whole tiles
+  // (cover). F(4x4) on exactly tiling maps: 0.25; ASPP's d18 on 48x48 (sub-lattices of 3 or 2 rows in one 4-row tile): 0.56, still a
+  // measured 1.3x over direct. Above 0.6 the transforms eat the gain.
   int m = 0;
-  for (int cand = g_wino_mode; cand >= 2 && !m; cand -= 2) {
+  double best_ratio = 0.6;
+  for (int cand = g_wino_mode; cand >= 2; cand -= 2) {
     const pm_wino_geom g = pm_wino_make_geom(xin->n, xin->h, xin->w, p->dil, cand);
     const double cover = (double)(cand * g.TY * p->dil) * (double)(cand * g.TX * p->dil) / ((double)xin->h * xin->w);
-    if (cover <= 1.15) m = cand, wp.g = g;
+    const double ratio = cover * (cand + 2) * (cand + 2) / (9.0 * cand * cand);
+    if (ratio <= best_ratio) best_ratio = ratio, m = cand, wp.g = g;
   }
   if (!m) return wp;
   wp.P = (m + 2) * (m + 2);

@@ -14,6 +14,9 @@ SHAPES = [  # name, n, cin, h, w, cout, k, stride, pad, dil
     ('layer1.conv2 3x3 64->64 @192', 8, 64, 192, 192, 64, 3, 1, 1, 1),
     ('layer1.conv3 1x1 64->256 @192', 8, 64, 192, 192, 256, 1, 1, 0, 1),
     ('layer2.conv2 3x3 128->128 @96', 8, 128, 96, 96, 128, 3, 1, 1, 1),
+    ('layer2.conv3 1x1 128->512 @96', 8, 128, 96, 96, 512, 1, 1, 0, 1),
+    ('layer1.conv1 1x1 256->64 @192', 8, 256, 192, 192, 64, 1, 1, 0, 1),
+    ('layer3.conv1 1x1 1024->256 @48', 8, 1024, 48, 48, 256, 1, 1, 0, 1),
     ('layer3.conv3 1x1 256->1024 @48', 8, 256, 48, 48, 1024, 1, 1, 0, 1),
     ('stem 7x7 s2 4->64 @768', 8, 4, 768, 768, 64, 7, 2, 3, 1),
     ('final2 1x1 256->19 @192', 8, 256, 192, 192, 19, 1, 1, 0, 1),
@@ -27,8 +30,12 @@ def bench(fn, iters=5):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
 
+import os
+ONLY = os.environ.get('PROBE_ONLY')
 rows = []
 for name, n, cin, h, w, cout, k, s, p, d in SHAPES:
+    if ONLY and ONLY not in name:
+        continue
     x = torch.randn(n, h, w, cin, device='cuda')
     wt = torch.randn(cout, k, k, cin, device='cuda') * 0.05
     y = K.conv_fwd(x, wt, s, p, d)

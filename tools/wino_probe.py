@@ -11,6 +11,7 @@ SHAPES = [  # name, n, cin, h, w, cout, dil
     ('layer4.conv2 d2 512->512 @48', 8, 512, 48, 48, 512, 2),
     ('aspp d6 2048->256 @48', 8, 2048, 48, 48, 256, 6),
     ('aspp d12 2048->256 @48', 8, 2048, 48, 48, 256, 12),
+    ('aspp d18 2048->256 @48', 8, 2048, 48, 48, 256, 18),
     ('dsn.0 1024->512 @48', 8, 1024, 48, 48, 512, 1),
     ('layer2.conv2 128->128 @96', 8, 128, 96, 96, 128, 1),
 ]
@@ -23,8 +24,11 @@ def bench(fn, iters=5):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
 
+ONLY = os.environ.get('PROBE_ONLY')
 rows = []
 for name, n, cin, h, w, cout, d in SHAPES:
+    if ONLY and ONLY not in name:
+        continue
     x = torch.randn(n, h, w, cin, device='cuda')
     wt = torch.randn(cout, 3, 3, cin, device='cuda') * 0.05
     dy = torch.randn(n, h, w, cout, device='cuda')
