@@ -742,19 +742,14 @@ Plan make_plan(int mode, long M, long Nn, long K) {
   double best = 1e30;
   static const int force_bm = getenv("PM_FORCE_BM") ? atoi(getenv("PM_FORCE_BM")) : 0;   // tuning runs only
   static const int force_bn = getenv("PM_FORCE_BN") ? atoi(getenv("PM_FORCE_BN")) : 0;
-  static const int wide_k = getenv("PM_WIDE_K") ? atoi(getenv("PM_WIDE_K")) : 0;
-  // 128 x 256 tile (the whole 256-wide output row panel from one pass over A) for the short-K expansion 1x1s: HBM-bound, so
-  // halving the A re-reads and prologues per output byte is what counts
-  const bool wide = mode != MODE_WGRAD && Nn % 256 == 0 && K <= wide_k && K % BK == 0;
   int bn = Nn > 64 ? 128 : (Nn > 32 ? 64 : 32);
-  if (wide) bn = 256;
   if (force_bn && mode != MODE_WGRAD) bn = force_bn;
   const long ksteps = (K + BK - 1) / BK;
   // candidate row tiles: 128 always; 64 halves the tile so that problems with few / awkward tile counts (the 48x48 maps: 144
   // row tiles of 128) spread evenly over the 256 CUs; a 64-row tile is ~8 % less efficient per FLOP (half the MFMAs per
   // fragment read and per barrier).
   for (int bm = 128; bm >= 64; bm -= 64) {
-    if (bm == 64 && (bn < 64 || bn == 256)) continue;             // no 64x32 / 64x256 instantiation
+    if (bm == 64 && bn < 64) continue;                            // no 64x32 instantiation (4 waves need >= 2 tiles)
     if (force_bm && mode != MODE_WGRAD && bm != force_bm && !(force_bm == 64 && bn < 64)) continue;
     if (bm == 64 && mode == MODE_WGRAD && M > 64) continue;       // wgrad: 64 rows only for Cout <= 64
     if (bm == 128 && mode == MODE_WGRAD && M <= 64 && bn >= 64) continue;
@@ -844,9 +839,7 @@ int launch(const ConvK& k0, const Plan& p, hipStream_t st, int batch = 1, double
   }
   constexpr bool akc = MODE != MODE_WGRAD, bkc = MODE == MODE_FWD;
   auto smem = [&](int bm, int bn) { return (size_t)2 * ((akc ? bm * LDK : BK * bm) + (bkc ? bn * LDK : BK * bn)) * sizeof(float); };
-  if (p.bn == 256) {
-    if constexpr (MODE != MODE_WGRAD) launch_nst<MODE, 128, 256, 2, 2, K_FAST, 0, 1>(k, grid, smem(128, 256), st);
-  } else if (p.bm == 64) {
+  if (p.bm == 64) {
     if (p.bn == 128) launch_one<MODE, 64, 128, 2, 2>(k, grid, smem(64, 128), st);
     else launch_one<MODE, 64, 64, 2, 2>(k, grid, smem(64, 64), st);
   } else if (p.bn == 128) {

@@ -266,6 +266,30 @@ def test_full_size_properties(env):
     assert outs[0] == outs[1], 'HIP path must be run-to-run deterministic'
 
 
+def test_conv_routes_agree_on_the_network(env):
+    """The Winograd routes (F(4x4,3x3) default, F(2x2,3x3)) and the direct implicit GEMM are the same function up to fp32 rounding:
+    eval logits of the flagship network at 384^2 (48^2 / 96^2 maps: every Winograd layer incl. the dilated ASPP branches is active)
+    agree to LOGIT_TOL / 10 and give the same class map wherever the top-2 margin exceeds that; the direct route at this size is
+    also the link to the oracle-checked 256^2 case above (where only part of the layers tile)."""
+    from pinthememory_amd.hip import kernels as K
+    synth = env['synth']
+    net = synth.load_det_weights(env['deepv3plus'].DeepR50V3PlusD(synth.model_args(), 19, CRIT, CRIT)).cuda().eval()
+    x, _ = synth.make_batch(2, 384)
+    lg = {}
+    try:
+        for mode in (0, 2, 4):
+            K.set_winograd(mode)
+            with torch.no_grad():
+                lg[mode] = net(x.cuda())[0].cpu()
+    finally:
+        K.set_winograd(4)
+    for mode in (2, 4):
+        assert not torch.equal(lg[mode], lg[0])
+        assert (lg[mode] - lg[0]).abs().max().item() < LOGIT_TOL / 10, mode
+        ok, frac, _ = argmax_gate(lg[mode], lg[0], tol=LOGIT_TOL / 10)
+        assert ok and frac > 0.9999, (mode, frac)
+
+
 def test_config3_bf16_mfma_forward_and_step(env):
     """BASELINE configs[2]: the same network with bf16-MFMA convolutions (operands rounded to bf16, fp32 accumulate / storage).
     Gate: looser than fp32 by the operand precision -- eval logits within 2e-2 of the fp32 oracle relative to their range and
