@@ -129,6 +129,15 @@ def bn_apply(x, mean, invstd, gamma, beta, residual=None, relu=False, out=None):
     return y
 
 
+def scale_shift_act(x, scale, shift, residual=None, relu=False):
+    """y = relu?(x * scale[c] + shift[c] + residual?) -- per-channel affine on an NHWC tensor."""
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    rd = tdesc(residual) if residual is not None else None
+    check(_lib().pm_scale_shift_act(byref(tdesc(x)), scale.data_ptr(), shift.data_ptr(), byref(rd) if rd else None, 1 if relu else 0, byref(tdesc(y)), stream()),
+          'pm_scale_shift_act')
+    return y
+
+
 def bn_bwd_reduce(dy, y, x, mean, invstd, relu, gamma=None, beta=None, want_gmask=False):
     """relu: 0 / False none, 1 / True mask from the forward output y, 2 mask rebuilt from x (needs gamma, beta). -> (sums, dy * mask or None)"""
     relu = int(relu)

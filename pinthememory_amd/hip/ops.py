@@ -220,24 +220,38 @@ class _ConvBnAct(torch.autograd.Function):
         rv = nhwc(residual) if residual is not None else None
         ov = nhwc(out) if out is not None else None
         ctx.geom, ctx.relu, ctx.train, ctx.deferred = geom, relu, bn.training, deferred and bias is None
-        if not bn.training:
+        needs_grad = any(ctx.needs_input_grad[:6])   # grad mode is off inside forward(); this reflects the caller's graph
+        if not bn.training and not needs_grad:     # inference: BN folded into the conv epilogue, nothing saved
             scale, shift = K.bn_fold(gamma, beta, bn.running_mean, bn.running_var, bn.eps, bias)
             o = K.conv_fwd(xv, wk, stride, pad, dil, scale=scale, shift=shift, residual=rv, relu=relu, out=ov)
             return nchw(o)
         y = K.conv_fwd(xv, wk, stride, pad, dil, bias=bias)
-        o, mean, invstd = _bn_train_fwd(y, gamma, beta, bn, rv, relu, ov)
+        if bn.training:
+            o, mean, invstd = _bn_train_fwd(y, gamma, beta, bn, rv, relu, ov)
+        else:                                      # frozen statistics with a graph: normalise by the running moments, keep y for backward
+            mean, invstd = bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
+            o = K.bn_apply(y, mean, invstd, gamma, beta, residual=rv, relu=relu, out=ov)
         ctx.group, ctx.has_bias, ctx.has_res = bn.group, bias is not None, residual is not None
         ctx.save_for_backward(xv, wk, y, o, mean, invstd, gamma, beta)
         return nchw(o)
 
     @staticmethod
     def backward(ctx, dout):
-        if not ctx.train:
-            raise NotImplementedError('backward through eval-mode (frozen-statistics) BatchNorm is not implemented in the HIP path')
         xv, wk, y, o, mean, invstd, gamma, beta = ctx.saved_tensors
         stride, pad, dil = ctx.geom
         dv = _grad_view(dout)
-        dy, dres, dgamma, dbeta = _bn_train_bwd(dv, o, y, mean, invstd, gamma, beta, ctx.relu, ctx.group, ctx.has_res and ctx.needs_input_grad[5], ctx.has_res)
+        want_dres = ctx.has_res and ctx.needs_input_grad[5]
+        if ctx.train:
+            dy, dres, dgamma, dbeta = _bn_train_bwd(dv, o, y, mean, invstd, gamma, beta, ctx.relu, ctx.group, want_dres, ctx.has_res)
+        else:
+            # frozen statistics (eval mode): xhat does not depend on the batch, so dy = g * gamma * invstd with g the ReLU-masked
+            # gradient; dgamma = sum(g * xhat), dbeta = sum(g) come from the same reduce pass as in training
+            c = y.shape[3]
+            mode = 0 if not ctx.relu else (1 if ctx.has_res else 2)
+            sums, g = K.bn_bwd_reduce(dv, o, y, mean, invstd, mode, gamma, beta, want_gmask=mode != 0)
+            g = dv if g is None else g
+            dy = K.scale_shift_act(g, gamma * invstd, torch.zeros_like(gamma))
+            dres, dgamma, dbeta = (g if want_dres else None), sums[c:], sums[:c]
         dx = nchw(K.conv_bwd_data(dy, wk, tuple(xv.shape), stride, pad, dil)) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
