@@ -33,6 +33,10 @@ typedef struct pm_conv_params { /* nn.Conv2d geometry (square kernels/strides as
   int32_t kh, kw, stride, pad, dil;
   int32_t prec;                 /* 0: fp32 MFMA (exact fp32 chain, parity path); 1: operands rounded to bf16 for
                                    v_mfma_f32_32x32x16_bf16, fp32 accumulate and storage (BASELINE configs[2]) */
+  void* wino_v;                 /* optional caller-owned buffer for the Winograd-transformed input of this convolution (NULL: none).
+                                   pm_conv_fwd writes it there instead of its workspace; pm_conv_bwd_weight then reads it instead of
+                                   transforming x again. Size from pm_conv_winograd_v_bytes (0 = the layer does not take the route). */
+  int64_t wino_v_bytes;
 } pm_conv_params;
 
 typedef struct pm_conv_epilogue { /* optional fused epilogue of pm_conv_fwd; all pointers may be NULL */
@@ -51,6 +55,7 @@ int pm_version(void);
  * Replaces nn.Conv2d forward/backward at Resnet.py:145-150,195,404,453-457; deepv3plus.py:72-81,87,398-424;
  * deepv2.py:44-51,138-151; memory.py:75,104.  y: [n,ho,wo,cout], x: [n,h,w,cin], cin % 4 == 0. */
 size_t pm_conv_workspace(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p, int which /*0 fwd,1 dgrad,2 wgrad*/);
+size_t pm_conv_winograd_v_bytes(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p);
 int pm_conv_fwd(const pm_tensor* x, const float* w_krsc, const pm_tensor* y, const pm_conv_params* p,
                 const pm_conv_epilogue* ep, void* ws, size_t ws_bytes, void* stream);
 /* dx = dgrad(dy) [+ add]: `add` (nullable, same shape as dx) fuses the sum with a second gradient path, e.g. the

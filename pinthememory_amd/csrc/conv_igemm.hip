@@ -932,8 +932,8 @@ WinoPlan wino_plan(const pm_tensor* xin, int cout, const pm_conv_params* p, bool
 inline size_t wino_ws(const WinoPlan& wp) { return wp.v_bytes + wp.m_bytes + wp.u_bytes; }
 
 int wino_conv(const pm_tensor* xin, const float* w, int w_cout, int w_cin, bool dgrad, const pm_tensor* yout, const WinoPlan& wp,
-              const pm_conv_epilogue& ep, void* ws, hipStream_t st) {
-  float* V = (float*)ws;
+              const pm_conv_epilogue& ep, void* ws, hipStream_t st, float* v_keep = nullptr) {
+  float* V = v_keep ? v_keep : (float*)ws;   // forward of a training step: the transformed input is kept for the weight gradient
   float* Mo = (float*)((char*)ws + wp.v_bytes);
   float* U = (float*)((char*)ws + wp.v_bytes + wp.m_bytes);
   const int cout = yout->c;
@@ -973,12 +973,14 @@ WinoWgradPlan wino_wgrad_plan(const WinoPlan& wp, int cout) {
 }
 inline size_t wino_wgrad_ws(const WinoPlan& wp, const WinoWgradPlan& q) { return wp.v_bytes + wp.m_bytes + q.slab_bytes; }
 
-int wino_wgrad(const pm_tensor* x, const pm_tensor* dy, float* dw, const WinoPlan& wp, const WinoWgradPlan& q, void* ws, hipStream_t st) {
-  float* V = (float*)ws;
+int wino_wgrad(const pm_tensor* x, const pm_tensor* dy, float* dw, const WinoPlan& wp, const WinoWgradPlan& q, void* ws, hipStream_t st,
+               float* v_kept = nullptr) {
+  float* V = v_kept ? v_kept : (float*)ws;
   float* Z = (float*)((char*)ws + wp.v_bytes);
   float* slab = (float*)((char*)ws + wp.v_bytes + wp.m_bytes);
   const int cout = dy->c;
-  if (int e = pm_wino_input_xf((const float*)x->ptr, x->pitch, x->c, wp.Kp, wp.g, V, st)) return e;
+  if (!v_kept)
+    if (int e = pm_wino_input_xf((const float*)x->ptr, x->pitch, x->c, wp.Kp, wp.g, V, st)) return e;
   if (int e = pm_wino_dy_xf((const float*)dy->ptr, dy->pitch, cout, wp.g, Z, st)) return e;
   const pm_tensor xv = {V, 1, 1, (int32_t)wp.g.tiles, wp.Kp, wp.Kp};
   const pm_tensor zv = {Z, 1, 1, (int32_t)wp.g.tiles, cout, cout};
@@ -1048,6 +1050,12 @@ extern "C" int pm_profile_dump(const char* path) {
   return PM_OK;
 }
 
+extern "C" size_t pm_conv_winograd_v_bytes(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p) {
+  if (!x || !y || !p) return 0;
+  const WinoPlan f = wino_plan(x, y->c, p), g = wino_plan(x, y->c, p, true);   // forward and weight gradient both on the route
+  return (f.use && g.use && f.g.m == g.g.m) ? f.v_bytes : 0;
+}
+
 extern "C" size_t pm_conv_workspace(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p, int which) {
   if (which == MODE_DGRAD && p->stride == 2) {   // four parity classes: compact results + the largest split-K slab set
     size_t slab = 0, tmp = 0;
@@ -1085,7 +1093,8 @@ extern "C" int pm_conv_fwd(const pm_tensor* x, const float* w, const pm_tensor* 
     const WinoPlan wp = wino_plan(x, y->c, p);
     if (wp.use) {
       PM_REQUIRE(ws && ws_bytes >= wino_ws(wp), PM_EWORKSPACE, "conv_fwd(winograd): workspace %zu < %zu", ws_bytes, wino_ws(wp));
-      return wino_conv(x, w, y->c, x->c, false, y, wp, e1, ws, (hipStream_t)stream);
+      float* keep = (p->wino_v && (size_t)p->wino_v_bytes >= wp.v_bytes) ? (float*)p->wino_v : nullptr;
+      return wino_conv(x, w, y->c, x->c, false, y, wp, e1, ws, (hipStream_t)stream, keep);
     }
   }
   long M, Nn, K;
@@ -1204,7 +1213,8 @@ extern "C" int pm_conv_bwd_weight(const pm_tensor* x, const pm_tensor* dy, float
   const WinoPlan wp = wino_plan(x, dy->c, p, true);
   if (wp.use) {
     const WinoWgradPlan q = wino_wgrad_plan(wp, dy->c);
-    if (int e = wino_wgrad(x, dy, dw, wp, q, ws, (hipStream_t)stream)) return e;
+    float* kept = (p->wino_v && (size_t)p->wino_v_bytes >= wp.v_bytes) ? (float*)p->wino_v : nullptr;
+    if (int e = wino_wgrad(x, dy, dw, wp, q, ws, (hipStream_t)stream, kept)) return e;
     pl.ws_bytes = wino_wgrad_ws(wp, q);     // the bias partials follow the Winograd buffers
   }
   ConvK k;

@@ -2,6 +2,8 @@
 Every function enqueues on torch's current stream and returns torch tensors; no CPU fallback exists."""
 from ctypes import byref
 
+import os
+
 import torch
 
 from . import lib as L
@@ -39,7 +41,12 @@ def krsc(w):
     return v if v.is_contiguous() else v.contiguous()
 
 
-def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, residual=None, relu=False, out=None):
+KEEP_WINOGRAD_V = os.environ.get('PM_KEEP_V', '1') == '1'   # forward keeps the Winograd-transformed input for the weight gradient
+
+
+def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, residual=None, relu=False, out=None, keep_v=None):
+    """keep_v: a list; if this convolution and its weight gradient both take the Winograd route, the transformed input V is written
+    to a fresh tensor that is appended to the list (else None is appended) -- pass it to conv_bwd_weight(wino_v=...)."""
     cout, kh, kw, cin = w_krsc.shape
     n, h, w_, c = x.shape
     assert c == cin, 'conv: Cin mismatch %d vs %d' % (c, cin)
@@ -48,6 +55,12 @@ def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, res
     xd, yd = tdesc(x), tdesc(y)
     p = PmConvParams(kh, kw, stride, pad, dil, CONV_PREC)
     lib = _lib()
+    if keep_v is not None:
+        nbv = lib.pm_conv_winograd_v_bytes(byref(xd), byref(yd), byref(p)) if KEEP_WINOGRAD_V else 0
+        v = torch.empty(nbv // 4, dtype=torch.float32, device=x.device) if nbv else None
+        keep_v.append(v)
+        if v is not None:
+            p.wino_v, p.wino_v_bytes = v.data_ptr(), nbv
     nb = lib.pm_conv_workspace(byref(xd), byref(yd), byref(p), 0)
     ws = workspace(nb, x.device) if nb else None
     ep = None
@@ -71,12 +84,14 @@ def conv_bwd_data(dy, w_krsc, x_shape, stride, pad, dil, add=None):
     return dx
 
 
-def conv_bwd_weight(x, dy, w_shape_krsc, stride, pad, dil, want_bias=False):
+def conv_bwd_weight(x, dy, w_shape_krsc, stride, pad, dil, want_bias=False, wino_v=None):
     cout, kh, kw, cin = w_shape_krsc
     dw = torch.empty(w_shape_krsc, dtype=torch.float32, device=x.device)
     db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_bias else None
     xd, dyd = tdesc(x), tdesc(dy)
     p = PmConvParams(kh, kw, stride, pad, dil, CONV_PREC)
+    if wino_v is not None:       # Winograd-transformed x kept by conv_fwd(keep_v=...)
+        p.wino_v, p.wino_v_bytes = wino_v.data_ptr(), wino_v.numel() * 4
     lib = _lib()
     nb = lib.pm_conv_workspace(byref(xd), byref(dyd), byref(p), 2)
     ws = workspace(nb, x.device)

@@ -15,7 +15,8 @@ class PmTensor(ctypes.Structure):
 
 
 class PmConvParams(ctypes.Structure):
-    _fields_ = [('kh', c_int32), ('kw', c_int32), ('stride', c_int32), ('pad', c_int32), ('dil', c_int32), ('prec', c_int32)]
+    _fields_ = [('kh', c_int32), ('kw', c_int32), ('stride', c_int32), ('pad', c_int32), ('dil', c_int32), ('prec', c_int32),
+                ('wino_v', c_void_p), ('wino_v_bytes', c_int64)]
 
 
 class PmConvEpilogue(ctypes.Structure):
@@ -34,6 +35,7 @@ _vp, _sz, _i, _f, _i64 = c_void_p, c_size_t, c_int, c_float, c_int64
 SIGNATURES = {
     'pm_last_error': (c_char_p, []),
     'pm_version': (c_int, []),
+    'pm_conv_winograd_v_bytes': (_sz, [_T, _T, _P]),
     'pm_conv_workspace': (_sz, [_T, _T, _P, _i]),
     'pm_conv_fwd': (_i, [_T, _vp, _T, _P, _E, _vp, _sz, _vp]),
     'pm_conv_bwd_data': (_i, [_T, _vp, _T, _P, _T, _vp, _sz, _vp]),

@@ -114,15 +114,17 @@ def _w(weight):
     return (p, True) if p is not None else (weight, False)
 
 
-def _wgrad(x, dy, wshape, geom, want_bias=False, deferred=False):
+def _wgrad(x, dy, wshape, geom, want_bias=False, deferred=False, wino_v=None):
     if not deferred:
-        return K.conv_bwd_weight(x, dy, wshape, *geom, want_bias=want_bias)
+        return K.conv_bwd_weight(x, dy, wshape, *geom, want_bias=want_bias, wino_v=wino_v)
     side = _side_stream()
     ev = torch.cuda.Event()
     ev.record()
     with torch.cuda.stream(side):
         side.wait_event(ev)
-        out = K.conv_bwd_weight(x, dy, wshape, *geom, want_bias=want_bias)
+        out = K.conv_bwd_weight(x, dy, wshape, *geom, want_bias=want_bias, wino_v=wino_v)
+    if wino_v is not None:
+        wino_v.record_stream(side)
     x.record_stream(side)
     dy.record_stream(side)
     out[0].record_stream(torch.cuda.current_stream())
@@ -169,7 +171,8 @@ class _Bottleneck(torch.autograd.Function):
         k1, k2, k3 = K.krsc(w1), K.krsc(w2), K.krsc(w3)
         y1 = K.conv_fwd(xv, k1, *geoms[0])
         o1, m1, i1 = _bn_train_fwd(y1, g1, b1, bns[0], None, True)
-        y2 = K.conv_fwd(o1, k2, *geoms[1])
+        kv = []
+        y2 = K.conv_fwd(o1, k2, *geoms[1], keep_v=kv)      # Winograd layers keep the transformed input for the weight gradient
         o2, m2, i2 = _bn_train_fwd(y2, g2, b2, bns[1], None, True)
         y3 = K.conv_fwd(o2, k3, *geoms[2])
         if wd is not None:
@@ -181,19 +184,19 @@ class _Bottleneck(torch.autograd.Function):
             res = xv
         out, m3, i3 = _bn_train_fwd(y3, g3, b3, bns[2], res, True)
         ctx.geoms, ctx.groups, ctx.has_ds, ctx.deferred = geoms, [b.group for b in bns], wd is not None, deferred
-        ctx.save_for_backward(xv, k1, k2, k3, kd, y1, o1, y2, o2, y3, yd, out, m1, i1, m2, i2, m3, i3, md, idd, g1, g2, g3, gd, b1, b2, b3)
+        ctx.save_for_backward(xv, k1, k2, k3, kd, y1, o1, y2, o2, y3, yd, out, m1, i1, m2, i2, m3, i3, md, idd, g1, g2, g3, gd, b1, b2, b3, kv[0])
         return nchw(out)
 
     @staticmethod
     def backward(ctx, dout):
-        xv, k1, k2, k3, kd, y1, o1, y2, o2, y3, yd, out, m1, i1, m2, i2, m3, i3, md, idd, g1, g2, g3, gd, b1, b2, b3 = ctx.saved_tensors
+        xv, k1, k2, k3, kd, y1, o1, y2, o2, y3, yd, out, m1, i1, m2, i2, m3, i3, md, idd, g1, g2, g3, gd, b1, b2, b3, v2 = ctx.saved_tensors
         ge, gr, df = ctx.geoms, ctx.groups, ctx.deferred
         dv = _grad_view(dout)
         dy3, dres, dg3, db3 = _bn_train_bwd(dv, out, y3, m3, i3, g3, b3, True, gr[2], True, True)
         dw3, _ = _wgrad(o2, dy3, tuple(k3.shape), ge[2], deferred=df[2])
         do2 = K.conv_bwd_data(dy3, k3, tuple(o2.shape), *ge[2])
         dy2, _, dg2, db2 = _bn_train_bwd(do2, o2, y2, m2, i2, g2, b2, True, gr[1], False, False)
-        dw2, _ = _wgrad(o1, dy2, tuple(k2.shape), ge[1], deferred=df[1])
+        dw2, _ = _wgrad(o1, dy2, tuple(k2.shape), ge[1], deferred=df[1], wino_v=v2)
         do1 = K.conv_bwd_data(dy2, k2, tuple(o1.shape), *ge[1])
         dy1, _, dg1, db1 = _bn_train_bwd(do1, o1, y1, m1, i1, g1, b1, True, gr[0], False, False)
         dw1, _ = _wgrad(xv, dy1, tuple(k1.shape), ge[0], deferred=df[0])
@@ -225,19 +228,20 @@ class _ConvBnAct(torch.autograd.Function):
             scale, shift = K.bn_fold(gamma, beta, bn.running_mean, bn.running_var, bn.eps, bias)
             o = K.conv_fwd(xv, wk, stride, pad, dil, scale=scale, shift=shift, residual=rv, relu=relu, out=ov)
             return nchw(o)
-        y = K.conv_fwd(xv, wk, stride, pad, dil, bias=bias)
+        kv = []
+        y = K.conv_fwd(xv, wk, stride, pad, dil, bias=bias, keep_v=kv if ctx.needs_input_grad[1] else None)
         if bn.training:
             o, mean, invstd = _bn_train_fwd(y, gamma, beta, bn, rv, relu, ov)
         else:                                      # frozen statistics with a graph: normalise by the running moments, keep y for backward
             mean, invstd = bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
             o = K.bn_apply(y, mean, invstd, gamma, beta, residual=rv, relu=relu, out=ov)
         ctx.group, ctx.has_bias, ctx.has_res = bn.group, bias is not None, residual is not None
-        ctx.save_for_backward(xv, wk, y, o, mean, invstd, gamma, beta)
+        ctx.save_for_backward(xv, wk, y, o, mean, invstd, gamma, beta, kv[0] if kv else None)
         return nchw(o)
 
     @staticmethod
     def backward(ctx, dout):
-        xv, wk, y, o, mean, invstd, gamma, beta = ctx.saved_tensors
+        xv, wk, y, o, mean, invstd, gamma, beta, vk = ctx.saved_tensors
         stride, pad, dil = ctx.geom
         dv = _grad_view(dout)
         want_dres = ctx.has_res and ctx.needs_input_grad[5]
@@ -255,7 +259,7 @@ class _ConvBnAct(torch.autograd.Function):
         dx = nchw(K.conv_bwd_data(dy, wk, tuple(xv.shape), stride, pad, dil)) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dwk, db = _wgrad(xv, dy, tuple(wk.shape), (stride, pad, dil), want_bias=ctx.has_bias, deferred=ctx.deferred)
+            dwk, db = _wgrad(xv, dy, tuple(wk.shape), (stride, pad, dil), want_bias=ctx.has_bias, deferred=ctx.deferred, wino_v=vk)
             dw = dwk.permute(0, 3, 1, 2)
         return dx, dw, db, dgamma, dbeta, (nchw(dres) if dres is not None else None), None, None, None, None, None
 

@@ -111,6 +111,11 @@ def test_conv_winograd(K, case):
         try:
             y = K.conv_fwd(xg, wg, 1, d, d, bias=b.cuda(), out=buf[..., 32:32 + cout])
             dw, db = K.conv_bwd_weight(xg, dyg, tuple(wg.shape), 1, d, d, want_bias=True)
+            kv = []      # transformed input kept by the forward pass and handed to the weight gradient: the same bits
+            y_k = K.conv_fwd(xg, wg, 1, d, d, bias=b.cuda(), keep_v=kv)
+            dw_k, _ = K.conv_bwd_weight(xg, dyg, tuple(wg.shape), 1, d, d, want_bias=True, wino_v=kv[0])
+            assert torch.equal(y_k, y) and torch.equal(dw_k, dw)
+            assert (kv[0] is not None) == (wino != 0 and cin * cout >= 256 * 256), (wino, kv[0] is None)
             res[wino] = (nchw(y).clone(), nchw(K.conv_bwd_data(dyg, wg, tuple(xg.shape), 1, d, d, add=addg)), dw.permute(0, 3, 1, 2).cpu(), db.cpu())
         finally:
             K.set_winograd(True)
