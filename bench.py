@@ -152,8 +152,18 @@ def main():
             what = '%s, %dx%dx32 tile, %s K-state, %s LDS, %s; direct convolutions and the batched Winograd F(4x4,3x3) / F(2x2,3x3) GEMMs; FLOPs = 2*M*N*K executed' % (
                 ('forward', 'data gradient', 'weight gradient')[mode], bm, bn, ('wave-uniform', 'per-lane', 'per-lane looping')[km],
                 'double-buffered' if nst == 2 else 'single-stage', 'v_mfma_f32_32x32x16_bf16' if a.dtype == 'bf16' else 'v_mfma_f32_32x32x2_f32')
+            traffic, traffic_src = None, None      # HBM bytes per launch of that symbol, from the committed PMC passes of this command
+            try:
+                pj = os.path.join(ROOT, 'profiles', 'r01f_bench_1gpu_hbm_counters.json')
+                for kr in json.load(open(pj))['kernels']:
+                    if kr['kernel'].replace('void ', '').strip() == sym:
+                        traffic = round((kr['read_MB_per_launch'] + kr['write_MB_per_launch']) * 1e6)
+                        traffic_src = ('profiles/r01f_bench_1gpu_hbm_counters.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of '
+                                       'bench.py --steps 1 --warmup 1; read = 2 x FETCH_SIZE (gfx950), average over all launches of the symbol')
+            except (OSError, KeyError, ValueError):
+                pass
             roof = {'bound': 'mfma', 'kernel': '%s (%s)' % (sym, what), 'achieved': round(ach, 2),
-                    'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': None,
+                    'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_source': traffic_src,
                     'launches_per_step': n / prof_steps, 'avg_launch_ms': round(ms / n, 5), 'gflop_per_launch': round(fl / n / 1e9, 3),
                     'measured': '%d extra steps after the timed region, all launches serialised on one stream (in the timed region the weight '
                                 'gradients overlap on a side stream, which inflates every concurrent kernel\'s duration)' % prof_steps,
