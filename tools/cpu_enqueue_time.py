@@ -1,0 +1,25 @@
+"""GPU debug: host time to enqueue one agg train step vs its GPU time (is the step launch-bound anywhere?)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pinthememory_amd import harness, synth
+from pinthememory_amd.network import deepv3plus
+crit = torch.nn.CrossEntropyLoss(reduction='mean', ignore_index=255)
+net = synth.load_det_weights(deepv3plus.DeepR50V3PlusD(synth.model_args(gumbel_off=False), 19, crit, crit)).cuda()
+opt, sched = harness.make_optimizer(net)
+x, y = synth.make_batch(8, 768)
+x, y = x.cuda(), y.cuda()
+for _ in range(3):
+    harness.agg_train_step(net, opt, x, y, sched=sched)
+torch.cuda.synchronize()
+enq = []
+t0 = time.perf_counter()
+for _ in range(6):
+    a = time.perf_counter()
+    harness.agg_train_step(net, opt, x, y, sched=sched)
+    enq.append(time.perf_counter() - a)
+t_enq = time.perf_counter() - t0
+torch.cuda.synchronize()
+t_all = time.perf_counter() - t0
+print('host enqueue per step: %s ms' % ['%.1f' % (e * 1e3) for e in enq])
+print('enqueue total %.1f ms, wall incl. final sync %.1f ms -> %.1f ms/step; host is ahead of the GPU by %.1f ms at the end' % (t_enq * 1e3, t_all * 1e3, t_all / 6 * 1e3, (t_all - t_enq) * 1e3))
