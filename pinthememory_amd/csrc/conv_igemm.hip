@@ -757,7 +757,9 @@ Plan make_plan(int mode, long M, long Nn, long K) {
     const long tiles = (long)tiles_m * tiles_n;
     const double unit_us = 2.0 * (bm / 128.0) * (bn / 128.0) * (bm == 64 ? 1.08 : 1.0);
     const long ks_max = std::max<long>(1, std::min<long>(ksteps / 4, 512));
+    static const int force_ks = getenv("PM_FORCE_KS") ? atoi(getenv("PM_FORCE_KS")) : 0;
     for (long ks = 1; ks <= ks_max; ++ks) {
+      if (force_ks && mode != MODE_WGRAD && ks != force_ks && force_ks <= ks_max) continue;
       const long steps_per = (ksteps + ks - 1) / ks;
       if ((ksteps + steps_per - 1) / steps_per != ks) continue;
       const long blocks = tiles * ks;

@@ -20,80 +20,58 @@ __device__ __forceinline__ float dot4(const float4& a, const float4& b) { return
 // ---------------------------------------------------------------------------------------------------------------
 // read forward
 // ---------------------------------------------------------------------------------------------------------------
-template <int M_>
-__global__ __launch_bounds__(256) void mem_read_fwd_kernel(const float* __restrict__ x, long xp, long rows, const float* __restrict__ mem, int m_rt,
-                                                           const float* __restrict__ noise, float* __restrict__ qr, long qp, float* __restrict__ score,
-                                                           float* __restrict__ pm) {
-  const int M = M_ > 0 ? M_ : m_rt;
-  __shared__ __align__(16) float smem[MAXM * D];
-  for (int i = threadIdx.x; i < M * D / 4; i += 256) reinterpret_cast<float4*>(smem)[i] = reinterpret_cast<const float4*>(mem)[i];
+
+// softmax over ALL rows per slot column (memory.py:186). Two launches over an L2-resident [N][m]: (1) every block folds its 128 rows
+// into a per-column (max, sum exp) pair with the online-softmax merge, (2) every block merges all partials in block order (fixed,
+// deterministic) and normalises its rows. Thread = (column c < 32, row lane rl < 8).
+constexpr int CS_ROWS = 128;
+struct MaxSum {
+  float m, s;
+};
+__device__ __forceinline__ MaxSum cs_merge(MaxSum a, MaxSum b) {   // (max, sum of exp(v - max)) of the union
+  const float m = fmaxf(a.m, b.m);
+  MaxSum r;
+  r.m = m;
+  r.s = (a.m == -INFINITY ? 0.f : a.s * expf(a.m - m)) + (b.m == -INFINITY ? 0.f : b.s * expf(b.m - m));
+  return r;
+}
+__global__ __launch_bounds__(256) void mem_colsoftmax_partial_kernel(const float* __restrict__ score, const float* __restrict__ noise, long rows, int M,
+                                                                     float* __restrict__ part) {
+  __shared__ MaxSum red[8][32];
+  const int c = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const long r0 = (long)blockIdx.x * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
+  MaxSum acc = {-INFINITY, 0.f};
+  if (c < M)
+    for (long r = r0 + rl; r < r1; r += 8) {
+      const float v = score[r * M + c] + (noise ? noise[r * M + c] : 0.f);
+      acc = cs_merge(acc, MaxSum{v, 1.f});
+    }
+  red[rl][c] = acc;
   __syncthreads();
-  const int lane = threadIdx.x & 63;
-  for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * 4) {
-    const float4 v = PM_LD4(x + r * xp + lane * 4);
-    const float nrm = fmaxf(sqrtf(pm_wave_sum(dot4(v, v))), EPS);
-    const float4 q = make_float4(v.x / nrm, v.y / nrm, v.z / nrm, v.w / nrm);
-    float s[M_ > 0 ? M_ : MAXM];
+  if (rl == 0 && c < M) {
 #pragma unroll
-    for (int j = 0; j < (M_ > 0 ? M_ : MAXM); ++j)
-      if (j < M) s[j] = pm_wave_sum(dot4(q, reinterpret_cast<const float4*>(smem + j * D)[lane]));
-    if (lane < M) {
-      float mine = 0.f;
-#pragma unroll
-      for (int j = 0; j < (M_ > 0 ? M_ : MAXM); ++j)
-        if (j == lane) mine = s[j];
-      score[r * M + lane] = mine;
-    }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < (M_ > 0 ? M_ : MAXM); ++j)
-      if (j < M) {
-        if (noise) s[j] += noise[r * M + j];
-        mx = fmaxf(mx, s[j]);
-      }
-    float se = 0.f;
-#pragma unroll
-    for (int j = 0; j < (M_ > 0 ? M_ : MAXM); ++j)
-      if (j < M) s[j] = expf(s[j] - mx), se += s[j];
-    float4 agg = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int j = 0; j < (M_ > 0 ? M_ : MAXM); ++j)
-      if (j < M) {
-        s[j] = s[j] / se;
-        const float4 mv = reinterpret_cast<const float4*>(smem + j * D)[lane];
-        agg.x += s[j] * mv.x, agg.y += s[j] * mv.y, agg.z += s[j] * mv.z, agg.w += s[j] * mv.w;
-      }
-    if (lane < M) {
-      float mine = 0.f;
-#pragma unroll
-      for (int j = 0; j < (M_ > 0 ? M_ : MAXM); ++j)
-        if (j == lane) mine = s[j];
-      pm[r * M + lane] = mine;
-    }
-    PM_ST4(qr + r * qp + lane * 4, q);
-    PM_ST4(qr + r * qp + D + lane * 4, agg);
+    for (int i = 1; i < 8; ++i) acc = cs_merge(acc, red[i][c]);
+    part[((long)blockIdx.x * M + c) * 2] = acc.m;
+    part[((long)blockIdx.x * M + c) * 2 + 1] = acc.s;
   }
 }
-
-// softmax over ALL rows per slot column (memory.py:186); one block per column, three sweeps over an L2-resident [N][m]
-__global__ __launch_bounds__(256) void mem_colsoftmax_kernel(const float* __restrict__ score, const float* __restrict__ noise, long rows, int M,
-                                                             float* __restrict__ out) {
-  __shared__ float red[4];
-  const int j = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float mx = -INFINITY;
-  for (long r = threadIdx.x; r < rows; r += 256) mx = fmaxf(mx, score[r * M + j] + (noise ? noise[r * M + j] : 0.f));
-  mx = pm_wave_max(mx);
-  if (lane == 0) red[wv] = mx;
+__global__ __launch_bounds__(256) void mem_colsoftmax_apply_kernel(const float* __restrict__ score, const float* __restrict__ noise, long rows, int M,
+                                                                   const float* __restrict__ part, int nb, float* __restrict__ out) {
+  __shared__ MaxSum red[8][32];
+  const int c = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  MaxSum g = {-INFINITY, 0.f};
+  if (c < M) {   // row lane rl merges partials [rl * per, (rl + 1) * per): contiguous ranges keep the overall order fixed
+    const int per = (nb + 7) / 8;
+    for (int b = rl * per; b < min(nb, (rl + 1) * per); ++b) g = cs_merge(g, MaxSum{part[((long)b * M + c) * 2], part[((long)b * M + c) * 2 + 1]});
+  }
+  red[rl][c] = g;
   __syncthreads();
-  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  __syncthreads();
-  float se = 0.f;
-  for (long r = threadIdx.x; r < rows; r += 256) se += expf(score[r * M + j] + (noise ? noise[r * M + j] : 0.f) - mx);
-  se = pm_wave_sum(se);
-  if (lane == 0) red[wv] = se;
-  __syncthreads();
-  se = (red[0] + red[1]) + (red[2] + red[3]);
-  for (long r = threadIdx.x; r < rows; r += 256) out[r * M + j] = expf(score[r * M + j] + (noise ? noise[r * M + j] : 0.f) - mx) / se;
+  g = red[0][c];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) g = cs_merge(g, red[i][c]);
+  if (c >= M) return;
+  const long r0 = (long)blockIdx.x * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
+  for (long r = r0 + rl; r < r1; r += 8) out[r * M + c] = expf(score[r * M + c] + (noise ? noise[r * M + c] : 0.f) - g.m) / g.s;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -167,12 +145,21 @@ __global__ __launch_bounds__(256) void mem_read_bwd_kernel(const float* __restri
   }
 }
 
-__global__ void reduce_partials_kernel(const float* __restrict__ part, int nb, long n, float* __restrict__ out) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// out[i] = sum_b part[b][i]: 16 elements x 16 partial-lanes per block (lane z sums b = z, z + 16, ...; lanes combined in order)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nb, long n, float* __restrict__ out) {
+  __shared__ float red[16][16];
+  const int e = threadIdx.x & 15, z = threadIdx.x >> 4;
+  const long i = (long)blockIdx.x * 16 + e;
   float s = 0.f;
-  for (int b = 0; b < nb; ++b) s += part[(long)b * n + i];
-  out[i] = s;
+  if (i < n)
+    for (int b = z; b < nb; b += 16) s += part[(long)b * n + i];
+  red[z][e] = s;
+  __syncthreads();
+  if (z == 0 && i < n) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += red[k][e];
+    out[i] = s;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -210,14 +197,24 @@ __global__ __launch_bounds__(256) void mem_write_accum_kernel(const float* __res
   float* mine = sacc + wv * slab;
   for (int i = lane; i < slab; i += 64) mine[i] = 0.f;
   const long rows = (long)n * h * w;
-  for (long r = (long)blockIdx.x * ACC_W + wv; r < rows; r += (long)gridDim.x * ACC_W) {
-    const int x = (int)(r % w), y = (int)((r / w) % h), b = (int)(r / ((long)w * h));
-    float4 v = PM_LD4(z + r * zp + lane * 4);
+  const long stride = (long)gridDim.x * ACC_W;
+  long r = (long)blockIdx.x * ACC_W + wv;
+  auto fetch = [&](long rr, float4& v, Taps& t) {
+    v = PM_LD4(z + rr * zp + lane * 4);
+    t = soft_label_taps(lab, (int)(rr / ((long)w * h)), (int)((rr / w) % h), (int)(rr % w), H, W, h, w, sy, sx, m);
+  };
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  Taps t{};
+  if (r < rows) fetch(r, v, t);
+  while (r < rows) {   // the next row's feature vector and label taps are in flight while this one is accumulated
+    const long rn = r + stride;
+    float4 vn = v;
+    Taps tn = t;
+    if (rn < rows) fetch(rn, vn, tn);
     if (normalize) {
       const float nrm = fmaxf(sqrtf(pm_wave_sum(dot4(v, v))), EPS);
       v = make_float4(v.x / nrm, v.y / nrm, v.z / nrm, v.w / nrm);
     }
-    const Taps t = soft_label_taps(lab, b, y, x, H, W, h, w, sy, sx, m);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (t.cls[k] < 0 || t.w[k] == 0.f) continue;   // wave-uniform
@@ -227,6 +224,7 @@ __global__ __launch_bounds__(256) void mem_write_accum_kernel(const float* __res
       *a = c;
       if (lane == 0) mine[(m + 1) * D + t.cls[k]] += t.w[k];
     }
+    v = vn, t = tn, r = rn;
   }
   __syncthreads();
   const int nout = (m + 1) * D + (m + 1);
@@ -304,8 +302,122 @@ __global__ __launch_bounds__(256) void mem_write_update_bwd_kernel(const float* 
   if (dmem_in) dmem_in[j * D + c] = den != 0.f ? du * mu : du;
 }
 
+// Memory read on the matrix cores. One wave owns 32 query rows: S = X M^T (32 x 256 . 256 x 32, slots padded to 32) with the rows
+// streamed straight from global memory into MFMA operand registers (lane = (row, k-half): float4 pieces of its own row, which also
+// gives ||x||^2 with one cross-lane add), the 32 x 32 score tile transposed through LDS so that every lane holds its row's slots for
+// the softmax, then  agg = P M  (32 x 32 . 32 x 256) again on the MFMA with P fed from registers. ~220 MFMAs per 32 rows instead of
+// 20 six-step wave reductions per row; the slots live in LDS for the whole block.
+typedef float mr_f32x16 __attribute__((ext_vector_type(16)));
+template <int M_>
+__global__ __launch_bounds__(256) void mem_read_fwd_mfma_kernel(const float* __restrict__ x, long xp, long rows, const float* __restrict__ mem, int m_rt,
+                                                                const float* __restrict__ noise, float* __restrict__ qr, long qp,
+                                                                float* __restrict__ score, float* __restrict__ pm) {
+  constexpr int LDK = D + 4;
+  const int M = M_ > 0 ? M_ : m_rt;
+  __shared__ __align__(16) float Ms[MAXM * LDK];   // slot-major, rows >= M are zero
+  __shared__ float Ss[4][32][33];
+  __shared__ float Nr[4][32];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, half = lane >> 5;
+  for (int i = t; i < MAXM * (D / 4); i += 256) {
+    const int r = i / (D / 4), c4 = i - r * (D / 4);
+    *reinterpret_cast<float4*>(Ms + r * LDK + c4 * 4) = r < M ? PM_LD4(mem + (long)r * D + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  for (long base = (long)blockIdx.x * 128; base < rows; base += (long)gridDim.x * 128) {   // uniform trip count per block
+    const long row0 = base + wave * 32;
+    const long myrow = min(row0 + l31, rows - 1);          // rows past the end are computed on the last row and never stored
+    const float* xr = x + myrow * xp + 4 * half;
+    mr_f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    float n2 = 0.f;
+#pragma unroll 16
+    for (int g = 0; g < D / 8; ++g) {
+      const float4 a = PM_LD4(xr + 8 * g);
+      n2 += dot4(a, a);
+      const float4 b = *reinterpret_cast<const float4*>(Ms + l31 * LDK + 8 * g + 4 * half);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+    n2 += __shfl_xor(n2, 32, 64);
+    const float nrm = fmaxf(sqrtf(n2), EPS);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Ss[wave][(q & 3) + 8 * (q >> 2) + 4 * half][l31] = acc[q];   // acc[q]: row from (q, half), slot = lane % 32
+    if (half == 0) Nr[wave][l31] = nrm;
+    __syncthreads();
+    // this lane's row: cosine scores and softmax over the slots (the two half-lanes of a row do the same work)
+    float pr[MAXM];
+    const bool mine = half == 0 && row0 + l31 < rows;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < (M_ > 0 ? M_ : MAXM); ++j)
+      if (j < M) {
+        float sv = Ss[wave][l31][j] / nrm;
+        if (mine) score[myrow * M + j] = sv;
+        if (noise) sv += noise[myrow * M + j];
+        pr[j] = sv;
+        mx = fmaxf(mx, sv);
+      }
+    float se = 0.f;
+#pragma unroll
+    for (int j = 0; j < (M_ > 0 ? M_ : MAXM); ++j)
+      if (j < M) pr[j] = expf(pr[j] - mx), se += pr[j];
+#pragma unroll
+    for (int j = 0; j < MAXM; ++j) {
+      if (j < (M_ > 0 ? M_ : MAXM) && j < M) {
+        pr[j] = pr[j] / se;
+        if (mine) pm[myrow * M + j] = pr[j];
+      } else {
+        pr[j] = 0.f;
+      }
+    }
+    // agg = P M, 128 channels per pass
+    constexpr int KG = ((M_ > 0 ? M_ : MAXM) + 7) / 8;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      mr_f32x16 ag[4];
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) ag[n][q] = 0.f;
+#pragma unroll
+      for (int g = 0; g < KG; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a = half ? pr[(8 * g + 4 + j) & (MAXM - 1)] : pr[8 * g + j];
+          const float* bp = Ms + (8 * g + 4 * half + j) * LDK + pass * 128 + l31;
+#pragma unroll
+          for (int n = 0; n < 4; ++n) ag[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[n * 32], ag[n], 0, 0, 0);
+        }
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const long r = row0 + (q & 3) + 8 * (q >> 2) + 4 * half;
+          if (r < rows) qr[r * qp + D + pass * 128 + n * 32 + l31] = ag[n][q];
+        }
+    }
+    // qhat = x / ||x||, one row (1 KB) per wave instruction
+#pragma unroll
+    for (int it0 = 0; it0 < 32; it0 += 8) {   // 8 independent row loads in flight
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = PM_LD4(x + min(row0 + it0 + u, rows - 1) * xp + lane * 4);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long r = row0 + it0 + u;
+        const float nr = Nr[wave][it0 + u];
+        if (r < rows) PM_ST4(qr + r * qp + lane * 4, make_float4(v[u].x / nr, v[u].y / nr, v[u].z / nr, v[u].w / nr));
+      }
+    }
+    __syncthreads();
+  }
+}
+
 inline int row_blocks(long rows) { return (int)std::min<long>((rows + 3) / 4, 256 * 8); }
-inline int accum_blocks(long rows) { return (int)std::min<long>((rows + 63) / 64, 128); }
+inline int accum_blocks(long rows) { return (int)std::min<long>((rows + 15) / 16, 256); }   // one block (4 wave slabs in LDS) per CU
 
 }  // namespace
 
@@ -316,19 +428,23 @@ extern "C" int pm_mem_read_fwd(const pm_tensor* x, const float* mem, int m, cons
   PM_REQUIRE(m >= 1 && m <= MAXM && pm_pixels(x) == pm_pixels(qr), PM_EINVAL, "mem_read_fwd: bad slots/rows");
   const long rows = pm_pixels(x);
   hipStream_t st = (hipStream_t)stream;
+  const int nb = (int)std::min<long>((rows + 127) / 128, 256 * 3);
   if (m == 19)
-    hipLaunchKernelGGL(mem_read_fwd_kernel<19>, dim3(row_blocks(rows)), dim3(256), 0, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, noise,
-                       (float*)qr->ptr, (long)qr->pitch, score, p_mem);
+    hipLaunchKernelGGL(mem_read_fwd_mfma_kernel<19>, dim3(nb), dim3(256), 0, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, noise, (float*)qr->ptr,
+                       (long)qr->pitch, score, p_mem);
   else
-    hipLaunchKernelGGL(mem_read_fwd_kernel<0>, dim3(row_blocks(rows)), dim3(256), 0, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, noise,
-                       (float*)qr->ptr, (long)qr->pitch, score, p_mem);
+    hipLaunchKernelGGL(mem_read_fwd_mfma_kernel<0>, dim3(nb), dim3(256), 0, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, noise, (float*)qr->ptr,
+                       (long)qr->pitch, score, p_mem);
   return pm_check_launch("mem_read_fwd");
 }
 
-extern "C" size_t pm_mem_colsoftmax_workspace(int64_t, int) { return 0; }
-extern "C" int pm_mem_colsoftmax(const float* score, const float* noise, int64_t rows, int m, float* p_query, void*, size_t, void* stream) {
-  PM_REQUIRE(score && p_query && rows > 0 && m >= 1, PM_EINVAL, "mem_colsoftmax: bad args");
-  hipLaunchKernelGGL(mem_colsoftmax_kernel, dim3(m), dim3(256), 0, (hipStream_t)stream, score, noise, (long)rows, m, p_query);
+extern "C" size_t pm_mem_colsoftmax_workspace(int64_t rows, int m) { return pm_align_up((size_t)pm_cdiv(rows, CS_ROWS) * m * 2 * sizeof(float), 256); }
+extern "C" int pm_mem_colsoftmax(const float* score, const float* noise, int64_t rows, int m, float* p_query, void* ws, size_t ws_bytes, void* stream) {
+  PM_REQUIRE(score && p_query && rows > 0 && m >= 1 && m <= MAXM, PM_EINVAL, "mem_colsoftmax: bad args");
+  PM_REQUIRE(ws && ws_bytes >= pm_mem_colsoftmax_workspace(rows, m), PM_EWORKSPACE, "mem_colsoftmax: workspace too small");
+  const int nb = pm_cdiv(rows, CS_ROWS);
+  hipLaunchKernelGGL(mem_colsoftmax_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, score, noise, (long)rows, m, (float*)ws);
+  hipLaunchKernelGGL(mem_colsoftmax_apply_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, score, noise, (long)rows, m, (const float*)ws, nb, p_query);
   return pm_check_launch("mem_colsoftmax");
 }
 
@@ -351,7 +467,7 @@ extern "C" int pm_mem_read_bwd(const pm_tensor* x, const float* mem, int m, cons
       hipLaunchKernelGGL((mem_read_bwd_kernel<0, true>), dim3(nb), dim3(256), 0, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, p_mem,
                          (const float*)dqr->ptr, (long)dqr->pitch, dsx, (float*)dx->ptr, (long)dx->pitch, (float*)ws);
     const long n = (long)m * D;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(pm_cdiv(n, 256)), dim3(256), 0, st, (const float*)ws, nb, n, dmem);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(pm_cdiv(n, 16)), dim3(256), 0, st, (const float*)ws, nb, n, dmem);
   } else {
     if (m == 19)
       hipLaunchKernelGGL((mem_read_bwd_kernel<19, false>), dim3(nb), dim3(256), 0, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, p_mem,
@@ -383,7 +499,7 @@ extern "C" int pm_mem_write_accum(const pm_tensor* z, const int64_t* labels, int
   hipLaunchKernelGGL(mem_write_accum_kernel, dim3(nb), dim3(256), lds, st, (const float*)z->ptr, (long)z->pitch, z->n, z->h, z->w, labels, H, W, m, normalize,
                      pm_ac_scale(H, z->h), pm_ac_scale(W, z->w), (float*)ws);
   const long n = (long)(m + 1) * (D + 1);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(pm_cdiv(n, 256)), dim3(256), 0, st, (const float*)ws, nb, n, nomden);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(pm_cdiv(n, 16)), dim3(256), 0, st, (const float*)ws, nb, n, nomden);
   return pm_check_launch("mem_write_accum");
 }
 

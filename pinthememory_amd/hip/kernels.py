@@ -339,7 +339,10 @@ def mem_read_fwd(x, mem, noise=None):
 def mem_colsoftmax(score, noise=None):
     rows, m = score.shape
     out = torch.empty_like(score)
-    check(_lib().pm_mem_colsoftmax(score.data_ptr(), ptr(noise), rows, m, out.data_ptr(), None, 0, stream()), 'pm_mem_colsoftmax')
+    lib = _lib()
+    nb = lib.pm_mem_colsoftmax_workspace(rows, m)
+    ws = workspace(nb, score.device)
+    check(lib.pm_mem_colsoftmax(score.data_ptr(), ptr(noise), rows, m, out.data_ptr(), ptr(ws), nb, stream()), 'pm_mem_colsoftmax')
     return out
 
 
