@@ -107,7 +107,7 @@ __device__ __forceinline__ float tap_weight(const pm_lerp& l, int i) { return (l
 // segment's support computes softmax - onehot (0 for ignored pixels) into LDS. Phase B: one thread per (low-res column, class) sums
 // its supporting hi-res columns in ascending order.
 template <int C_>
-__global__ __launch_bounds__(256) void ce_bwd_rows_kernel(const CEGeom g, int XW, float* __restrict__ T) {
+__global__ __launch_bounds__(256) void ce_bwd_rows_kernel(const CEGeom g, int XW, int max_nx, int max_nl, float* __restrict__ T) {
   extern __shared__ float G[];
   const int C = C_ > 0 ? C_ : g.C;
   const int CP = C | 1;   // odd pitch: conflict-free LDS rows
@@ -118,23 +118,40 @@ __global__ __launch_bounds__(256) void ce_bwd_rows_kernel(const CEGeom g, int XW
   support(g.sx, x1 - 1, g.W, tmp, Xhi);
   const int nX = Xhi - Xlo + 1;
   const pm_lerp ly = pm_ac_lerp(g.sy, Y, g.h);
+  // the two low-res logit rows this hi-res row interpolates between, columns [xa, xb], staged once (coalesced) and pre-scaled by 1/T:
+  // the per-pixel gathers below then hit LDS instead of issuing 4 x C scattered global loads per thread
+  const int xa = pm_ac_lerp(g.sx, Xlo, g.w).i0, xb = pm_ac_lerp(g.sx, Xhi, g.w).i1;
+  const int nL = xb - xa + 1;
+  float* L0 = G + (size_t)max_nx * CP;
+  float* L1 = L0 + (size_t)nL * CP;
+  float* TW = G + ((size_t)max_nx + 2 * (size_t)max_nl) * CP;   // per hi-res column: low-res index i0 (as float), weights w0, w1
+  for (int i = threadIdx.x; i < nL * C; i += 256) {
+    const int xl = i / C, c = i - xl * C;
+    L0[xl * CP + c] = g.logits[((long)(b * g.h + ly.i0) * g.w + xa + xl) * g.lp + c] * g.inv_temp;
+    L1[xl * CP + c] = g.logits[((long)(b * g.h + ly.i1) * g.w + xa + xl) * g.lp + c] * g.inv_temp;
+  }
+  __syncthreads();
   for (int j = threadIdx.x; j < nX; j += 256) {
     const int X = Xlo + j;
     const int64_t lab = g.labels[((long)b * g.H + Y) * g.W + X];
     float* out = G + j * CP;
+    const pm_lerp lx = pm_ac_lerp(g.sx, X, g.w);
+    TW[3 * j] = (float)lx.i0, TW[3 * j + 1] = lx.i1 == lx.i0 ? lx.w0 + lx.w1 : lx.w0, TW[3 * j + 2] = lx.i1 == lx.i0 ? 0.f : lx.w1;
     if (lab == 255) {
 #pragma unroll
       for (int c = 0; c < (C_ > 0 ? C_ : MAXC); ++c)
         if (c < C) out[c] = 0.f;
       continue;
     }
-    const pm_lerp lx = pm_ac_lerp(g.sx, X, g.w);
+    const float *p00 = L0 + (lx.i0 - xa) * CP, *p01 = L0 + (lx.i1 - xa) * CP, *p10 = L1 + (lx.i0 - xa) * CP, *p11 = L1 + (lx.i1 - xa) * CP;
     float v[C_ > 0 ? C_ : MAXC];
-    interp_logits<C_>(g, b, ly, lx, v);
     float mx = -INFINITY;
 #pragma unroll
     for (int c = 0; c < (C_ > 0 ? C_ : MAXC); ++c)
-      if (c < C) mx = fmaxf(mx, v[c]);
+      if (c < C) {
+        v[c] = ly.w0 * (lx.w0 * p00[c] + lx.w1 * p01[c]) + ly.w1 * (lx.w0 * p10[c] + lx.w1 * p11[c]);   // same expression as interp_logits
+        mx = fmaxf(mx, v[c]);
+      }
     float se = 0.f;
 #pragma unroll
     for (int c = 0; c < (C_ > 0 ? C_ : MAXC); ++c)
@@ -151,7 +168,11 @@ __global__ __launch_bounds__(256) void ce_bwd_rows_kernel(const CEGeom g, int XW
     int lo, hi;
     support(g.sx, x, g.W, lo, hi);
     float acc = 0.f;
-    for (int X = lo; X <= hi; ++X) acc += tap_weight(pm_ac_lerp(g.sx, X, g.w), x) * G[(X - Xlo) * CP + c];
+    for (int X = lo; X <= hi; ++X) {   // tap weight of hi-res column X on low-res column x, from the table built in phase A
+      const int j = X - Xlo, i0 = (int)TW[3 * j];
+      const float wgt = (i0 == x ? TW[3 * j + 1] : 0.f) + (i0 + 1 == x ? TW[3 * j + 2] : 0.f);
+      acc += wgt * G[j * CP + c];
+    }
     T[(((long)b * g.H + Y) * g.w + x) * C + c] = acc;
   }
 }
@@ -188,7 +209,7 @@ inline int bwd_seg(const CEGeom& g, int& max_nx) {
       support(g.sx, std::min(g.w, x0 + xw) - 1, g.W, tmp, hi);
       max_nx = std::max(max_nx, hi - lo + 1);
     }
-    if ((size_t)max_nx * cp * sizeof(float) <= 60 * 1024 || xw == 1) return xw;
+    if ((((size_t)max_nx + 2 * (size_t)(xw + 3)) * cp + 3 * (size_t)max_nx) * sizeof(float) <= 60 * 1024 || xw == 1) return xw;
     xw = std::max(1, xw / 2);
   }
 }
@@ -235,12 +256,21 @@ extern "C" int pm_upsample_ce_bwd(const pm_tensor* logits, float inv_temp, const
   PM_REQUIRE(H <= 65535 && g.n <= 65535, PM_EUNSUPPORTED, "upsample_ce_bwd: H or batch > 65535");
   int max_nx = 0;
   const int xw = bwd_seg(g, max_nx);
-  const size_t lds = (size_t)max_nx * (g.C | 1) * sizeof(float);
+  int max_nl = 0;   // widest low-res column range one segment interpolates from (same index math as pm_ac_lerp)
+  auto lo_i0 = [&](int X) { return std::min((int)(g.sx * (float)X), g.w - 1); };
+  for (int x0 = 0; x0 < g.w; x0 += xw) {
+    int lo, hi, tmp;
+    support(g.sx, x0, g.W, lo, tmp);
+    support(g.sx, std::min(g.w, x0 + xw) - 1, g.W, tmp, hi);
+    const int xa = lo_i0(lo), xb = std::min(lo_i0(hi) + 1, g.w - 1);
+    max_nl = std::max(max_nl, xb - xa + 1);
+  }
+  const size_t lds = (((size_t)max_nx + 2 * (size_t)max_nl) * (g.C | 1) + 3 * (size_t)max_nx) * sizeof(float);
   PM_REQUIRE(lds <= 64 * 1024, PM_EUNSUPPORTED, "upsample_ce_bwd: one low-res column is supported by %d hi-res columns (LDS)", max_nx);
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(pm_cdiv(g.w, xw), H, g.n);
-  if (g.C == 19) hipLaunchKernelGGL(ce_bwd_rows_kernel<19>, grid, dim3(256), lds, st, g, xw, (float*)ws);
-  else hipLaunchKernelGGL(ce_bwd_rows_kernel<0>, grid, dim3(256), lds, st, g, xw, (float*)ws);
+  if (g.C == 19) hipLaunchKernelGGL(ce_bwd_rows_kernel<19>, grid, dim3(256), lds, st, g, xw, max_nx, max_nl, (float*)ws);
+  else hipLaunchKernelGGL(ce_bwd_rows_kernel<0>, grid, dim3(256), lds, st, g, xw, max_nx, max_nl, (float*)ws);
   const long total = (long)g.n * g.h * g.w * g.C;
   hipLaunchKernelGGL(ce_bwd_cols_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 1 << 20)), dim3(256), 0, st, g, (const float*)ws, loss_out, gscale,
                      (float*)dlogits->ptr, (long)dlogits->pitch);
