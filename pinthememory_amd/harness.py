@@ -47,6 +47,9 @@ def agg_train_step(net, opt, x, gts, aux_gts=None, sched=None, buckets=None, tru
     m = net.module if hasattr(net, 'module') else net
     net.train()
     mem_t = m.memory.m_items.clone().detach()
+    if x.is_cuda and x.shape[1] == 3:
+        # both forward passes of the step read the same batch: lay it out once as the stem's NHWC / 4-channel input
+        x = ops.nchw(K.nchw_to_nhwc(x.float(), c_pad=4))
     if buckets is not None:
         buckets.zero()
     else:
