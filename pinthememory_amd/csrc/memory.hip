@@ -1,7 +1,8 @@
 // K7/K8: the categorical memory of "Pin the Memory" (/root/reference/network/memory.py) -- HBM-bound row kernels.
 //   read   (memory.py:317-336 + get_score :167-189): qhat = x/max(|x|,1e-12); S = qhat.M^T; P = softmax_slots(S [+gumbel]);
-//          R = P.M; writes [qhat | R] (the 2d-channel input of memory.output), S and P. One wave per query row
-//          (d = 256 = 64 lanes x float4), the 19x256 memory lives in LDS, per-slot dot products reduced with wave shuffles.
+//          R = P.M; writes [qhat | R] (the 2d-channel input of memory.output), S and P. Forward: one wave per 32 query rows, both
+//          products as MFMA tiles against the 19x256 memory held in LDS (mem_read_fwd_mfma_kernel below); backward: one wave per row
+//          (d = 256 = 64 lanes x float4), per-slot dot products reduced with wave shuffles.
 //   write  (memory.py:206-239): 4-tap bilinear(align_corners) soft labels straight from the int64 mask (never the
 //          755 MB one-hot), class-masked accumulation of nominator[20][256] / denominator[20] in per-wave LDS slabs,
 //          fixed-order two-stage reduce; momentum update + renormalise with a device-side `den != 0` predicate
@@ -16,10 +17,6 @@ constexpr int MAXM = 32;   // max slots (+1 for the ignore class in write)
 constexpr float EPS = 1e-12f;
 
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
-
-// ---------------------------------------------------------------------------------------------------------------
-// read forward
-// ---------------------------------------------------------------------------------------------------------------
 
 // softmax over ALL rows per slot column (memory.py:186). Two launches over an L2-resident [N][m]: (1) every block folds its 128 rows
 // into a per-column (max, sum exp) pair with the online-softmax merge, (2) every block merges all partials in block order (fixed,
