@@ -85,8 +85,8 @@ enum { K_FAST = 0, K_MID = 1, K_SMALL = 2 };
 // PREC 0: operands stay fp32 -> v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 157 TF). PREC 1: the fp32 tiles staged in LDS are
 // rounded to bf16 (RNE, v_cvt_pk_bf16_f32) as the fragments are read -> v_mfma_f32_32x32x16_bf16 with fp32 accumulation (2.5 PF):
 // BASELINE configs[2]. Gathers, LDS layout and epilogue are shared; storage stays fp32.
-// NST: LDS stages. 2 = double-buffered (default). 1 = single buffer for short reductions (<= 16 K-steps: the 1x1 convolutions and the
-// Winograd GEMMs with <= 512 input channels), halving the LDS footprint so that three blocks share a CU and cover each other's load / store phases.
+// NST: LDS stages. 1 = single buffer for reductions of <= 64 K-steps (K <= 2048: every 1x1 convolution and Winograd GEMM of the
+// flagship), 2 = double-buffered beyond that. A single stage halves the LDS footprint so that three blocks share a CU and cover each other's load / store phases.
 template <int MODE, int BM, int BN, int WM, int WN, int KM, int PREC, int NST>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   constexpr bool A_KC = (MODE != MODE_WGRAD);  // A tile stored [BM][LDK] (k contiguous) else [BK][BM]
@@ -791,7 +791,7 @@ void launch_nst(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
 inline int nst1_max_steps() {
   static const int v = [] {
     const char* e = getenv("PM_NST1_STEPS");
-    return e ? atoi(e) : 16;
+    return e ? atoi(e) : 64;
   }();
   return v;
 }

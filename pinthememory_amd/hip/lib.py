@@ -7,7 +7,7 @@ from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_int32, c_int64, c
 import torch
 
 _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_HERE, 'libpinmem_hip.so')
+LIB_PATH = os.environ.get('PM_LIB') or os.path.join(_HERE, 'libpinmem_hip.so')   # PM_LIB: A/B runs against another build of the library
 
 
 class PmTensor(ctypes.Structure):
