@@ -310,12 +310,16 @@ extern "C" int pm_global_avgpool_bwd(const pm_tensor* dy, const pm_tensor* dx, i
 
 extern "C" int pm_resize_bilinear_fwd(const pm_tensor* x, const pm_tensor* y, void* stream) {
   PM_REQUIRE(x && y && x->ptr && y->ptr && x->n == y->n && x->c == y->c, PM_EINVAL, "resize_fwd: bad args");
-  const bool v = pm_vec4(x) && pm_vec4(y);
-  const long total = pm_pixels(y) * (v ? y->c / 4 : y->c);
+  // channel counts that are not a multiple of 4 (the 19 class logits) on pitch-padded views: run the float4 path over the padded
+  // width -- the pad lanes of the input are zero (kernels.new), so the pad lanes of the output are written as zero
+  const int cv = (x->c + 3) & ~3;
+  const bool v = pm_vec_ok(x) && pm_vec_ok(y) && (x->c % 4 == 0 || (x->pitch == cv && y->pitch == cv));   // padded lanes only when they are the views' own
+  const int ceff = v ? cv : y->c;
+  const long total = pm_pixels(y) * (v ? ceff / 4 : ceff);
   const float sy = pm_ac_scale(x->h, y->h), sx = pm_ac_scale(x->w, y->w);
   if (v)
     hipLaunchKernelGGL(resize_fwd_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr, (long)x->pitch, x->h, x->w,
-                       (float*)y->ptr, (long)y->pitch, y->h, y->w, y->c, total, sy, sx);
+                       (float*)y->ptr, (long)y->pitch, y->h, y->w, ceff, total, sy, sx);
   else
     hipLaunchKernelGGL(resize_fwd_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr, (long)x->pitch, x->h, x->w,
                        (float*)y->ptr, (long)y->pitch, y->h, y->w, y->c, total, sy, sx);

@@ -22,12 +22,14 @@ def set_conv_precision(name):
     CONV_PREC = {'f32': 0, 'fp32': 0, 'bf16': 1}[name]
 
 
-def new(shape, like, pitch_pad=False):
-    """Fresh NHWC tensor. Channel counts that are not a multiple of 4 (the 19 logits) get a padded pitch so rows stay 16B aligned."""
+def new(shape, like, pitch_pad=False, zero_pad=True):
+    """Fresh NHWC tensor. Channel counts that are not a multiple of 4 (the 19 logits) get a padded pitch so rows stay 16B aligned;
+    the pad lanes are zero unless the producer writes them itself (zero_pad=False)."""
     n, h, w, c = shape
     if c % 4 and pitch_pad:
         cp = (c + 3) // 4 * 4
-        return torch.zeros((n, h, w, cp), dtype=torch.float32, device=like.device)[..., :c]
+        alloc = torch.zeros if zero_pad else torch.empty
+        return alloc((n, h, w, cp), dtype=torch.float32, device=like.device)[..., :c]
     return torch.empty((n, h, w, c), dtype=torch.float32, device=like.device)
 
 
@@ -228,7 +230,9 @@ def global_avgpool_bwd(dy, x_shape):
 
 def resize_fwd(x, size, out=None):
     n, h, w, c = x.shape
-    y = out if out is not None else new((n, size[0], size[1], c), x, pitch_pad=True)
+    # pitch-padded input (zero pad lanes) -> the float4 path writes the output's pad lanes too: no zero fill of a 358 MB tensor
+    own_pad = c % 4 != 0 and x.stride(2) == (c + 3) // 4 * 4
+    y = out if out is not None else new((n, size[0], size[1], c), x, pitch_pad=True, zero_pad=not own_pad)
     check(_lib().pm_resize_bilinear_fwd(byref(tdesc(x)), byref(tdesc(y)), stream()), 'pm_resize_bilinear_fwd')
     return y
 

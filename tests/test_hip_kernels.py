@@ -225,6 +225,10 @@ def test_pool_and_resize(K):
         xg.copy_(nhwc(x))
         y = K.resize_fwd(xg, size)
         assert rel(nchw(y), y_ref.detach()) < 2e-6, (shape, size)
+        if shape[1] % 4:      # pitch-padded 19-channel logits: float4 path over the padded width, pad lane written as zero
+            assert y.stride(2) == 20 and y.as_strided((y.shape[0], y.shape[1], y.shape[2], 20), y.stride())[..., 19].abs().max().item() == 0
+            xs = nhwc(x)      # unpadded (pitch 19) view of the same data takes the scalar path: same result
+            assert rel(K.resize_fwd(xs, size), y) < 1e-6
         dyg = K.new(tuple(y.shape), y, pitch_pad=True)
         dyg.copy_(nhwc(dy))
         dx = K.resize_bwd(dyg, tuple(xg.shape))
