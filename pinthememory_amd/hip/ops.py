@@ -39,7 +39,7 @@ def _grad_view(g):
 
 class BNState:
     """What the BN part of a fused op needs besides gamma/beta: the module's buffers and mode."""
-    __slots__ = ('running_mean', 'running_var', 'eps', 'momentum', 'training', 'group')
+    __slots__ = ('running_mean', 'running_var', 'eps', 'momentum', 'training', 'group', 'grad_enabled')
 
     def __init__(self, bn):
         self.running_mean, self.running_var = bn.running_mean, bn.running_var
@@ -48,6 +48,7 @@ class BNState:
         self.training = bn.training or bn.running_mean is None
         # nn.SyncBatchNorm (train.py:95 convert_sync_batchnorm) -> exchange statistics over RCCL
         self.group = D.bn_group(bn)
+        self.grad_enabled = torch.is_grad_enabled()      # the caller's mode: inside autograd.Function.forward it always reads False
         if bn.training and bn.num_batches_tracked is not None:
             _nbt_pending.append(bn.num_batches_tracked)
 
@@ -223,7 +224,7 @@ class _ConvBnAct(torch.autograd.Function):
         rv = nhwc(residual) if residual is not None else None
         ov = nhwc(out) if out is not None else None
         ctx.geom, ctx.relu, ctx.train, ctx.deferred = geom, relu, bn.training, deferred and bias is None
-        needs_grad = any(ctx.needs_input_grad[:6])   # grad mode is off inside forward(); this reflects the caller's graph
+        needs_grad = bn.grad_enabled and any(ctx.needs_input_grad[:6])   # needs_input_grad alone ignores torch.no_grad()
         if not bn.training and not needs_grad:     # inference: BN folded into the conv epilogue, nothing saved
             scale, shift = K.bn_fold(gamma, beta, bn.running_mean, bn.running_var, bn.eps, bias)
             o = K.conv_fwd(xv, wk, stride, pad, dil, scale=scale, shift=shift, residual=rv, relu=relu, out=ov)
