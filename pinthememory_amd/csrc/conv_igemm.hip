@@ -675,6 +675,32 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   __syncthreads();
   if (r == 0 && c < C) part[(long)blockIdx.x * C + c] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
 }
+// narrow tensors (pitch <= 64 floats, e.g. the 19 class logits at pitch 20): the rows are one contiguous stream of float4 groups;
+// thread = (group g of the row, row lane), so a wave reads 1 KB of consecutive memory per instruction instead of one 76 B row
+__global__ __launch_bounds__(256) void colsum_partial_narrow_kernel(const float* __restrict__ x, int p4, long P, int C, int rows_per_block,
+                                                                    float* __restrict__ part) {
+  __shared__ float4 sm[256];
+  const int RL = 256 / p4, t = threadIdx.x;
+  const int g = t % p4, rl = t / p4;
+  const long p0 = (long)blockIdx.x * rows_per_block, p1 = min(P, p0 + rows_per_block);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (rl < RL)
+    for (long p = p0 + rl; p < p1; p += RL) {
+      const float4 v = PM_LD4(x + (p * p4 + g) * 4);
+      s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+    }
+  sm[t] = s;
+  __syncthreads();
+  if (t < p4) {   // fixed-order sum over the row lanes of this group
+    for (int k = 1; k < RL; ++k) {
+      const float4 v = sm[k * p4 + t];
+      s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+    }
+    const float o[4] = {s.x, s.y, s.z, s.w};
+    for (int j = 0; j < 4; ++j)
+      if (t * 4 + j < C) part[(long)blockIdx.x * C + t * 4 + j] = o[j];
+  }
+}
 __global__ void colsum_final_kernel(const float* __restrict__ part, int nb, int C, float* __restrict__ out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
@@ -1238,7 +1264,10 @@ extern "C" int pm_conv_bwd_weight(const pm_tensor* x, const pm_tensor* dy, float
     const long P = pm_pixels(dy);
     const int nb = pm_cdiv(P, 2048);
     float* part = (float*)((char*)ws + pm_align_up(pl.ws_bytes, 256));
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb, pm_cdiv(dy->c, 64)), dim3(256), 0, st, (const float*)dy->ptr, (long)dy->pitch, P, dy->c, 2048, part);
+    if (dy->pitch == ((dy->c + 3) & ~3) && dy->pitch <= 64 && pm_aligned16(dy->ptr))   // the tensor's own (pad-to-4) rows, not a channel slice
+      hipLaunchKernelGGL(colsum_partial_narrow_kernel, dim3(nb), dim3(256), 0, st, (const float*)dy->ptr, (int)(dy->pitch / 4), P, dy->c, 2048, part);
+    else
+      hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb, pm_cdiv(dy->c, 64)), dim3(256), 0, st, (const float*)dy->ptr, (long)dy->pitch, P, dy->c, 2048, part);
     hipLaunchKernelGGL(colsum_final_kernel, dim3(pm_cdiv(dy->c, 64)), dim3(64), 0, st, (const float*)part, nb, dy->c, dbias);
     return pm_check_launch("conv_bias_grad");
   }

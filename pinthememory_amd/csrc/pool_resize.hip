@@ -50,6 +50,35 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
   }
 }
 
+// float4 variant (C % 4 == 0): thread = (input pixel, 4 channels); the argmax bytes of 4 channels come as one 32-bit load
+__global__ __launch_bounds__(256) void maxpool_bwd_vec_kernel(const float* __restrict__ dy, long dp, int Ho, int Wo, const uint8_t* __restrict__ arg,
+                                                              float* __restrict__ dx, long xp, int H, int W, int C, long total) {
+  const int cg = C >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long ip = i / cg;
+    const int ch = (int)(i - ip * cg) * 4;
+    const int ix = (int)(ip % W), iy = (int)((ip / W) % H), n = (int)(ip / ((long)W * H));
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int oy_hi = min((iy + 1) >> 1, Ho - 1), ox_hi = min((ix + 1) >> 1, Wo - 1);
+    for (int oy = iy >> 1; oy <= oy_hi; ++oy) {
+      const int ky = iy + 1 - 2 * oy;
+      if (ky < 0 || ky > 2) continue;
+      for (int ox = ix >> 1; ox <= ox_hi; ++ox) {
+        const int kx = ix + 1 - 2 * ox;
+        if (kx < 0 || kx > 2) continue;
+        const long op = (long)(n * Ho + oy) * Wo + ox;
+        const unsigned a = *reinterpret_cast<const unsigned*>(arg + op * C + ch), want = (unsigned)(ky * 3 + kx);
+        const float4 d = PM_LD4(dy + op * dp + ch);
+        g.x += (a & 255u) == want ? d.x : 0.f;
+        g.y += ((a >> 8) & 255u) == want ? d.y : 0.f;
+        g.z += ((a >> 16) & 255u) == want ? d.z : 0.f;
+        g.w += (a >> 24) == want ? d.w : 0.f;
+      }
+    }
+    PM_ST4(dx + ip * xp + ch, g);
+  }
+}
+
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, long dp, int Ho, int Wo, const uint8_t* __restrict__ arg,
                                                           float* __restrict__ dx, long xp, int H, int W, int C, long total) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -282,8 +311,12 @@ extern "C" int pm_maxpool3x3s2_fwd(const pm_tensor* x, const pm_tensor* y, uint8
 extern "C" int pm_maxpool3x3s2_bwd(const pm_tensor* dy, const uint8_t* argmax, const pm_tensor* dx, void* stream) {
   PM_REQUIRE(dy && dx && argmax && dy->ptr && dx->ptr && dy->n == dx->n && dy->c == dx->c, PM_EINVAL, "maxpool_bwd: bad args");
   const long total = pm_pixels(dx) * dx->c;
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)dy->ptr, (long)dy->pitch, dy->h, dy->w, argmax,
-                     (float*)dx->ptr, (long)dx->pitch, dx->h, dx->w, dx->c, total);
+  if (pm_vec4(dy) && pm_vec4(dx) && (reinterpret_cast<uintptr_t>(argmax) & 3u) == 0)
+    hipLaunchKernelGGL(maxpool_bwd_vec_kernel, dim3(grid_for(total / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)dy->ptr, (long)dy->pitch, dy->h, dy->w,
+                       argmax, (float*)dx->ptr, (long)dx->pitch, dx->h, dx->w, dx->c, total / 4);
+  else
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)dy->ptr, (long)dy->pitch, dy->h, dy->w, argmax,
+                       (float*)dx->ptr, (long)dx->pitch, dx->h, dx->w, dx->c, total);
   return pm_check_launch("maxpool_bwd");
 }
 
