@@ -108,11 +108,26 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ 
   const int g = threadIdx.x & 15, r = threadIdx.x >> 4;
   const int c = blockIdx.y * 64 + g * 4, n = blockIdx.x;
   float s[4] = {0, 0, 0, 0};
-  if (c < C)
-    for (long p = r; p < HW; p += 16) {
-      const float4 v = PM_LD4(x + ((long)n * HW + p) * xp + c);
-      s[0] += v.x, s[1] += v.y, s[2] += v.z, s[3] += v.w;
+  if (c < C) {   // four independent partial sums: four 16 B loads in flight per thread (one block per CU has little else to hide latency with)
+    float4 a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* base = x + (long)n * HW * xp + c;
+    long p = r;
+    for (; p + 48 < HW; p += 64) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float4 v = PM_LD4(base + (p + 16 * u) * xp);
+        a[u].x += v.x, a[u].y += v.y, a[u].z += v.z, a[u].w += v.w;
+      }
     }
+    for (; p < HW; p += 16) {
+      const float4 v = PM_LD4(base + p * xp);
+      a[0].x += v.x, a[0].y += v.y, a[0].z += v.z, a[0].w += v.w;
+    }
+    s[0] = (a[0].x + a[1].x) + (a[2].x + a[3].x), s[1] = (a[0].y + a[1].y) + (a[2].y + a[3].y);
+    s[2] = (a[0].z + a[1].z) + (a[2].z + a[3].z), s[3] = (a[0].w + a[1].w) + (a[2].w + a[3].w);
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) sm[r][g * 4 + j] = s[j];
   __syncthreads();
