@@ -662,6 +662,13 @@ int splitk_reduce(const float* ws, int ksplit, long M, long Nn, float* C, long c
   return pm_check_launch("splitk_reduce");
 }
 
+// pixel rows per block of the bias-gradient column sum: ~1024 blocks in flight, 64 ... 2048 rows each
+inline int colsum_rows(long P, int C) {
+  const long col_blocks = std::max<long>(1, (C + 63) / 64);
+  const long want = col_blocks == 1 ? 256 : std::max<long>(1, 1024 / col_blocks);   // the final pass walks the partials serially per channel
+  return (int)std::min<long>(2048, std::max<long>(64, (P + want - 1) / want));
+}
+
 // column sum of dy for the conv bias gradient: one block per 64 channels x pixel chunk, fixed-order second stage.
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, long pitch, long P, int C, int rows_per_block,
                                                              float* __restrict__ part) {
@@ -1098,7 +1105,7 @@ extern "C" size_t pm_conv_workspace(const pm_tensor* x, const pm_tensor* y, cons
     const WinoPlan wp = which == MODE_FWD ? wino_plan(x, y->c, p) : wino_plan(y, x->c, p);
     if (wp.use) return wino_ws(wp);
   }
-  const size_t bias_part = pm_align_up((size_t)pm_cdiv(pm_pixels(y), 2048) * y->c * sizeof(float), 256);
+  const size_t bias_part = pm_align_up((size_t)pm_cdiv(pm_pixels(y), colsum_rows(pm_pixels(y), y->c)) * y->c * sizeof(float), 256);
   if (which == MODE_WGRAD) {
     const WinoPlan wp = wino_plan(x, y->c, p, true);
     if (wp.use) return pm_align_up(wino_wgrad_ws(wp, wino_wgrad_plan(wp, y->c)), 256) + bias_part;
@@ -1106,7 +1113,7 @@ extern "C" size_t pm_conv_workspace(const pm_tensor* x, const pm_tensor* y, cons
   long M, Nn, K;
   gemm_dims(which, x, y, p, M, Nn, K);
   size_t b = make_plan(which, M, Nn, K).ws_bytes;
-  if (which == MODE_WGRAD) b += pm_align_up((size_t)pm_cdiv(pm_pixels(y), 2048) * y->c * sizeof(float), 256);  // bias partials
+  if (which == MODE_WGRAD) b += bias_part;
   return pm_align_up(b, 256);
 }
 
@@ -1262,12 +1269,12 @@ extern "C" int pm_conv_bwd_weight(const pm_tensor* x, const pm_tensor* dy, float
   }
   if (dbias) {
     const long P = pm_pixels(dy);
-    const int nb = pm_cdiv(P, 2048);
+    const int rpb = colsum_rows(P, dy->c), nb = pm_cdiv(P, rpb);
     float* part = (float*)((char*)ws + pm_align_up(pl.ws_bytes, 256));
     if (dy->pitch == ((dy->c + 3) & ~3) && dy->pitch <= 64 && pm_aligned16(dy->ptr))   // the tensor's own (pad-to-4) rows, not a channel slice
-      hipLaunchKernelGGL(colsum_partial_narrow_kernel, dim3(nb), dim3(256), 0, st, (const float*)dy->ptr, (int)(dy->pitch / 4), P, dy->c, 2048, part);
+      hipLaunchKernelGGL(colsum_partial_narrow_kernel, dim3(nb), dim3(256), 0, st, (const float*)dy->ptr, (int)(dy->pitch / 4), P, dy->c, rpb, part);
     else
-      hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb, pm_cdiv(dy->c, 64)), dim3(256), 0, st, (const float*)dy->ptr, (long)dy->pitch, P, dy->c, 2048, part);
+      hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb, pm_cdiv(dy->c, 64)), dim3(256), 0, st, (const float*)dy->ptr, (long)dy->pitch, P, dy->c, rpb, part);
     hipLaunchKernelGGL(colsum_final_kernel, dim3(pm_cdiv(dy->c, 64)), dim3(64), 0, st, (const float*)part, nb, dy->c, dbias);
     return pm_check_launch("conv_bias_grad");
   }
