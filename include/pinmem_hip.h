@@ -111,6 +111,9 @@ int pm_bn_fold(const float* gamma, const float* beta, const float* running_mean,
 /* eval-mode / frozen-stat backward helper and plain elementwise ops */
 int pm_relu_bwd(const pm_tensor* dy, const pm_tensor* y, const pm_tensor* dx, void* stream);
 int pm_add(const pm_tensor* a, const pm_tensor* b, const pm_tensor* y, void* stream);
+/* y = xs[0] + ... + xs[n-1], 2 <= n <= 8, one pass (gradient accumulation of a multi-consumer tensor, e.g. the ASPP input,
+ * deepv3plus.py:72-95: autograd would chain n-1 two-operand adds) */
+int pm_add_n(const pm_tensor* const* xs, int n, const pm_tensor* y, void* stream);
 int pm_copy(const pm_tensor* src, const pm_tensor* dst, void* stream);
 int pm_scale_shift_act(const pm_tensor* x, const float* scale, const float* shift, const pm_tensor* residual, int relu,
                        const pm_tensor* y, void* stream);

@@ -50,6 +50,32 @@ extern "C" int pm_add(const pm_tensor* x, const pm_tensor* y, const pm_tensor* o
                    [=] __device__(long p, int ch) { po[p * c + ch] = px[p * a + ch] + py[p * b + ch]; });
 }
 
+// o = x[0] + x[1] + ... + x[n-1] (2 <= n <= 8, same shapes, float4 views), summed left to right in one pass: the gradient of a
+// tensor with several consumers (the ASPP input feeds five branches) without a chain of two-operand adds
+struct AddN {
+  const float* p[8];
+  long pitch[8];
+};
+extern "C" int pm_add_n(const pm_tensor* const* xs, int n, const pm_tensor* o, void* stream) {
+  PM_REQUIRE(xs && o && n >= 2 && n <= 8, PM_EINVAL, "add_n: 2..8 operands");
+  AddN a;
+  for (int i = 0; i < n; ++i) {
+    PM_REQUIRE(xs[i] && same_shape(xs[i], o) && vec4(xs[i]), PM_EINVAL, "add_n: operand %d: shape / float4 view mismatch", i);
+    a.p[i] = (const float*)xs[i]->ptr, a.pitch[i] = xs[i]->pitch;
+  }
+  PM_REQUIRE(vec4(o), PM_EINVAL, "add_n: output must be a float4 view");
+  float* po = (float*)o->ptr;
+  const long c = o->pitch;
+  return ew_launch(true, pm_pixels(o), o->c, (hipStream_t)stream, "add_n", [=] __device__(long p, int ch) {
+    float4 s = LD4(a.p[0] + p * a.pitch[0] + ch);
+    for (int i = 1; i < n; ++i) {
+      const float4 v = LD4(a.p[i] + p * a.pitch[i] + ch);
+      s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+    }
+    ST4(po + p * c + ch, s);
+  });
+}
+
 extern "C" int pm_copy(const pm_tensor* x, const pm_tensor* o, void* stream) {
   PM_REQUIRE(x && o && same_shape(x, o), PM_EINVAL, "copy: shape mismatch");
   const float* px = (const float*)x->ptr;

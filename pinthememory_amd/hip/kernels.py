@@ -189,6 +189,17 @@ def relu_bwd(dy, y):
     return dx
 
 
+def add_n(xs):
+    """Sum of 2..8 same-shape NHWC tensors in one pass."""
+    from .lib import PmTensor
+    from ctypes import POINTER, pointer
+    descs = [tdesc(x) for x in xs]
+    arr = (POINTER(PmTensor) * len(xs))(*[pointer(d) for d in descs])
+    y = torch.empty(xs[0].shape, dtype=torch.float32, device=xs[0].device)
+    check(_lib().pm_add_n(arr, len(xs), byref(tdesc(y)), stream()), 'pm_add_n')
+    return y
+
+
 def add(a, b, out=None):
     y = out if out is not None else torch.empty(a.shape, dtype=torch.float32, device=a.device)
     check(_lib().pm_add(byref(tdesc(a)), byref(tdesc(b)), byref(tdesc(y)), stream()), 'pm_add')

@@ -54,6 +54,7 @@ SIGNATURES = {
     'pm_bn_bwd_apply': (_i, [_T, _T, _T, _vp, _vp, _vp, _vp, _vp, _f, _i, _T, _T, _vp]),
     'pm_relu_bwd': (_i, [_T, _T, _T, _vp]),
     'pm_add': (_i, [_T, _T, _T, _vp]),
+    'pm_add_n': (_i, [POINTER(_T), _i, _T, _vp]),
     'pm_copy': (_i, [_T, _T, _vp]),
     'pm_scale_shift_act': (_i, [_T, _vp, _vp, _T, _i, _T, _vp]),
     'pm_maxpool3x3s2_fwd': (_i, [_T, _T, _vp, _vp]),

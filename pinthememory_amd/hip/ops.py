@@ -354,6 +354,26 @@ class _Add(torch.autograd.Function):
         return g, g
 
 
+class _Fanout(torch.autograd.Function):
+    """n aliases of a tensor that feeds n branches (the ASPP input, deepv3plus.py:72-95): their gradients are summed left to right
+    in ONE pass (pm_add_n) instead of autograd's chain of n - 1 two-operand adds over the 151 MB feature map."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [_grad_view(g) for g in gs if g is not None]
+        return (nchw(K.add_n(gs)) if len(gs) > 1 else nchw(gs[0])), None
+
+
+def fanout(x, n):
+    if n < 2 or n > 8 or not (torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * n
+    return _Fanout.apply(x, n)
+
+
 class _UpsampleCE(torch.autograd.Function):
     """mean CE(ignore 255) of bilinearly up-sampled logits vs full-resolution labels, logits never materialised."""
 

@@ -56,14 +56,15 @@ class _AtrousSpatialPyramidPoolingModule(nn.Module):
     def forward(self, x):
         widths = [self.img_conv[0].out_channels] + [f[0].out_channels for f in self.features]
         buf = ops.concat_buffer(x, widths, x.shape[2:])
+        xs = ops.fanout(x, 1 + len(self.features))     # one alias per branch: their gradients are summed in a single pass
         if isinstance(self.img_pooling, nn.AdaptiveAvgPool2d) and self.img_pooling.output_size in (1, (1, 1)):
-            pooled = ops.global_avgpool(x)
+            pooled = ops.global_avgpool(xs[0])
         else:                                          # callers may swap the pooling module (eval.py:744-745)
-            pooled = self.img_pooling(x)
+            pooled = self.img_pooling(xs[0])
         img = run_cbr(self.img_conv, pooled)
         parts, off = [ops.resize(img, x.shape[2:], out=buf[:, :widths[0]])], widths[0]
-        for f, wd in zip(self.features, widths[1:]):
-            parts.append(run_cbr(f, x, out=buf[:, off:off + wd]))
+        for f, wd, xi in zip(self.features, widths[1:], xs[1:]):
+            parts.append(run_cbr(f, xi, out=buf[:, off:off + wd]))
             off += wd
         return ops.concat(buf, parts)
 
