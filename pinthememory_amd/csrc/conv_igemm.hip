@@ -784,6 +784,10 @@ Plan make_plan(int mode, long M, long Nn, long K) {
   for (int bm = 128; bm >= 64; bm -= 64) {
     if (bm == 64 && bn < 64) continue;                            // no 64x32 instantiation (4 waves need >= 2 tiles)
     if (force_bm && mode != MODE_WGRAD && bm != force_bm && !(force_bm == 64 && bn < 64)) continue;
+    // forward / data gradient: 64-row blocks (64 x 128: 114 VGPRs, 27.6 KB single-stage LDS -> four per CU) beat 128-row ones (three
+    // per CU) on the whole step by ~0.9 ms (same-box A/B), so the larger tile is not a candidate (PM_PREFER_BM64=0 restores it)
+    static const int prefer64 = getenv("PM_PREFER_BM64") ? atoi(getenv("PM_PREFER_BM64")) : 1;
+    if (prefer64 && !force_bm && mode != MODE_WGRAD && bn >= 64 && bm == 128) continue;
     if (bm == 64 && mode == MODE_WGRAD && M > 64) continue;       // wgrad: 64 rows only for Cout <= 64
     if (bm == 128 && mode == MODE_WGRAD && M <= 64 && bn >= 64) continue;
     const int tiles_m = pm_cdiv(M, bm), tiles_n = pm_cdiv(Nn, bn);
@@ -958,8 +962,9 @@ WinoPlan wino_plan(const pm_tensor* xin, int cout, const pm_conv_params* p, bool
   wp.v_bytes = pm_align_up((size_t)wp.P * wp.g.tiles * wp.Kp * sizeof(float), 256);
   wp.m_bytes = pm_align_up((size_t)wp.P * wp.g.tiles * cout * sizeof(float), 256);
   wp.u_bytes = pm_align_up((size_t)wp.P * cout * wp.Kp * sizeof(float), 256);
-  wp.pl.bm = 128, wp.pl.bn = 128;
-  wp.pl.tiles_m = pm_cdiv(wp.g.tiles, 128), wp.pl.tiles_n = pm_cdiv(cout, 128);
+  static const int wino_bm = getenv("PM_WINO_BM") ? atoi(getenv("PM_WINO_BM")) : 128;
+  wp.pl.bm = wino_bm, wp.pl.bn = 128;
+  wp.pl.tiles_m = pm_cdiv(wp.g.tiles, wino_bm), wp.pl.tiles_n = pm_cdiv(cout, 128);
   wp.pl.ksplit = 1, wp.pl.kper = wp.Kp, wp.pl.ws_bytes = 0;
   wp.use = true;
   return wp;
