@@ -775,7 +775,12 @@ Plan make_plan(int mode, long M, long Nn, long K) {
   double best = 1e30;
   static const int force_bm = getenv("PM_FORCE_BM") ? atoi(getenv("PM_FORCE_BM")) : 0;   // tuning runs only
   static const int force_bn = getenv("PM_FORCE_BN") ? atoi(getenv("PM_FORCE_BN")) : 0;
+  // column tile: weight gradients keep 128-wide tiles; forward / data gradient run best as many small blocks (64 x 64: 70 VGPRs,
+  // 18 KB single-stage LDS -> 7-8 resident per CU): -1.4 ms/step of kernel time against 64 x 128 in the per-shape A/B
+  // (tools/conv_compare.py), within +-3 % on the few N >= 1024 shapes that preferred the wider tile. PM_WIDE_BN=1 restores 128.
+  static const int wide_bn = getenv("PM_WIDE_BN") ? atoi(getenv("PM_WIDE_BN")) : 0;
   int bn = Nn > 64 ? 128 : (Nn > 32 ? 64 : 32);
+  if (mode != MODE_WGRAD && !wide_bn && bn == 128) bn = 64;
   if (force_bn && mode != MODE_WGRAD) bn = force_bn;
   const long ksteps = (K + BK - 1) / BK;
   // candidate row tiles: 128 always; 64 halves the tile so that problems with few / awkward tile counts (the 48x48 maps: 144
@@ -963,8 +968,9 @@ WinoPlan wino_plan(const pm_tensor* xin, int cout, const pm_conv_params* p, bool
   wp.m_bytes = pm_align_up((size_t)wp.P * wp.g.tiles * cout * sizeof(float), 256);
   wp.u_bytes = pm_align_up((size_t)wp.P * cout * wp.Kp * sizeof(float), 256);
   static const int wino_bm = getenv("PM_WINO_BM") ? atoi(getenv("PM_WINO_BM")) : 128;
-  wp.pl.bm = wino_bm, wp.pl.bn = 128;
-  wp.pl.tiles_m = pm_cdiv(wp.g.tiles, wino_bm), wp.pl.tiles_n = pm_cdiv(cout, 128);
+  static const int wino_bn = getenv("PM_WINO_BN") ? atoi(getenv("PM_WINO_BN")) : 128;
+  wp.pl.bm = wino_bm, wp.pl.bn = wino_bn;
+  wp.pl.tiles_m = pm_cdiv(wp.g.tiles, wino_bm), wp.pl.tiles_n = pm_cdiv(cout, wino_bn);
   wp.pl.ksplit = 1, wp.pl.kper = wp.Kp, wp.pl.ws_bytes = 0;
   wp.use = true;
   return wp;
