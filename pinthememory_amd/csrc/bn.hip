@@ -17,8 +17,10 @@ __device__ __forceinline__ float bn_affine(float v, float mu, float is, float ga
   return fmaf(v, s, fmaf(-mu, s, be));
 }
 
-inline int chunk_rows(long P) {  // pixels per block: aim for ~2048 blocks total, >= 64 rows each
-  long r = (P + 511) / 512;
+inline int chunk_rows(long P, int C) {  // pixels per block: >= 2048 blocks over (pixel chunks x 64-channel groups), >= 64 rows each
+  const long colblocks = std::max<long>(1, (C + CB - 1) / CB);
+  const long want = std::max<long>(512, 2048 / colblocks);   // narrow tensors (64 channels) need more pixel chunks to fill the GPU
+  long r = (P + want - 1) / want;
   r = std::max<long>(r, 64);
   return (int)((r + RL - 1) / RL * RL);
 }
@@ -186,7 +188,7 @@ int check_bn(const pm_tensor* x, const char* who) {
 
 extern "C" size_t pm_bn_workspace(const pm_tensor* x) {
   const long P = pm_pixels(x);
-  const int nb = pm_cdiv(P, chunk_rows(P));
+  const int nb = pm_cdiv(P, chunk_rows(P, x->c));
   return pm_align_up((size_t)nb * x->c * 2 * sizeof(float), 256);
 }
 
@@ -195,7 +197,7 @@ extern "C" int pm_bn_stats(const pm_tensor* x, float* moments, void* ws, size_t 
   PM_REQUIRE(moments && ws && ws_bytes >= pm_bn_workspace(x), PM_EWORKSPACE, "bn_stats: workspace too small");
   const long P = pm_pixels(x);
   PM_REQUIRE(P > 0, PM_EINVAL, "bn_stats: empty tensor");
-  const int rows = chunk_rows(P), nb = pm_cdiv(P, rows);
+  const int rows = chunk_rows(P, x->c), nb = pm_cdiv(P, rows);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_stats_partial, dim3(nb, pm_cdiv(x->c, CB)), dim3(256), 0, st, (const float*)x->ptr, (long)x->pitch, P, x->c, rows, (float*)ws);
   hipLaunchKernelGGL(bn_stats_final, dim3(pm_cdiv(x->c, FC)), dim3(256), 0, st, (const float*)ws, nb, (const float*)x->ptr, P, x->c, moments);
@@ -259,7 +261,7 @@ extern "C" int pm_bn_bwd_reduce(const pm_tensor* dy, const pm_tensor* y, const p
   PM_REQUIRE(!gmask || (relu != 0 && pm_vec4(gmask) && pm_same_shape(gmask, x)), PM_EINVAL, "bn_bwd_reduce: gmask needs a ReLU mode and the shape of x");
   PM_REQUIRE(ws && ws_bytes >= pm_bn_workspace(x), PM_EWORKSPACE, "bn_bwd_reduce: workspace too small");
   const long P = pm_pixels(x);
-  const int rows = chunk_rows(P), nb = pm_cdiv(P, rows);
+  const int rows = chunk_rows(P, x->c), nb = pm_cdiv(P, rows);
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(nb, pm_cdiv(x->c, CB));
   const float *pdy = (const float*)dy->ptr, *py = relu == 1 ? (const float*)y->ptr : nullptr, *px = (const float*)x->ptr;
