@@ -54,9 +54,9 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
   }
 }
 
-// Second stage: 8 channels x 32 lanes per block; each lane sums a strided subset of the block partials in double, the 32
+// Second stage: 4 channels x 64 lanes per block; each lane sums a strided subset of the block partials in double, the 64
 // lane sums are combined in fixed order (deterministic; a 512-long serial chain per channel would cost ~100 us of pure latency).
-constexpr int FC = 8, FL = 32;
+constexpr int FC = 4, FL = 64;
 __device__ __forceinline__ void final_sums(const float* __restrict__ part, int nb, int C, int c, int lane, double& s1, double& s2) {
   __shared__ double red[FL][FC][2];
   double a = 0.0, b = 0.0;
