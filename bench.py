@@ -72,8 +72,12 @@ def main():
     backend = os.environ.get('PM_BENCH_BACKEND', 'nccl')
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
-    if world > 1:
+    multi = world > 1 or os.environ.get('PM_DIST_FORCE', '0') == '1'      # PM_DIST_FORCE: one-rank RCCL rehearsal (pinthememory_amd/dist.py)
+    if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29531')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         if backend == 'nccl':
             dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local))
         else:
@@ -86,11 +90,11 @@ def main():
     crit = torch.nn.CrossEntropyLoss(reduction='mean', ignore_index=255)
     K.set_conv_precision(a.dtype)
     peak = PEAK_TFLOPS_BF16_MFMA if a.dtype == 'bf16' else PEAK_TFLOPS_F32_MFMA
-    if world > 1:
+    if multi:
         mynn.set_bnfunc(torch.nn.SyncBatchNorm)        # train.py:95 converts to SyncBN under DDP
     net = synth.load_det_weights(deepv3plus.DeepR50V3PlusD(synth.model_args(gumbel_off=False), 19, crit, crit)).to(dev)
     opt, sched = harness.make_optimizer(net)
-    buckets = D.GradBuckets(net.parameters()) if world > 1 else None
+    buckets = D.GradBuckets(net.parameters()) if multi else None
     x, y = synth.make_batch(a.batch, a.size, seed=304 + rank)          # rank r: its own 8 images (config 4)
     x, y = x.to(dev), y.to(dev)
 
@@ -103,18 +107,18 @@ def main():
     if prof:
         K.profile_enable(True)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         losses = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -191,7 +195,10 @@ def main():
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
+        from pinthememory_amd import rccl
+        torch.cuda.synchronize()
+        rccl.shutdown()
         dist.destroy_process_group()
 
 

@@ -2,20 +2,28 @@
 
 One process per GPU. Three exchanges exist on the hot path:
   C1 gradients      -- flat-bucket all-reduce (mean), the DDP of /root/reference/network/__init__.py:31
-  C2 BN statistics  -- per-layer (mean, M2, count) merge == nn.SyncBatchNorm (/root/reference/train.py:95)
+  C2 BN statistics  -- per-layer (mean, M2, count) merge == nn.SyncBatchNorm (/root/reference/train.py:95); on GPUs these 130
+                       tiny exchanges per step go through a direct RCCL communicator on the compute stream (rccl.py)
   C3 memory slots   -- one all-reduce(SUM) of nominator[20,256] | denominator[20] inside write(); the reference never
                        syncs m_items across ranks -- with it every rank holds the single-process
                        big-batch memory (memory.py:229-230 already sums over the batch).
 All functions are no-ops for world_size 1 and work on CPU tensors (gloo) as well as GPU tensors (RCCL).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 SYNC_MEMORY = True          # C3 on by default (north star); set False to reproduce the reference's per-rank memory
 
 
+# PM_DIST_FORCE=1: issue every collective even in a one-rank group -- rehearses the RCCL call sequence (all-gather of BN moments,
+# bucketed async all-reduce on the side stream, autograd-aware memory-slot all-reduce) on a 1-GPU box; results are unchanged.
+FORCE = os.environ.get('PM_DIST_FORCE', '0') == '1'
+
+
 def is_dist():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE)
 
 
 def group_size(group=None):
@@ -29,9 +37,21 @@ def bn_group(bn):
     return None
 
 
+def _direct(t, group):
+    """The same-stream RCCL communicator (rccl.py) for small fp32 GPU tensors; None -> torch.distributed."""
+    if t.is_cuda and t.is_contiguous() and t.dtype == torch.float32:
+        from . import rccl
+        return rccl.get(group)
+    return None
+
+
 def all_reduce_sum(t, group=None):
     if is_dist():
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        comm = _direct(t, group)
+        if comm is not None:
+            comm.all_reduce_sum_(t)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
 
@@ -51,7 +71,12 @@ def merge_moments(mom, c, group=None):
         return mom
     world = dist.get_world_size(group)
     flat = torch.empty(world * mom.numel(), dtype=mom.dtype, device=mom.device)
-    dist.all_gather_into_tensor(flat, mom.contiguous(), group=group)
+    mom = mom.contiguous()
+    comm = _direct(mom, group)
+    if comm is not None:
+        comm.all_gather_into(flat, mom)
+    else:
+        dist.all_gather_into_tensor(flat, mom, group=group)
     if mom.is_cuda:
         from .hip import kernels as K
         return K.bn_merge(flat, world, c)
@@ -113,7 +138,7 @@ class GradBuckets:
         self.ready = [0] * len(self.buckets)
         self.works = []
         self.stream = torch.cuda.Stream() if dev.type == 'cuda' else None
-        if self.world > 1:
+        if is_dist():
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)
 
@@ -145,7 +170,7 @@ class GradBuckets:
 
     def finish(self):
         """Call after backward: flush buckets whose hooks never fired (unused params), wait, average."""
-        if self.world == 1:
+        if not is_dist():
             return
         for b, r in enumerate(self.ready):
             if r != self.buckets[b][2]:

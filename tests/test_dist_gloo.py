@@ -140,3 +140,39 @@ def test_single_process_is_a_noop():
     t = torch.arange(6.0)
     assert D.all_reduce_sum(t.clone()).equal(t) and D.merge_moments(t, 2).equal(t) and D.group_size() == 1
     assert D.all_reduce_sum_autograd(t) is t and D.bn_group(torch.nn.SyncBatchNorm(4)) is None
+
+
+# ---- GPU: the same-stream RCCL communicator (pinthememory_amd/rccl.py), one-rank group on the 1-GPU box -------------------
+_RCCL_PROBE = r'''
+import os, sys, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=sys.argv[1], RANK='0', WORLD_SIZE='1', PM_DIST_FORCE='1')
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+from pinthememory_amd import dist as D, rccl
+comm = rccl.get(None)
+assert comm is not None, 'direct RCCL communicator was not created'
+x = torch.arange(768, dtype=torch.float32, device='cuda') * 0.5
+y = x.clone()
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):                      # the collective runs on whatever stream is current
+    D.all_reduce_sum(y)
+    mom = D.merge_moments(torch.cat([x[:256], x[256:512].abs() + 1, torch.full((256,), 64.0, device='cuda')]), 256)
+torch.cuda.current_stream().wait_stream(side)
+torch.cuda.synchronize()
+assert torch.equal(y, x)
+assert torch.allclose(mom[:256], x[:256]) and torch.allclose(mom[512:], torch.full((256,), 64.0, device='cuda'))
+rccl.shutdown()
+dist.destroy_process_group()
+print('RCCL_DIRECT_OK')
+'''
+
+
+@pytest.mark.gpu
+def test_direct_rccl_communicator_one_rank():
+    """ncclCommInitRank / ncclAllReduce / ncclAllGather through ctypes on torch's own librccl, issued on a non-default stream."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', _RCCL_PROBE, str(_free_port())], cwd=root, capture_output=True, text=True, timeout=300)
+    assert 'RCCL_DIRECT_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
