@@ -583,6 +583,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const float* __r
     const long grp = g0 + gl;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (grp < groups)
+#pragma unroll 4   // four independent slab loads in flight; the additions stay in z order
       for (int z = zl; z < ksplit; z += ZL) {
         const float4 q = PM_LD4(ws + (long)z * slab + grp * 4);
         v.x += q.x, v.y += q.y, v.z += q.z, v.w += q.w;
@@ -770,7 +771,7 @@ struct Plan {
 //   T(ks) = ceil(blocks / 256 CUs) * (K-steps per block + 2 for prologue/epilogue) + workspace round trip + reduce launch.
 // It fills the 256 CUs when a problem has few output tiles (wgrad: Cout x taps*Cin) without paying for partial slabs
 // when the tile count alone already does.
-Plan make_plan(int mode, long M, long Nn, long K) {
+Plan make_plan(int mode, long M, long Nn, long K, bool bf16 = false) {
   Plan best_p{};
   double best = 1e30;
   static const int force_bm = getenv("PM_FORCE_BM") ? atoi(getenv("PM_FORCE_BM")) : 0;   // tuning runs only
@@ -780,7 +781,9 @@ Plan make_plan(int mode, long M, long Nn, long K) {
   // (tools/conv_compare.py), within +-3 % on the few N >= 1024 shapes that preferred the wider tile. PM_WIDE_BN=1 restores 128.
   static const int wide_bn = getenv("PM_WIDE_BN") ? atoi(getenv("PM_WIDE_BN")) : 0;
   int bn = Nn > 64 ? 128 : (Nn > 32 ? 64 : 32);
-  if (mode != MODE_WGRAD && !wide_bn && bn == 128) bn = 64;
+  // bf16 operands (configs[2], direct algorithm everywhere): the MFMA phase is 16x shorter, the kernel is bound by staging its
+  // operands through L2 / LDS, so the 128 x 128 tile (half the operand traffic per FLOP of 64 x 64) wins: 73.1 -> see DESIGN
+  if (mode != MODE_WGRAD && !wide_bn && !bf16 && bn == 128) bn = 64;
   if (force_bn && mode != MODE_WGRAD) bn = force_bn;
   const long ksteps = (K + BK - 1) / BK;
   // candidate row tiles: 128 always; 64 halves the tile so that problems with few / awkward tile counts (the 48x48 maps: 144
@@ -792,7 +795,7 @@ Plan make_plan(int mode, long M, long Nn, long K) {
     // forward / data gradient: 64-row blocks (64 x 128: 114 VGPRs, 27.6 KB single-stage LDS -> four per CU) beat 128-row ones (three
     // per CU) on the whole step by ~0.9 ms (same-box A/B), so the larger tile is not a candidate (PM_PREFER_BM64=0 restores it)
     static const int prefer64 = getenv("PM_PREFER_BM64") ? atoi(getenv("PM_PREFER_BM64")) : 1;
-    if (prefer64 && !force_bm && mode != MODE_WGRAD && bn >= 64 && bm == 128) continue;
+    if (prefer64 && !bf16 && !force_bm && mode != MODE_WGRAD && bn >= 64 && bm == 128) continue;
     if (bm == 64 && mode == MODE_WGRAD && M > 64) continue;       // wgrad: 64 rows only for Cout <= 64
     if (bm == 128 && mode == MODE_WGRAD && M <= 64 && bn >= 64) continue;
     const int tiles_m = pm_cdiv(M, bm), tiles_n = pm_cdiv(Nn, bn);
@@ -1108,7 +1111,7 @@ extern "C" size_t pm_conv_workspace(const pm_tensor* x, const pm_tensor* y, cons
     for (int cls = 0; cls < 4; ++cls) {
       const S2Class c = s2_class(cls, x, p);
       tmp = std::max(tmp, (size_t)c.M * x->c * sizeof(float));
-      if (c.M > 0 && c.nky * c.nkx > 0) slab = std::max(slab, make_plan(MODE_DGRAD, c.M, x->c, (long)c.nky * c.nkx * y->c).ws_bytes);
+      if (c.M > 0 && c.nky * c.nkx > 0) slab = std::max(slab, make_plan(MODE_DGRAD, c.M, x->c, (long)c.nky * c.nkx * y->c, p->prec == 1).ws_bytes);
     }
     return pm_align_up(4 * pm_align_up(tmp, 256) + slab + 256, 256);
   }
@@ -1123,7 +1126,7 @@ extern "C" size_t pm_conv_workspace(const pm_tensor* x, const pm_tensor* y, cons
   }
   long M, Nn, K;
   gemm_dims(which, x, y, p, M, Nn, K);
-  size_t b = make_plan(which, M, Nn, K).ws_bytes;
+  size_t b = make_plan(which, M, Nn, K, p->prec == 1).ws_bytes;
   if (which == MODE_WGRAD) b += bias_part;
   return pm_align_up(b, 256);
 }
@@ -1145,7 +1148,7 @@ extern "C" int pm_conv_fwd(const pm_tensor* x, const float* w, const pm_tensor* 
   }
   long M, Nn, K;
   gemm_dims(MODE_FWD, x, y, p, M, Nn, K);
-  Plan pl = make_plan(MODE_FWD, M, Nn, K);
+  Plan pl = make_plan(MODE_FWD, M, Nn, K, p->prec == 1);
   PM_REQUIRE(pl.ws_bytes <= ws_bytes && (pl.ws_bytes == 0 || ws), PM_EWORKSPACE, "conv_fwd: workspace %zu < %zu", ws_bytes, pl.ws_bytes);
   ConvK k;
   fill_geom(k, x, y, p);
@@ -1193,7 +1196,7 @@ extern "C" int pm_conv_bwd_data(const pm_tensor* dy, const float* w, const pm_te
       valid[cls] = c.M > 0 && c.nky * c.nkx > 0;
       if (!valid[cls]) continue;
       const long Kc = (long)c.nky * c.nkx * dy->c;
-      const Plan pl = make_plan(MODE_DGRAD, c.M, dx->c, Kc);
+      const Plan pl = make_plan(MODE_DGRAD, c.M, dx->c, Kc, p->prec == 1);
       ConvK k;
       fill_geom(k, dx, dy, p);
       k.A = (const float*)dy->ptr, k.B = w;
@@ -1229,7 +1232,7 @@ extern "C" int pm_conv_bwd_data(const pm_tensor* dy, const float* w, const pm_te
   }
   long M, Nn, K;
   gemm_dims(MODE_DGRAD, dx, dy, p, M, Nn, K);
-  Plan pl = make_plan(MODE_DGRAD, M, Nn, K);
+  Plan pl = make_plan(MODE_DGRAD, M, Nn, K, p->prec == 1);
   PM_REQUIRE(pl.ws_bytes <= ws_bytes && (pl.ws_bytes == 0 || ws), PM_EWORKSPACE, "conv_bwd_data: workspace %zu < %zu", ws_bytes, pl.ws_bytes);
   ConvK k;
   fill_geom(k, dx, dy, p);
@@ -1253,7 +1256,7 @@ extern "C" int pm_conv_bwd_weight(const pm_tensor* x, const pm_tensor* dy, float
   PM_REQUIRE(dw && pm_aligned16(dw), PM_EINVAL, "conv_bwd_weight: dw null or unaligned");
   long M, Nn, K;
   gemm_dims(MODE_WGRAD, x, dy, p, M, Nn, K);
-  Plan pl = make_plan(MODE_WGRAD, M, Nn, K);
+  Plan pl = make_plan(MODE_WGRAD, M, Nn, K, p->prec == 1);
   const size_t need = pm_conv_workspace(x, dy, p, MODE_WGRAD);
   PM_REQUIRE(need <= ws_bytes && ws, PM_EWORKSPACE, "conv_bwd_weight: workspace %zu < %zu", ws_bytes, need);
   const WinoPlan wp = wino_plan(x, dy->c, p, true);

@@ -314,16 +314,24 @@ __global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ 
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int co = (int)(i / Cin), ci = (int)(i - (long)co * Cin);
     const float* in = slab + (long)co * Kp + ci;
+    // slab sum with z outermost: the P loads of one slab are independent and all in flight together (the per-element order of the
+    // additions over z is unchanged, so the result is bit-identical to a z-innermost loop)
+    float du[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) du[q] = 0.f;
+    for (int z = 0; z < ks; ++z) {
+      float ld[P];
+#pragma unroll
+      for (int q = 0; q < P; ++q) ld[q] = in[((long)z * P + q) * plane];
+#pragma unroll
+      for (int q = 0; q < P; ++q) du[q] += ld[q];
+    }
     Vec<1> h[3][A];
 #pragma unroll
     for (int b = 0; b < A; ++b) {   // Gt dU
       Vec<1> col[A], o[3];
 #pragma unroll
-      for (int a = 0; a < A; ++a) {
-        float acc = 0.f;
-        for (int z = 0; z < ks; ++z) acc += in[((long)z * P + a * A + b) * plane];
-        col[a].v[0] = acc;
-      }
+      for (int a = 0; a < A; ++a) col[a].v[0] = du[a * A + b];
       mat_apply<MT, W_GT>(col, o);
 #pragma unroll
       for (int k = 0; k < 3; ++k) h[k][b] = o[k];

@@ -89,15 +89,11 @@ class _AllReduceSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, group):
         ctx.group = group
-        y = x.clone()
-        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
-        return y
+        return all_reduce_sum(x.clone().contiguous(), group)
 
     @staticmethod
     def backward(ctx, g):
-        g = g.clone()
-        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
-        return g, None
+        return all_reduce_sum(g.clone().contiguous(), ctx.group), None
 
 
 def all_reduce_sum_autograd(x, group=None):
