@@ -973,7 +973,10 @@ WinoPlan wino_plan(const pm_tensor* xin, int cout, const pm_conv_params* p, bool
   static const int wino_bm = getenv("PM_WINO_BM") ? atoi(getenv("PM_WINO_BM")) : 128;
   static const int wino_bn = getenv("PM_WINO_BN") ? atoi(getenv("PM_WINO_BN")) : 128;
   wp.pl.bm = wino_bm, wp.pl.bn = wino_bn;
-  wp.pl.tiles_m = pm_cdiv(wp.g.tiles, wino_bm), wp.pl.tiles_n = pm_cdiv(cout, wino_bn);
+  // column tile: 64 wide where 128-wide tiles would pad the channel extent by more than 12 % (final1's 304-channel data gradient:
+  // 3 x 128 = 384 columns of MFMA work for 304 real ones, 5 x 64 = 320)
+  if (wp.pl.bn == 128 && pm_cdiv(cout, 128) * 128 > cout * 1.12 && pm_cdiv(cout, 64) * 64 < pm_cdiv(cout, 128) * 128) wp.pl.bn = 64;
+  wp.pl.tiles_m = pm_cdiv(wp.g.tiles, wino_bm), wp.pl.tiles_n = pm_cdiv(cout, wp.pl.bn);
   wp.pl.ksplit = 1, wp.pl.kper = wp.Kp, wp.pl.ws_bytes = 0;
   wp.use = true;
   return wp;
@@ -1010,7 +1013,8 @@ struct WinoWgradPlan {
 WinoWgradPlan wino_wgrad_plan(const WinoPlan& wp, int cout) {
   WinoWgradPlan q{};
   q.pl.bm = 128, q.pl.bn = 128;
-  q.pl.tiles_m = pm_cdiv(cout, 128), q.pl.tiles_n = pm_cdiv(wp.Kp, 128);
+  if (pm_cdiv(wp.Kp, 128) * 128 > wp.Kp * 1.12 && pm_cdiv(wp.Kp, 64) * 64 < pm_cdiv(wp.Kp, 128) * 128) q.pl.bn = 64;   // Kp = 320: 5 x 64, not 3 x 128
+  q.pl.tiles_m = pm_cdiv(cout, 128), q.pl.tiles_n = pm_cdiv(wp.Kp, q.pl.bn);
   const long ksteps = (wp.g.tiles + BK - 1) / BK;
   const long per_split = (long)q.pl.tiles_m * q.pl.tiles_n * wp.P;
   long ks = std::max<long>(1, std::min<long>((768 + per_split / 2) / per_split, ksteps / 8));   // ~3 rounds of 256 CUs, >= 8 K-steps per block
