@@ -158,13 +158,14 @@ def main():
                 'double-buffered' if nst == 2 else 'single-stage', 'v_mfma_f32_32x32x16_bf16' if a.dtype == 'bf16' else 'v_mfma_f32_32x32x2_f32')
             traffic, traffic_src = None, None      # HBM bytes per launch of that symbol, from the committed PMC passes of this command
             try:
-                pj = os.path.join(ROOT, 'profiles', 'r01i_bench_1gpu_hbm_counters.json')
+                import glob
+                pj = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_1gpu_hbm_counters.json')))[-1]      # the latest committed PMC passes
                 for kr in json.load(open(pj))['kernels']:
                     if kr['kernel'].replace('void ', '').strip() == sym:
                         traffic = round((kr['read_MB_per_launch'] + kr['write_MB_per_launch']) * 1e6)
-                        traffic_src = ('profiles/r01i_bench_1gpu_hbm_counters.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of '
+                        traffic_src = ('profiles/' + os.path.basename(pj) + ': rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of '
                                        'bench.py --steps 1 --warmup 1; read = 2 x FETCH_SIZE (gfx950), average over all launches of the symbol')
-            except (OSError, KeyError, ValueError):
+            except (OSError, KeyError, ValueError, IndexError):
                 pass
             roof = {'bound': 'mfma', 'kernel': '%s (%s)' % (sym, what), 'achieved': round(ach, 2),
                     'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_source': traffic_src,
