@@ -39,7 +39,50 @@ def parse():
     ap.add_argument('--no-profile', action='store_true', help='do not bracket conv launches with HIP events')
     ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
                     help='f32 = BASELINE configs[1] (the metric; default). bf16 = configs[2]: conv operands rounded to bf16 for the bf16 MFMA, fp32 accumulate/storage')
+    ap.add_argument('--workload', choices=['train', 'config5'], default='train',
+                    help="train = the metric (default). config5 = side measurement of BASELINE configs[4]: ResNet-101 DeepLabV2 sliding-window "
+                         "evaluation of 1024x2048 images (crop 1024, overlap 1/3 -> 3 tiles x 2 flips, eval.py:148-274), single GPU")
     return ap.parse_args()
+
+
+CONFIG5_GFLOP_PER_TILE = 2057.0        # R101-DeepLabV2 'D' forward on one 1x3x1024x1024 tile
+
+
+def config5(a):
+    """Side measurement (not the metric): sliding-window logits of one resident 1024x2048 image through DeepR101V2D + argmax,
+    `--steps` images after `--warmup`; properties checked on the result: finite logits, every pixel covered, deterministic repeat."""
+    import torch
+    from pinthememory_amd import harness, synth
+    from pinthememory_amd.network import deepv2
+    assert torch.cuda.is_available(), 'bench.py needs a GPU: the HIP path has no CPU fallback'
+    dev = torch.device('cuda', 0)
+    crit = torch.nn.CrossEntropyLoss(reduction='mean', ignore_index=255)
+    net = synth.load_det_weights(deepv2.DeepR101V2D(synth.model_args(), 19, crit, crit)).to(dev)
+    img = torch.randn(3, 1024, 2048, generator=torch.Generator().manual_seed(304)).to(dev)
+    tiles = harness.sliding_tiles(1024, 2048, 1024, 1.0 / 3)
+
+    def one():
+        return harness.sliding_logits(net, img, 1024).argmax(0)
+
+    for _ in range(a.warmup):
+        first = one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        pred = one()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    logits = harness.sliding_logits(net, img, 1024)
+    assert torch.isfinite(logits).all() and tuple(logits.shape) == (19, 1024, 2048)
+    assert a.warmup == 0 or torch.equal(first, pred), 'sliding-window evaluation is not run-to-run deterministic'
+    tf = CONFIG5_GFLOP_PER_TILE * len(tiles) * 2 / 1e3
+    print(json.dumps({'metric': 'eval imgs/sec 1024x2048 R101-DeepLabV2 sliding window (crop 1024, 2 flips)', 'value': round(a.steps / dt, 3),
+                      'unit': 'imgs/sec', 'n_gpus': 1, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
+                      'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                      'config': {'workload': 'configs[4]: ResNet-101 DeepLabV2 (network/deepv2.py) 1024x2048 sliding-window inference, side measurement',
+                                 'tiles': [list(t) for t in tiles], 'flips': 2, 'conv_tflop_per_image': round(tf, 2),
+                                 'direct_equivalent_mfma_frac': round(tf * a.steps / dt / PEAK_TFLOPS_F32_MFMA, 4)},
+                      'roofline': None, 'cpu_baseline': None}), flush=True)
 
 
 def cpu_baseline(batch, size):
@@ -62,6 +105,8 @@ def cpu_baseline(batch, size):
 
 def main():
     a = parse()
+    if a.workload == 'config5':
+        return config5(a)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
