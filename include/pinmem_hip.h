@@ -86,6 +86,9 @@ int pm_profile_read(int mode, int bm, int bn, int km, int nst, double* total_ms,
  * moments layout: float[3*C] = mean[C] | m2[C] | count (replicated [C]). */
 size_t pm_bn_workspace(const pm_tensor* x);
 int pm_bn_stats(const pm_tensor* x, float* moments, void* ws, size_t ws_bytes, void* stream);
+/* pm_bn_stats + pm_bn_finalize in one call for local (non-synchronised) statistics: same values, one launch less per BN layer */
+int pm_bn_stats_finalize(const pm_tensor* x, float eps, float* mean, float* invstd, float* running_mean /*nullable*/, float* running_var /*nullable*/,
+                         float momentum, void* ws, size_t ws_bytes, void* stream);
 /* SyncBatchNorm (train.py:95): exact merge of the per-rank moments gathered over the process group, parts = float[world][3*C] */
 int pm_bn_merge(const float* parts, int world, int c, float* moments, void* stream);
 /* mean/var(biased) -> invstd; optionally updates running stats (unbiased var), momentum as torch. */

@@ -61,6 +61,7 @@ __device__ __forceinline__ void final_sums(const float* __restrict__ part, int n
   __shared__ double red[FL][FC][2];
   double a = 0.0, b = 0.0;
   if (c < C)
+#pragma unroll 8   // eight independent partial loads in flight per lane (the additions keep their order)
     for (int i = lane; i < nb; i += FL) {
       const float2 v = *reinterpret_cast<const float2*>(part + ((long)i * C + c) * 2);
       a += (double)v.x, b += (double)v.y;
@@ -74,15 +75,29 @@ __device__ __forceinline__ void final_sums(const float* __restrict__ part, int n
   }
 }
 
-__global__ __launch_bounds__(256) void bn_stats_final(const float* __restrict__ part, int nb, const float* __restrict__ x, long P, int C, float* __restrict__ moments) {
+// FIN: local statistics (no process group) -- mean / invstd and the running-moment update of bn_finalize_kernel happen here, on the
+// same float values the two-kernel path hands over through `moments` (bit-identical), one launch less per BN layer.
+template <bool FIN>
+__global__ __launch_bounds__(256) void bn_stats_final(const float* __restrict__ part, int nb, const float* __restrict__ x, long P, int C, float* __restrict__ moments,
+                                                      float eps, float* __restrict__ mean, float* __restrict__ invstd, float* running_mean, float* running_var,
+                                                      float momentum) {
   const int c = blockIdx.x * FC + (threadIdx.x & (FC - 1)), lane = threadIdx.x / FC;
   double s1, s2;
   final_sums(part, nb, C, c, lane, s1, s2);
   if (lane != 0 || c >= C) return;
   const double n = (double)P;
-  moments[c] = (float)((double)x[c] + s1 / n);
-  moments[C + c] = (float)fmax(s2 - s1 * s1 / n, 0.0);
-  moments[2 * C + c] = (float)n;
+  const float m = (float)((double)x[c] + s1 / n), m2 = (float)fmax(s2 - s1 * s1 / n, 0.0), nf = (float)n;
+  if constexpr (!FIN) {
+    moments[c] = m;
+    moments[C + c] = m2;
+    moments[2 * C + c] = nf;
+  } else {
+    const float var = m2 / nf;
+    mean[c] = m;
+    invstd[c] = 1.f / sqrtf(var + eps);
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (m2 / (nf - 1.f));
+  }
 }
 
 __global__ void bn_finalize_kernel(const float* __restrict__ moments, int C, float eps, float* __restrict__ mean, float* __restrict__ invstd,
@@ -200,8 +215,24 @@ extern "C" int pm_bn_stats(const pm_tensor* x, float* moments, void* ws, size_t 
   const int rows = chunk_rows(P, x->c), nb = pm_cdiv(P, rows);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_stats_partial, dim3(nb, pm_cdiv(x->c, CB)), dim3(256), 0, st, (const float*)x->ptr, (long)x->pitch, P, x->c, rows, (float*)ws);
-  hipLaunchKernelGGL(bn_stats_final, dim3(pm_cdiv(x->c, FC)), dim3(256), 0, st, (const float*)ws, nb, (const float*)x->ptr, P, x->c, moments);
+  hipLaunchKernelGGL(bn_stats_final<false>, dim3(pm_cdiv(x->c, FC)), dim3(256), 0, st, (const float*)ws, nb, (const float*)x->ptr, P, x->c, moments, 0.f,
+                     (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f);
   return pm_check_launch("bn_stats");
+}
+
+extern "C" int pm_bn_stats_finalize(const pm_tensor* x, float eps, float* mean, float* invstd, float* running_mean, float* running_var, float momentum,
+                                    void* ws, size_t ws_bytes, void* stream) {
+  if (int e = check_bn(x, "bn_stats_finalize")) return e;
+  PM_REQUIRE(mean && invstd, PM_EINVAL, "bn_stats_finalize: bad args");
+  PM_REQUIRE(ws && ws_bytes >= pm_bn_workspace(x), PM_EWORKSPACE, "bn_stats_finalize: workspace too small");
+  const long P = pm_pixels(x);
+  PM_REQUIRE(P > 0, PM_EINVAL, "bn_stats_finalize: empty tensor");
+  const int rows = chunk_rows(P, x->c), nb = pm_cdiv(P, rows);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_stats_partial, dim3(nb, pm_cdiv(x->c, CB)), dim3(256), 0, st, (const float*)x->ptr, (long)x->pitch, P, x->c, rows, (float*)ws);
+  hipLaunchKernelGGL(bn_stats_final<true>, dim3(pm_cdiv(x->c, FC)), dim3(256), 0, st, (const float*)ws, nb, (const float*)x->ptr, P, x->c, (float*)nullptr, eps,
+                     mean, invstd, running_mean, running_var, momentum);
+  return pm_check_launch("bn_stats_finalize");
 }
 
 extern "C" int pm_bn_finalize(const float* moments, int c, float eps, float* mean, float* invstd, float* running_mean, float* running_var,

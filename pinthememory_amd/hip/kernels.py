@@ -114,6 +114,20 @@ def bn_stats(x):
     return mom
 
 
+def bn_stats_finalize(x, eps, running_mean=None, running_var=None, momentum=0.1):
+    """bn_stats + bn_finalize for local statistics in one library call -> (mean, invstd); running moments updated in place."""
+    c = x.shape[3]
+    mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    invstd = torch.empty_like(mean)
+    xd = tdesc(x)
+    lib = _lib()
+    nb = lib.pm_bn_workspace(byref(xd))
+    ws = workspace(nb, x.device)
+    check(lib.pm_bn_stats_finalize(byref(xd), eps, mean.data_ptr(), invstd.data_ptr(), ptr(running_mean), ptr(running_var), momentum, ptr(ws), nb, stream()),
+          'pm_bn_stats_finalize')
+    return mean, invstd
+
+
 def bn_merge(parts, world, c):
     """parts: float[world, 3c] gathered per-rank moments -> merged float[3c]."""
     out = torch.empty(3 * c, dtype=torch.float32, device=parts.device)

@@ -132,13 +132,17 @@ def _wgrad(x, dy, wshape, geom, want_bias=False, deferred=False, wino_v=None):
     return out
 
 
+BN_FUSED_FINALIZE = _os.environ.get('PM_BN_FUSED', '1') == '1'      # A/B knob: 0 = separate bn_stats / bn_finalize launches
+
+
 def _bn_train_fwd(y, gamma, beta, bn, residual, relu, out=None):
     """Batch statistics (merged across ranks for SyncBN) -> normalise + residual + ReLU. Returns (o, mean, invstd)."""
     c = y.shape[3]
-    mom = K.bn_stats(y)
-    if bn.group is not None:
-        mom = D.merge_moments(mom, c, bn.group)
-    mean, invstd = K.bn_finalize(mom, c, bn.eps, bn.running_mean, bn.running_var, bn.momentum)
+    if bn.group is None and BN_FUSED_FINALIZE:
+        mean, invstd = K.bn_stats_finalize(y, bn.eps, bn.running_mean, bn.running_var, bn.momentum)
+    else:
+        mom = D.merge_moments(K.bn_stats(y), c, bn.group)
+        mean, invstd = K.bn_finalize(mom, c, bn.eps, bn.running_mean, bn.running_var, bn.momentum)
     return K.bn_apply(y, mean, invstd, gamma, beta, residual=residual, relu=relu, out=out), mean, invstd
 
 

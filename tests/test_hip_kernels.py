@@ -168,8 +168,11 @@ def test_batchnorm_train(K, shape, relu, res):
     y_ref.backward(dy)
 
     xg = nhwc(x)
+    rm2, rv2 = rm.clone(), rv.clone()
     mom = K.bn_stats(xg)
     mean, invstd = K.bn_finalize(mom, c, bn.eps, rm, rv, 0.1)
+    mean2, invstd2 = K.bn_stats_finalize(xg, bn.eps, rm2, rv2, 0.1)       # the fused local-statistics entry point: the same bits
+    assert torch.equal(mean, mean2) and torch.equal(invstd, invstd2) and torch.equal(rm, rm2) and torch.equal(rv, rv2)
     assert rel(mean, x.mean((0, 2, 3))) < 1e-5
     assert rel(rm, bn.running_mean) < 1e-5 and rel(rv, bn.running_var) < 1e-5
     g, b = bn.weight.detach().cuda(), bn.bias.detach().cuda()
