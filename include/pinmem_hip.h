@@ -111,6 +111,9 @@ int pm_bn_bwd_apply(const pm_tensor* dy, const pm_tensor* y /*relu == 1 only*/, 
 /* eval-mode fold: scale = gamma/sqrt(running_var+eps); shift = beta - running_mean*scale + (conv_bias ? conv_bias*scale : 0) */
 int pm_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var, const float* conv_bias,
                int c, float eps, float* scale, float* shift, void* stream);
+/* the same fold for n BatchNorm layers in one launch (eval-mode forward of a whole network): table = n x {gamma, beta, running_mean,
+ * running_var} device pointers (uint64), cs[n] channel counts, offs[n] offsets into arena; scale_i = arena + offs[i], shift_i = arena + total + offs[i] */
+int pm_bn_fold_multi(const void* table, const int* cs, const int* offs, int n, int max_c, int total, float eps, float* arena, void* stream);
 /* eval-mode / frozen-stat backward helper and plain elementwise ops */
 int pm_relu_bwd(const pm_tensor* dy, const pm_tensor* y, const pm_tensor* dx, void* stream);
 int pm_add(const pm_tensor* a, const pm_tensor* b, const pm_tensor* y, void* stream);

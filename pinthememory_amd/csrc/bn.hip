@@ -185,6 +185,21 @@ __global__ void bn_merge_kernel(const float* __restrict__ parts, int W, int C, f
   out[c] = (float)mean, out[C + c] = (float)m2, out[2 * C + c] = (float)n;
 }
 
+// every BatchNorm of a network folded in one launch (eval-mode forward): table[i] = {gamma, beta, running_mean, running_var} device
+// pointers of layer i, cs[i] its channel count, offs[i] its offset in the arena (scale at arena + offs[i], shift at arena + total + offs[i])
+__global__ void bn_fold_multi_kernel(const unsigned long long* __restrict__ table, const int* __restrict__ cs, const int* __restrict__ offs, int total,
+                                     float eps, float* __restrict__ arena) {
+  const int i = blockIdx.x, C = cs[i];
+  const float *g = (const float*)table[4 * i], *b = (const float*)table[4 * i + 1], *rm = (const float*)table[4 * i + 2], *rv = (const float*)table[4 * i + 3];
+  float* scale = arena + offs[i];
+  float* shift = arena + total + offs[i];
+  for (int c = blockIdx.y * blockDim.x + threadIdx.x; c < C; c += gridDim.y * blockDim.x) {
+    const float s = g[c] / sqrtf(rv[c] + eps);      // the same expressions as bn_fold_kernel: identical values
+    scale[c] = s;
+    shift[c] = b[c] - rm[c] * s;
+  }
+}
+
 __global__ void bn_fold_kernel(const float* __restrict__ g, const float* __restrict__ b, const float* __restrict__ rm, const float* __restrict__ rv,
                                const float* __restrict__ cb, int C, float eps, float* __restrict__ scale, float* __restrict__ shift) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -254,6 +269,13 @@ extern "C" int pm_bn_fold(const float* gamma, const float* beta, const float* rm
   PM_REQUIRE(gamma && beta && rm && rv && scale && shift && c > 0, PM_EINVAL, "bn_fold: bad args");
   hipLaunchKernelGGL(bn_fold_kernel, dim3(pm_cdiv(c, 64)), dim3(64), 0, (hipStream_t)stream, gamma, beta, rm, rv, conv_bias, c, eps, scale, shift);
   return pm_check_launch("bn_fold");
+}
+
+extern "C" int pm_bn_fold_multi(const void* table, const int* cs, const int* offs, int n, int max_c, int total, float eps, float* arena, void* stream) {
+  PM_REQUIRE(table && cs && offs && arena && n > 0 && max_c > 0 && total > 0, PM_EINVAL, "bn_fold_multi: bad args");
+  hipLaunchKernelGGL(bn_fold_multi_kernel, dim3(n, pm_cdiv(max_c, 256)), dim3(256), 0, (hipStream_t)stream, (const unsigned long long*)table, cs, offs, total, eps,
+                     arena);
+  return pm_check_launch("bn_fold_multi");
 }
 
 extern "C" int pm_bn_apply(const pm_tensor* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const pm_tensor* res,

@@ -143,6 +143,13 @@ def bn_finalize(moments, c, eps, running_mean=None, running_var=None, momentum=0
     return mean, invstd
 
 
+def bn_fold_multi(table, cs, offs, n, max_c, total, eps):
+    """n BatchNorm layers folded in one launch -> arena float[2 * total] (scales | shifts); table / cs / offs are device tensors."""
+    arena = torch.empty(2 * total, dtype=torch.float32, device=table.device)
+    check(_lib().pm_bn_fold_multi(table.data_ptr(), cs.data_ptr(), offs.data_ptr(), n, max_c, total, eps, arena.data_ptr(), stream()), 'pm_bn_fold_multi')
+    return arena
+
+
 def bn_fold(gamma, beta, running_mean, running_var, eps, conv_bias=None):
     c = gamma.numel()
     scale = torch.empty(c, dtype=torch.float32, device=gamma.device)

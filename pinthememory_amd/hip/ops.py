@@ -217,6 +217,57 @@ class _Bottleneck(torch.autograd.Function):
         return dx, p(dw1), dg1, db1, p(dw2), dg2, db2, p(dw3), dg3, db3, dwd, dgd, dbd, None, None, None
 
 
+# ---- eval-mode forward: every BatchNorm folded in ONE launch ---------------------------------------------------------------------
+# The no-grad eval forward folds each BN into its conv's epilogue; doing that per layer puts 64 four-microsecond kernels (plus their
+# launch boundaries) on the critical chain of the memory-commit forward. `prefold(model)` folds all of them at once when the forward
+# starts; _ConvBnAct picks its (scale, shift) views from the cache (keyed by the running_mean storage) and falls back to the per-layer
+# fold for anything not covered (a conv with a bias, a module swapped in later). PM_FOLD_BATCH=0 disables it.
+FOLD_BATCH = _os.environ.get('PM_FOLD_BATCH', '1') == '1'
+_fold_cache = None
+
+
+class prefold:
+    def __init__(self, model):
+        self.model, self.active = model, False
+
+    def __enter__(self):
+        global _fold_cache
+        m = self.model
+        if not FOLD_BATCH or m.training or torch.is_grad_enabled() or _fold_cache is not None:
+            return self
+        bns = getattr(m, '_pm_bn_list', None)
+        if bns is None:
+            bns = [b for b in m.modules() if isinstance(b, torch.nn.modules.batchnorm._BatchNorm)]
+            m.__dict__['_pm_bn_list'] = bns
+        bns = [b for b in bns if b.running_mean is not None and b.weight is not None and b.running_mean.is_cuda and not b.training]
+        if not bns or len({b.eps for b in bns}) != 1:
+            return self
+        ptrs = tuple(t.data_ptr() for b in bns for t in (b.weight, b.bias, b.running_mean, b.running_var))
+        plan = m.__dict__.get('_pm_fold_plan')
+        if plan is None or plan[0] != ptrs:            # pointers only change when parameters / buffers are re-created (load, .to, put_theta)
+            dev = bns[0].running_mean.device
+            cs = [b.num_features for b in bns]
+            offs, tot = [], 0
+            for c in cs:
+                offs.append(tot)
+                tot += (c + 3) // 4 * 4                # 16-byte aligned views
+            as_i64 = [p - (1 << 64) if p >= (1 << 63) else p for p in ptrs]
+            plan = (ptrs, torch.tensor(as_i64, dtype=torch.int64, device=dev), torch.tensor(cs, dtype=torch.int32, device=dev),
+                    torch.tensor(offs, dtype=torch.int32, device=dev), cs, offs, tot)
+            m.__dict__['_pm_fold_plan'] = plan
+        _, table, dcs, doffs, cs, offs, tot = plan
+        arena = K.bn_fold_multi(table, dcs, doffs, len(cs), max(cs), tot, bns[0].eps)
+        _fold_cache = {b.running_mean.data_ptr(): (arena[o:o + c], arena[tot + o:tot + o + c]) for b, c, o in zip(bns, cs, offs)}
+        self.active = True
+        return self
+
+    def __exit__(self, *exc):
+        global _fold_cache
+        if self.active:
+            _fold_cache = None
+        return False
+
+
 class _ConvBnAct(torch.autograd.Function):
     """conv -> BatchNorm(train: batch statistics | eval: folded into the conv epilogue) -> (+residual) -> ReLU.
     Replaces e.g. Resnet.py:195-216 conv/bn/relu triples and every Sequential(Conv2d, Norm2d, ReLU) of deepv3plus.py."""
@@ -230,7 +281,8 @@ class _ConvBnAct(torch.autograd.Function):
         ctx.geom, ctx.relu, ctx.train, ctx.deferred = geom, relu, bn.training, deferred and bias is None
         needs_grad = bn.grad_enabled and any(ctx.needs_input_grad[:6])   # needs_input_grad alone ignores torch.no_grad()
         if not bn.training and not needs_grad:     # inference: BN folded into the conv epilogue, nothing saved
-            scale, shift = K.bn_fold(gamma, beta, bn.running_mean, bn.running_var, bn.eps, bias)
+            hit = _fold_cache.get(bn.running_mean.data_ptr()) if (_fold_cache is not None and bias is None) else None
+            scale, shift = hit if hit is not None else K.bn_fold(gamma, beta, bn.running_mean, bn.running_var, bn.eps, bias)
             o = K.conv_fwd(xv, wk, stride, pad, dil, scale=scale, shift=shift, residual=rv, relu=relu, out=ov)
             return nchw(o)
         kv = []

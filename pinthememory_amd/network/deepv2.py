@@ -57,6 +57,10 @@ class DeepV2(_Base):
 
     def forward(self, x, gts=None, aux_gts=None, img_gt=None, visualize=False, cal_covstat=False, apply_wtloss=True,
                 memory_writing=False, writing_detach=True):
+        with ops.prefold(self):      # no-grad eval forward: all BatchNorm folds in one launch (no-op otherwise)
+            return self._forward(x, gts, aux_gts, img_gt, visualize, cal_covstat, apply_wtloss, memory_writing, writing_detach)
+
+    def _forward(self, x, gts, aux_gts, img_gt, visualize, cal_covstat, apply_wtloss, memory_writing, writing_detach):
         assert not cal_covstat and not visualize, 'whitening statistics are out of scope'
         x_size = x.size()
         _, aux_out, x = self._trunk(x)

@@ -331,6 +331,33 @@ def test_conv_routes_agree_on_the_network(env):
         assert ok and frac > 0.9999, (mode, frac)
 
 
+def test_batched_bn_fold_is_bit_identical(env):
+    """The no-grad eval forward folds every BatchNorm in one launch (ops.prefold); the per-layer fold computes the same expressions,
+    so logits and the committed memory are bit-identical with the batch switched off -- also after the running moments moved."""
+    from pinthememory_amd.hip import ops
+    synth = env['synth']
+    net = synth.load_det_weights(env['deepv3plus'].DeepR50V3PlusD(synth.model_args(), 19, CRIT, CRIT)).cuda()
+    x, y = synth.make_batch(2, 128)
+    x, y = x.cuda(), y.cuda()
+    net.train()
+    net(x, gts=y, aux_gts=y, memory_writing=True, writing_detach=True)       # moves every running mean / variance
+    net.eval()
+    out = {}
+    try:
+        for flag in (True, False, True):
+            ops.FOLD_BATCH = flag
+            m0 = net.memory.m_items.clone()
+            with torch.no_grad():
+                lg = net(x, gts=y, aux_gts=y, memory_writing=True)[0]
+            out.setdefault(flag, []).append((lg.clone(), net.memory.m_items.clone()))
+            net.memory.m_items = m0
+    finally:
+        ops.FOLD_BATCH = True
+    assert '_pm_fold_plan' in net.__dict__
+    for lg, mem in out[True]:
+        assert torch.equal(lg, out[False][0][0]) and torch.equal(mem, out[False][0][1])
+
+
 def test_config3_bf16_mfma_forward_and_step(env):
     """BASELINE configs[2]: the same network with bf16-MFMA convolutions (operands rounded to bf16, fp32 accumulate / storage).
     Gate: looser than fp32 by the operand precision -- eval logits within 2e-2 of the fp32 oracle relative to their range and
