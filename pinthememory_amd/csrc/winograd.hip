@@ -244,27 +244,33 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restric
   }
   __syncthreads();
   const long plane = (long)R * Kp;
-  for (int j = ty; j < 32; j += 8) {   // thread -> (row r0 + j, k = k0 + tx): coalesced over k
-    const int row = r0 + j, k = k0 + tx;
-    if (row >= R || k >= Kp) continue;
-    const bool kok = k < Kr;
-    Vec<1> gg[A][3];
+  // thread -> (row r0 + j, four consecutive k = k0 + 4 q): one float4 store per transform point (36 x 16 B instead of 144 x 4 B per thread)
+  const int j = threadIdx.x >> 3, q = threadIdx.x & 7;
+  const int row = r0 + j, k = k0 + 4 * q;
+  if (row >= R || k >= Kp) return;
+  Vec<4> gg[A][3];
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {   // G g
-      Vec<1> col[3], o[A];
+  for (int kx = 0; kx < 3; ++kx) {   // G g
+    Vec<4> col[3], o[A];
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) col[ky].v[0] = DGRAD ? sg[(2 - ky) * 3 + (2 - kx)][tx][j] : sg[ky * 3 + kx][j][tx];
-      mat_apply<MT, W_G>(col, o);
+    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-      for (int a = 0; a < A; ++a) gg[a][kx] = o[a];
-    }
-    float* out = U + (long)row * Kp + k;
+      for (int e = 0; e < 4; ++e) col[ky].v[e] = DGRAD ? sg[(2 - ky) * 3 + (2 - kx)][4 * q + e][j] : sg[ky * 3 + kx][j][4 * q + e];
+    mat_apply<MT, W_G>(col, o);
 #pragma unroll
-    for (int a = 0; a < A; ++a) {      // (G g) Gt
-      Vec<1> o[A];
-      mat_apply<MT, W_G>(gg[a], o);
+    for (int a = 0; a < A; ++a) gg[a][kx] = o[a];
+  }
+  float* out = U + (long)row * Kp + k;
 #pragma unroll
-      for (int b = 0; b < A; ++b) out[(a * A + b) * plane] = kok ? o[b].v[0] : 0.f;
+  for (int a = 0; a < A; ++a) {      // (G g) Gt
+    Vec<4> o[A];
+    mat_apply<MT, W_G>(gg[a], o);
+#pragma unroll
+    for (int b = 0; b < A; ++b) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (k + e >= Kr) o[b].v[e] = 0.f;   // zero fill of the K padding
+      vstore<4>(out + (a * A + b) * plane, o[b]);
     }
   }
 }
