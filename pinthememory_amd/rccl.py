@@ -14,6 +14,7 @@ rank (the ranks agree on that with one all-reduce), so the exchange itself never
 """
 import ctypes
 import os
+import time
 import warnings
 
 import torch
@@ -39,6 +40,7 @@ def _load():
         lib.ncclGetUniqueId.argtypes = [ctypes.POINTER(_UniqueId)]
         lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _UniqueId, ctypes.c_int]
         lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        lib.ncclCommAbort.argtypes = [ctypes.c_void_p]
         lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         lib.ncclAllGather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         _lib = lib
@@ -86,9 +88,21 @@ class DirectComm:
                                      torch.cuda.current_stream(t.device).cuda_stream), 'ncclAllGather')
         return out
 
-    def destroy(self):
+    def self_test(self, timeout_s=30.0):
+        """One small all-reduce, waited for with a bounded host-side poll: a communicator whose kernels never finish is reported
+        (and must then be aborted) instead of hanging the first BatchNorm layer."""
+        t = torch.ones(1024, dtype=torch.float32, device='cuda')
+        self.all_reduce_sum_(t)
+        ev = torch.cuda.Event()
+        ev.record()
+        deadline = time.time() + timeout_s
+        while not ev.query() and time.time() < deadline:
+            time.sleep(0.005)
+        return bool(ev.query()) and float(t[0].item()) == float(self.world)
+
+    def destroy(self, abort=False):
         if self.comm:
-            _load().ncclCommDestroy(self.comm)
+            (_load().ncclCommAbort if abort else _load().ncclCommDestroy)(self.comm)
             self.comm = ctypes.c_void_p()
 
 
@@ -103,12 +117,18 @@ def get(group=None):
     key = group
     c = _comms.get(key)
     if c is None:
-        err = None
+        err, alive = None, False
         try:
             c = DirectComm(group)
+            alive = c.self_test()
+            if not alive:
+                err = 'self-test all-reduce did not complete'
         except Exception as e:      # noqa: BLE001 -- every failure mode ends in the same agreed fall-back
-            c, err = None, e
-        ok = torch.tensor([1.0 if c is not None else 0.0], device='cuda')
+            err = e
+        if c is not None and not alive:
+            c.destroy(abort=True)       # before anything else is queued behind a kernel that may never finish
+            c = None
+        ok = torch.tensor([1.0 if alive else 0.0], device='cuda')
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
         if ok.item() < 1.0:
             if c is not None:
