@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const float* __r
     const long grp = g0 + gl;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (grp < groups)
-#pragma unroll 4   // four independent slab loads in flight; the additions stay in z order
+#pragma unroll 8   // eight independent slab loads in flight; the additions stay in z order
       for (int z = zl; z < ksplit; z += ZL) {
         const float4 q = PM_LD4(ws + (long)z * slab + grp * 4);
         v.x += q.x, v.y += q.y, v.z += q.z, v.w += q.w;
