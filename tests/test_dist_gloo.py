@@ -176,3 +176,54 @@ def test_direct_rccl_communicator_one_rank():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, '-c', _RCCL_PROBE, str(_free_port())], cwd=root, capture_output=True, text=True, timeout=300)
     assert 'RCCL_DIRECT_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+# ---- GPU: the whole N > 1 code path in a one-rank RCCL group must reproduce the plain single-process step bit for bit ---------------
+_STEP_PROBE = r'''
+import hashlib, os, sys, torch
+force = sys.argv[2] == '1'
+if force:
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=sys.argv[1], RANK='0', WORLD_SIZE='1', PM_DIST_FORCE='1')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+from pinthememory_amd import dist as D, harness, synth
+from pinthememory_amd.network import deepv3plus, mynn
+if force:
+    mynn.set_bnfunc(torch.nn.SyncBatchNorm)
+crit = torch.nn.CrossEntropyLoss(reduction='mean', ignore_index=255)
+net = synth.load_det_weights(deepv3plus.DeepR50V3PlusD(synth.model_args(), 19, crit, crit)).cuda()
+net.dsn[3].p = 0.0
+opt, sched = harness.make_optimizer(net)
+buckets = D.GradBuckets(net.parameters()) if force else None
+x, y = synth.make_batch(2, 128)
+x, y = x.cuda(), y.cuda()
+for _ in range(2):
+    out = harness.agg_train_step(net, opt, x, y, sched=sched, buckets=buckets)
+torch.cuda.synchronize()
+h = hashlib.sha256()
+for p in list(net.parameters()) + [net.memory.m_items] + [b for b in net.buffers() if b.dtype == torch.float32]:
+    h.update(p.detach().float().contiguous().cpu().numpy().tobytes())
+if force:
+    from pinthememory_amd import rccl
+    assert rccl.get(None) is not None
+    rccl.shutdown()
+    dist.destroy_process_group()
+print('STEP_DIGEST', h.hexdigest(), '%.6f' % out['total'].item())
+'''
+
+
+@pytest.mark.gpu
+def test_one_rank_rccl_step_equals_plain_step():
+    """SyncBN moments through all-gather + merge, bucketed gradient all-reduce on the side stream, memory-slot all-reduce: with one
+    rank every exchange is the identity, so parameters, buffers and memory after two agg steps carry the same bits as the plain path."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for force in ('0', '1'):
+        r = subprocess.run([sys.executable, '-c', _STEP_PROBE, str(_free_port()), force], cwd=root, capture_output=True, text=True, timeout=600)
+        lines = [l for l in r.stdout.splitlines() if l.startswith('STEP_DIGEST')]
+        assert lines, r.stdout[-2000:] + r.stderr[-4000:]
+        digests.append(lines[0].split()[1:])
+    assert digests[0] == digests[1], digests
