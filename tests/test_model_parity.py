@@ -51,6 +51,34 @@ def test_config1_eval_forward_vs_oracle_and_golden(env, golden):
     assert np.all(lg.argmax(1).numpy().astype(np.uint8)[safe_g] == g['argmax'][safe_g])
 
 
+def test_ragged_input_size_vs_oracle(env):
+    """Edge case: a 2 x 3 x 203 x 277 batch (odd, non-square, no multiple of any stride, block tile or Winograd tile: every map on the
+    way has ragged tile edges, 13 x 18 at output stride 16) -- eval logits and the memory read against the CPU oracle, then the five
+    losses of a training forward with labels (ignore rows included) on the same odd size."""
+    synth = env['synth']
+    args = synth.model_args()
+    ref = synth.load_det_weights(env['o_deeplab'].DeepR50V3PlusD(args, 19, CRIT, CRIT)).eval()
+    net = synth.load_det_weights(env['deepv3plus'].DeepR50V3PlusD(args, 19, CRIT, CRIT)).cuda().eval()
+    x, y = synth.make_batch(2, (203, 277), seed=11)
+    with torch.no_grad():
+        want, got = ref(x), net(x.cuda())
+    lg = got[0].cpu()
+    assert lg.shape == want[0].shape == (2, 19, 203, 277)
+    assert (lg - want[0]).abs().max().item() < LOGIT_TOL
+    ok, frac, safe = argmax_gate(lg, want[0])
+    assert ok and frac > 0.9995, (frac, safe)
+    assert (got[1][1].cpu() - want[1][1]).abs().max().item() < 1e-4
+    ref.train(), net.train()
+    ref.dsn[3].p = net.dsn[3].p = 0.0
+    with torch.no_grad():
+        w_tr = ref(x, gts=y, aux_gts=y, memory_writing=True, writing_detach=True)
+        g_tr = net(x.cuda(), gts=y.cuda(), aux_gts=y.cuda(), memory_writing=True, writing_detach=True)
+    for name, a, b in (('loss1', g_tr[0], w_tr[0]), ('loss2', g_tr[1], w_tr[1]), ('readloss', g_tr[-2], w_tr[-2]),
+                       ('div', g_tr[-3][0], w_tr[-3][0]), ('cls', g_tr[-3][1], w_tr[-3][1])):
+        assert abs(float(a) - float(b)) <= 2e-4 * max(1.0, abs(float(b))), (name, float(a), float(b))
+    assert (net.memory.m_items.cpu() - ref.memory.m_items).abs().max().item() < 1e-4
+
+
 def _oracle(env, dtype, x, y, step):
     """CPU oracle in `dtype` on the same inputs: fp32 is the reference's arithmetic, fp64 the ground truth that tells how
     much of any difference is fp32 round-off (train-mode BN at tiny batch amplifies 1e-7 to percents in the trunk
