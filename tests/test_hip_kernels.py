@@ -272,6 +272,17 @@ def test_upsample_ce(K, hw, HW, temp, C):
     assert out[1].item() == (lab != 255).sum().item()
     dl = K.upsample_ce_bwd(lgg, labg, out, torch.tensor([1.7], device='cuda'), 1.0 / temp)
     assert rel(nchw(dl), lr.grad) < 2e-5
+    # edge cases of the reference's criterion (CrossEntropyLoss(ignore_index=255), loss.py:38-39): one image with every pixel ignored
+    # contributes nothing; a batch with every pixel ignored gives NaN (0 / 0) exactly as torch does, and a valid-pixel count of zero
+    lab1 = lab.clone()
+    lab1[0] = 255
+    ref1 = F.cross_entropy(F.interpolate(lg / temp, size=HW, mode='bilinear', align_corners=True), lab1, ignore_index=255)
+    out1 = K.upsample_ce_fwd(lgg, lab1.cuda(), 1.0 / temp)
+    assert abs(out1[0].item() - ref1.item()) < 2e-6 * max(1, abs(ref1.item())) and out1[1].item() == (lab1 != 255).sum().item()
+    dl1 = K.upsample_ce_bwd(lgg, lab1.cuda(), out1, None, 1.0 / temp)
+    assert nchw(dl1)[0].abs().max().item() == 0.0                      # no gradient into the fully ignored image
+    out0 = K.upsample_ce_fwd(lgg, torch.full_like(lab, 255).cuda(), 1.0 / temp)
+    assert torch.isnan(out0[0]).item() and out0[1].item() == 0
 
 
 def test_memory_read(K):
