@@ -91,6 +91,9 @@ int pm_bn_stats_finalize(const pm_tensor* x, float eps, float* mean, float* invs
                          float momentum, void* ws, size_t ws_bytes, void* stream);
 /* SyncBatchNorm (train.py:95): exact merge of the per-rank moments gathered over the process group, parts = float[world][3*C] */
 int pm_bn_merge(const float* parts, int world, int c, float* moments, void* stream);
+/* pm_bn_merge + pm_bn_finalize in one launch (the same values): SyncBatchNorm forward = stats, all-gather, this, apply */
+int pm_bn_merge_finalize(const float* parts, int world, int c, float eps, float* mean, float* invstd, float* running_mean /*nullable*/,
+                         float* running_var /*nullable*/, float momentum, void* stream);
 /* mean/var(biased) -> invstd; optionally updates running stats (unbiased var), momentum as torch. */
 int pm_bn_finalize(const float* moments, int c, float eps, float* mean, float* invstd,
                    float* running_mean, float* running_var, float momentum, void* stream);

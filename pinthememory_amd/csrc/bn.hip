@@ -168,7 +168,11 @@ __global__ __launch_bounds__(256) void bn_bwd_final(const float* __restrict__ pa
 }
 
 // Chan et al. merge of per-rank (mean | M2 | count) rows gathered over the process group: [W][3C] -> [3C], in double.
-__global__ void bn_merge_kernel(const float* __restrict__ parts, int W, int C, float* __restrict__ out) {
+// FIN: mean / invstd and the running-moment update of bn_finalize_kernel in the same launch, on the float values the two-kernel path
+// would hand over through `out` (bit-identical), so that SyncBatchNorm costs one launch less per layer.
+template <bool FIN>
+__global__ void bn_merge_kernel(const float* __restrict__ parts, int W, int C, float* __restrict__ out, float eps, float* __restrict__ mean,
+                                float* __restrict__ invstd, float* running_mean, float* running_var, float momentum) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double n = 0.0, s = 0.0;
@@ -176,13 +180,22 @@ __global__ void bn_merge_kernel(const float* __restrict__ parts, int W, int C, f
     const double cnt = parts[(long)r * 3 * C + 2 * C + c];
     n += cnt, s += cnt * (double)parts[(long)r * 3 * C + c];
   }
-  const double mean = s / n;
-  double m2 = 0.0;
+  const double gmean = s / n;
+  double m2d = 0.0;
   for (int r = 0; r < W; ++r) {
-    const double cnt = parts[(long)r * 3 * C + 2 * C + c], d = (double)parts[(long)r * 3 * C + c] - mean;
-    m2 += (double)parts[(long)r * 3 * C + C + c] + cnt * d * d;
+    const double cnt = parts[(long)r * 3 * C + 2 * C + c], d = (double)parts[(long)r * 3 * C + c] - gmean;
+    m2d += (double)parts[(long)r * 3 * C + C + c] + cnt * d * d;
   }
-  out[c] = (float)mean, out[C + c] = (float)m2, out[2 * C + c] = (float)n;
+  const float m = (float)gmean, m2 = (float)m2d, nf = (float)n;
+  if constexpr (!FIN) {
+    out[c] = m, out[C + c] = m2, out[2 * C + c] = nf;
+  } else {
+    const float var = m2 / nf;
+    mean[c] = m;
+    invstd[c] = 1.f / sqrtf(var + eps);
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (m2 / (nf - 1.f));
+  }
 }
 
 // every BatchNorm of a network folded in one launch (eval-mode forward): table[i] = {gamma, beta, running_mean, running_var} device
@@ -260,8 +273,17 @@ extern "C" int pm_bn_finalize(const float* moments, int c, float eps, float* mea
 
 extern "C" int pm_bn_merge(const float* parts, int world, int c, float* moments, void* stream) {
   PM_REQUIRE(parts && moments && world >= 1 && c > 0, PM_EINVAL, "bn_merge: bad args");
-  hipLaunchKernelGGL(bn_merge_kernel, dim3(pm_cdiv(c, 64)), dim3(64), 0, (hipStream_t)stream, parts, world, c, moments);
+  hipLaunchKernelGGL(bn_merge_kernel<false>, dim3(pm_cdiv(c, 64)), dim3(64), 0, (hipStream_t)stream, parts, world, c, moments, 0.f, (float*)nullptr,
+                     (float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f);
   return pm_check_launch("bn_merge");
+}
+
+extern "C" int pm_bn_merge_finalize(const float* parts, int world, int c, float eps, float* mean, float* invstd, float* running_mean, float* running_var,
+                                    float momentum, void* stream) {
+  PM_REQUIRE(parts && mean && invstd && world >= 1 && c > 0, PM_EINVAL, "bn_merge_finalize: bad args");
+  hipLaunchKernelGGL(bn_merge_kernel<true>, dim3(pm_cdiv(c, 64)), dim3(64), 0, (hipStream_t)stream, parts, world, c, (float*)nullptr, eps, mean, invstd,
+                     running_mean, running_var, momentum);
+  return pm_check_launch("bn_merge_finalize");
 }
 
 extern "C" int pm_bn_fold(const float* gamma, const float* beta, const float* rm, const float* rv, const float* conv_bias, int c, float eps, float* scale,

@@ -65,6 +65,19 @@ def merge_moments_list(parts, c):
     return torch.cat([gmean, gm2, n]).to(parts[0].dtype)
 
 
+def gather_moments(mom, group=None):
+    """All-gather of the per-rank [3c] moments -> (flat float[world * 3c], world)."""
+    world = dist.get_world_size(group)
+    flat = torch.empty(world * mom.numel(), dtype=mom.dtype, device=mom.device)
+    mom = mom.contiguous()
+    comm = _direct(mom, group)
+    if comm is not None:
+        comm.all_gather_into(flat, mom)
+    else:
+        dist.all_gather_into_tensor(flat, mom, group=group)
+    return flat, world
+
+
 def merge_moments(mom, c, group=None):
     """One all-gather of [3c] floats per BN layer, then one merge kernel (GPU) / a few torch ops (CPU tensors in the gloo tests)."""
     if not is_dist():

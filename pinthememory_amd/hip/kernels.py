@@ -135,6 +135,15 @@ def bn_merge(parts, world, c):
     return out
 
 
+def bn_merge_finalize(parts, world, c, eps, running_mean=None, running_var=None, momentum=0.1):
+    """bn_merge + bn_finalize in one launch: gathered per-rank moments float[world, 3c] -> (mean, invstd); running moments in place."""
+    mean = torch.empty(c, dtype=torch.float32, device=parts.device)
+    invstd = torch.empty_like(mean)
+    check(_lib().pm_bn_merge_finalize(parts.data_ptr(), world, c, eps, mean.data_ptr(), invstd.data_ptr(), ptr(running_mean), ptr(running_var), momentum,
+                                      stream()), 'pm_bn_merge_finalize')
+    return mean, invstd
+
+
 def bn_finalize(moments, c, eps, running_mean=None, running_var=None, momentum=0.1):
     mean = torch.empty(c, dtype=torch.float32, device=moments.device)
     invstd = torch.empty_like(mean)

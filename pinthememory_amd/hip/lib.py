@@ -47,6 +47,7 @@ SIGNATURES = {
     'pm_bn_workspace': (_sz, [_T]),
     'pm_bn_stats': (_i, [_T, _vp, _vp, _sz, _vp]),
     'pm_bn_merge': (_i, [_vp, _i, _i, _vp, _vp]),
+    'pm_bn_merge_finalize': (_i, [_vp, _i, _i, _f, _vp, _vp, _vp, _vp, _f, _vp]),
     'pm_bn_finalize': (_i, [_vp, _i, _f, _vp, _vp, _vp, _vp, _f, _vp]),
     'pm_bn_stats_finalize': (_i, [_T, _f, _vp, _vp, _vp, _vp, _f, _vp, _sz, _vp]),
     'pm_bn_fold': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp]),

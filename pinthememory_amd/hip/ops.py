@@ -140,8 +140,13 @@ def _bn_train_fwd(y, gamma, beta, bn, residual, relu, out=None):
     c = y.shape[3]
     if bn.group is None and BN_FUSED_FINALIZE:
         mean, invstd = K.bn_stats_finalize(y, bn.eps, bn.running_mean, bn.running_var, bn.momentum)
+    elif bn.group is not None and D.is_dist() and BN_FUSED_FINALIZE:
+        flat, world = D.gather_moments(K.bn_stats(y), bn.group)        # SyncBN: stats, all-gather, merge + finalise, apply
+        mean, invstd = K.bn_merge_finalize(flat, world, c, bn.eps, bn.running_mean, bn.running_var, bn.momentum)
     else:
-        mom = D.merge_moments(K.bn_stats(y), c, bn.group)
+        mom = K.bn_stats(y)
+        if bn.group is not None:
+            mom = D.merge_moments(mom, c, bn.group)
         mean, invstd = K.bn_finalize(mom, c, bn.eps, bn.running_mean, bn.running_var, bn.momentum)
     return K.bn_apply(y, mean, invstd, gamma, beta, residual=residual, relu=relu, out=out), mean, invstd
 

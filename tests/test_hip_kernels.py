@@ -373,6 +373,13 @@ def test_bn_merge(K):
     got = K.bn_merge(torch.stack(parts).cuda().contiguous(), 3, c).cpu()
     assert rel(got, D.merge_moments_list(parts, c)) < 1e-6
     assert rel(got[:c], x.mean((0, 2, 3))) < 1e-6 and rel(got[c:2 * c], ((x - x.mean((0, 2, 3))[None, :, None, None]) ** 2).sum((0, 2, 3))) < 1e-5
+    # merge + finalize in one launch (the SyncBN forward path) == the two separate launches, bit for bit, running moments included
+    gp = torch.stack(parts).cuda().contiguous()
+    rm1, rv1 = torch.zeros(c, device='cuda'), torch.ones(c, device='cuda')
+    rm2, rv2 = rm1.clone(), rv1.clone()
+    mean1, inv1 = K.bn_finalize(K.bn_merge(gp, 3, c), c, 1e-5, rm1, rv1, 0.1)
+    mean2, inv2 = K.bn_merge_finalize(gp, 3, c, 1e-5, rm2, rv2, 0.1)
+    assert torch.equal(mean1, mean2) and torch.equal(inv1, inv2) and torch.equal(rm1, rm2) and torch.equal(rv1, rv2)
 
 
 @pytest.mark.parametrize('case', [CONV_CASES[1], CONV_CASES[3], CONV_CASES[5], CONV_CASES[8], CONV_CASES[9], CONV_CASES[10]])
