@@ -78,6 +78,61 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const CEGeom g, float* __re
   }
 }
 
+// Row-staged forward: block = one hi-res row (Y, image b). The two low-res logit rows that row interpolates between are staged in LDS
+// once (coalesced, pre-scaled by 1/T); every hi-res pixel then gathers its 4 x C taps from LDS instead of issuing 4 x C scattered global
+// loads. The interpolation expression is the one of interp_logits / ce_bwd_rows_kernel, so the per-pixel logits carry the same bits.
+template <int C_>
+__global__ __launch_bounds__(256) void ce_fwd_rows_kernel(const CEGeom g, float* __restrict__ part) {
+  extern __shared__ float L[];
+  const int C = C_ > 0 ? C_ : g.C;
+  const int CP = C | 1;
+  const int Y = blockIdx.x % g.H, b = blockIdx.x / g.H;
+  const pm_lerp ly = pm_ac_lerp(g.sy, Y, g.h);
+  float* L0 = L;
+  float* L1 = L + (size_t)g.w * CP;
+  const int64_t* lrow = g.labels + ((long)b * g.H + Y) * g.W;
+  int64_t labs[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) labs[u] = (int)threadIdx.x + 256 * u < g.W ? lrow[threadIdx.x + 256 * u] : 255;   // in flight while the rows are staged
+  for (int i = threadIdx.x; i < g.w * C; i += 256) {
+    const int xl = i / C, c = i - xl * C;
+    L0[xl * CP + c] = g.logits[((long)(b * g.h + ly.i0) * g.w + xl) * g.lp + c] * g.inv_temp;
+    L1[xl * CP + c] = g.logits[((long)(b * g.h + ly.i1) * g.w + xl) * g.lp + c] * g.inv_temp;
+  }
+  __syncthreads();
+  float lsum = 0.f, lcnt = 0.f;
+  for (int X = threadIdx.x, u = 0; X < g.W; X += 256, ++u) {
+    const int64_t lab = u < 3 ? (u == 0 ? labs[0] : (u == 1 ? labs[1] : labs[2])) : lrow[X];
+    if (lab == 255) continue;
+    const pm_lerp lx = pm_ac_lerp(g.sx, X, g.w);
+    const float *p00 = L0 + lx.i0 * CP, *p01 = L0 + lx.i1 * CP, *p10 = L1 + lx.i0 * CP, *p11 = L1 + lx.i1 * CP;
+    float v[C_ > 0 ? C_ : MAXC];
+    float mx = -INFINITY, vl = 0.f;
+#pragma unroll
+    for (int c = 0; c < (C_ > 0 ? C_ : MAXC); ++c)
+      if (c < C) {
+        v[c] = ly.w0 * (lx.w0 * p00[c] + lx.w1 * p01[c]) + ly.w1 * (lx.w0 * p10[c] + lx.w1 * p11[c]);
+        mx = fmaxf(mx, v[c]);
+        if (c == (int)lab) vl = v[c];
+      }
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < (C_ > 0 ? C_ : MAXC); ++c)
+      if (c < C) se += __expf(v[c] - mx);   // v_exp_f32 (~1 ulp per term, as in the backward pass): the libm expf was 2/3 of this kernel's ALU work
+    lsum += (mx + logf(se)) - vl;
+    lcnt += 1.f;
+  }
+  __shared__ float sm[2][4];
+  lsum = pm_wave_sum(lsum);
+  lcnt = pm_wave_sum(lcnt);
+  if ((threadIdx.x & 63) == 0) sm[0][threadIdx.x >> 6] = lsum, sm[1][threadIdx.x >> 6] = lcnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x * 2] = sm[0][0] + sm[0][1] + sm[0][2] + sm[0][3];
+    part[blockIdx.x * 2 + 1] = sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3];
+  }
+}
+
 __global__ void ce_final_kernel(const float* __restrict__ part, int nb, float* __restrict__ out) {
   __shared__ double s[2][64];
   double a = 0.0, c = 0.0;
@@ -232,17 +287,27 @@ int fill(CEGeom& g, const pm_tensor* logits, float inv_temp, const int64_t* labe
 
 }  // namespace
 
-extern "C" size_t pm_upsample_ce_workspace(int n, int H, int W) { return pm_align_up((size_t)fwd_blocks((long)n * H * W) * 2 * sizeof(float), 256); }
+extern "C" size_t pm_upsample_ce_workspace(int n, int H, int W) {   // one (sum, count) pair per block of either forward kernel
+  return pm_align_up((size_t)std::max<long>(fwd_blocks((long)n * H * W), (long)n * H) * 2 * sizeof(float), 256);
+}
 
 extern "C" int pm_upsample_ce_fwd(const pm_tensor* logits, float inv_temp, const int64_t* labels, int H, int W, float* loss_out, void* ws, size_t ws_bytes,
                                   void* stream) {
   CEGeom g;
   if (int e = fill(g, logits, inv_temp, labels, H, W, "upsample_ce_fwd")) return e;
   PM_REQUIRE(loss_out && ws && ws_bytes >= pm_upsample_ce_workspace(g.n, H, W), PM_EWORKSPACE, "upsample_ce_fwd: workspace too small");
-  const int nb = fwd_blocks((long)g.n * H * W);
+  int nb = fwd_blocks((long)g.n * H * W);
   hipStream_t st = (hipStream_t)stream;
-  if (g.C == 19) hipLaunchKernelGGL(ce_fwd_kernel<19>, dim3(nb), dim3(256), 0, st, g, (float*)ws);
-  else hipLaunchKernelGGL(ce_fwd_kernel<0>, dim3(nb), dim3(256), 0, st, g, (float*)ws);
+  const size_t row_lds = 2 * (size_t)g.w * (g.C | 1) * sizeof(float);     // the two staged low-res rows
+  if (row_lds <= 48 * 1024 && (long)g.n * H <= (1 << 20) && W >= 32) {     // row-staged kernel: one block per hi-res row
+    nb = g.n * H;
+    if (g.C == 19) hipLaunchKernelGGL(ce_fwd_rows_kernel<19>, dim3(nb), dim3(256), row_lds, st, g, (float*)ws);
+    else hipLaunchKernelGGL(ce_fwd_rows_kernel<0>, dim3(nb), dim3(256), row_lds, st, g, (float*)ws);
+  } else if (g.C == 19) {
+    hipLaunchKernelGGL(ce_fwd_kernel<19>, dim3(nb), dim3(256), 0, st, g, (float*)ws);
+  } else {
+    hipLaunchKernelGGL(ce_fwd_kernel<0>, dim3(nb), dim3(256), 0, st, g, (float*)ws);
+  }
   hipLaunchKernelGGL(ce_final_kernel, dim3(1), dim3(64), 0, st, (const float*)ws, nb, loss_out);
   return pm_check_launch("upsample_ce_fwd");
 }
