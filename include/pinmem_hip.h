@@ -136,6 +136,10 @@ int pm_global_avgpool_bwd(const pm_tensor* dy, const pm_tensor* dx, int accumula
 /* ---- K5 bilinear resize, align_corners=True (mynn.py:57-62), fp32 index math as ATen ---------------------------- */
 int pm_resize_bilinear_fwd(const pm_tensor* x, const pm_tensor* y, void* stream);
 int pm_resize_bilinear_bwd(const pm_tensor* dy, const pm_tensor* dx, int accumulate, void* stream);
+/* the same gradient as a column pass + a row pass through a [n, H, w, c] workspace: dy is read once (up-sampling ratio >= 2 both ways,
+ * c % 4 == 0; pm_resize_bilinear_bwd_workspace returns 0 for shapes that must take the gather above) */
+size_t pm_resize_bilinear_bwd_workspace(const pm_tensor* dy, const pm_tensor* dx);
+int pm_resize_bilinear_bwd_separable(const pm_tensor* dy, const pm_tensor* dx, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- pooled multi-scale / flip evaluation (eval.py:133-145,277-337) -------------------------------------------------
  * half-pixel bilinear (F.interpolate(mode='bilinear') default, align_corners=False) of the logits to the original size;

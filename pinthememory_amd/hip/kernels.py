@@ -278,9 +278,19 @@ def resize_fwd(x, size, out=None):
     return y
 
 
-def resize_bwd(dy, x_shape):
+RESIZE_SEPARABLE = os.environ.get('PM_RESIZE_SEP', '1') == '1'      # A/B knob: 0 = gather formulation everywhere
+
+
+def resize_bwd(dy, x_shape, separable=None):
+    separable = RESIZE_SEPARABLE if separable is None else separable
     dx = new(x_shape, dy, pitch_pad=True)
-    check(_lib().pm_resize_bilinear_bwd(byref(tdesc(dy)), byref(tdesc(dx)), 0, stream()), 'pm_resize_bilinear_bwd')
+    lib, dyd, dxd = _lib(), tdesc(dy), tdesc(dx)
+    nb = lib.pm_resize_bilinear_bwd_workspace(byref(dyd), byref(dxd)) if separable else 0
+    if nb:      # up-sampling by >= 2: column pass + row pass, the large gradient is read once
+        ws = workspace(nb, dy.device)
+        check(lib.pm_resize_bilinear_bwd_separable(byref(dyd), byref(dxd), 0, ptr(ws), nb, stream()), 'pm_resize_bilinear_bwd_separable')
+    else:
+        check(lib.pm_resize_bilinear_bwd(byref(dyd), byref(dxd), 0, stream()), 'pm_resize_bilinear_bwd')
     return dx
 
 

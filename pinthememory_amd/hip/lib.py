@@ -66,6 +66,8 @@ SIGNATURES = {
     'pm_global_avgpool_bwd': (_i, [_T, _T, _i, _vp]),
     'pm_resize_bilinear_fwd': (_i, [_T, _T, _vp]),
     'pm_resize_bilinear_bwd': (_i, [_T, _T, _i, _vp]),
+    'pm_resize_bilinear_bwd_workspace': (_sz, [_T, _T]),
+    'pm_resize_bilinear_bwd_separable': (_i, [_T, _T, _i, _vp, _sz, _vp]),
     'pm_resize_bilinear_hp_fwd': (_i, [_T, _T, _i, _vp]),
     'pm_softmax_mean_update': (_i, [_T, _vp, _i, _vp]),
     'pm_argmax_f64': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),

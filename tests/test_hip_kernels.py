@@ -217,7 +217,7 @@ def test_pool_and_resize(K):
     assert rel(nchw(y), y_ref.detach()) < 1e-6
     assert rel(nchw(K.global_avgpool_bwd(nhwc(dy), (3, 7, 9, 128))), xr.grad) < 1e-6
 
-    for (shape, size) in [((2, 64, 12, 12), (48, 48)), ((2, 19, 24, 24), (96, 96)), ((2, 256, 1, 1), (12, 12)), ((1, 32, 11, 7), (30, 41)),
+    for (shape, size) in [((2, 64, 12, 12), (48, 48)), ((2, 19, 24, 24), (96, 96)), ((2, 256, 1, 1), (12, 12)), ((1, 32, 11, 7), (30, 41)), ((1, 16, 13, 18), (50, 70)),
                           ((1, 8, 10, 10), (10, 10))]:
         x = rnd(*shape, seed=5)
         xr = x.clone().requires_grad_(True)
@@ -234,8 +234,10 @@ def test_pool_and_resize(K):
             assert rel(K.resize_fwd(xs, size), y) < 1e-6
         dyg = K.new(tuple(y.shape), y, pitch_pad=True)
         dyg.copy_(nhwc(dy))
-        dx = K.resize_bwd(dyg, tuple(xg.shape))
+        dx = K.resize_bwd(dyg, tuple(xg.shape))             # separable (column pass + row pass) where the up-sampling ratio is >= 2
         assert rel(nchw(dx), xr.grad) < 1e-5, (shape, size)
+        dx_g = K.resize_bwd(dyg, tuple(xg.shape), separable=False)      # the gather formulation: same operator, other summation order
+        assert rel(nchw(dx_g), xr.grad) < 1e-5 and rel(dx, dx_g) < 2e-6, (shape, size)
 
 
 def test_layout_and_labels(K):
