@@ -85,22 +85,125 @@ def config5(a):
                       'roofline': None, 'cpu_baseline': None}), flush=True)
 
 
-def cpu_baseline(batch, size):
-    """The oracle (CPU restatement == imported reference, bit-exact) timed on this box's host cores: one agg step."""
+def physical_cores():
+    """Physical cores of the host: unique (physical id, core id) pairs of /proc/cpuinfo, capped by the CPUs this process may run on."""
+    try:
+        pairs, phys = set(), None
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('physical id'):
+                phys = line.split(':')[1].strip()
+            elif line.startswith('core id'):
+                pairs.add((phys, line.split(':')[1].strip()))
+        n = len(pairs) or os.cpu_count()
+    except OSError:
+        n = os.cpu_count()
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(batch, size, steps=2):
+    """The oracle (CPU restatement == imported reference, bit-exact) timed on this box's host cores, SURVEY 8(d): torch threads =
+    physical cores, 1 warm-up step + `steps` timed agg steps on a bounded sample of the workload (bs=2 of the bs=8 batch by default:
+    ~15 s per step on a 64-core host, so the default bench.py run stays within minutes; --cpu-batch 8 runs the full batch, ~20 GB RSS)."""
     import torch
     from oracle.ref_cpu import deeplab, harness
     from pinthememory_amd import synth
-    cores = torch.get_num_threads()
+    cores = physical_cores()
+    prev = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    cpu_model = ''
+    try:
+        cpu_model = next(l.split(':')[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name'))
+    except (OSError, StopIteration):
+        pass
     crit = torch.nn.CrossEntropyLoss(reduction='mean', ignore_index=255)
     net = synth.load_det_weights(deeplab.DeepR50V3PlusD(synth.model_args(), 19, crit, crit))
     opt, _ = harness.make_optimizer(net)
     x, y = synth.make_batch(batch, size)
     t0 = time.time()
-    harness.agg_train_step(net, opt, x, y)
-    dt = time.time() - t0
-    return {'value': batch / dt, 'unit': 'imgs/sec', 'cores': cores, 'kind': 'port',
-            'sample': '1 agg train step (fwd+bwd+SGD+memory-commit fwd), bs=%d %dx%d fp32, torch CPU oracle, %d threads, %.1f s'
-                      % (batch, size, size, cores, dt)}
+    harness.agg_train_step(net, opt, x, y)              # warm-up (allocator, oneDNN primitive caches)
+    warm = time.time() - t0
+    t0 = time.time()
+    for _ in range(steps):
+        harness.agg_train_step(net, opt, x, y)
+    dt = (time.time() - t0) / steps
+    torch.set_num_threads(prev)
+    return {'value': batch / dt, 'unit': 'imgs/sec', 'cores': cores, 'kind': 'port', 'cpu': cpu_model,
+            'sample': '1 warm-up (%.1f s) + %d timed agg train steps (fwd+bwd+SGD+memory-commit fwd) of a bs=%d sample of the bs=8 %dx%d fp32 workload, '
+                      'torch CPU oracle on %d threads = physical cores, %.1f s per step' % (warm, steps, batch, size, size, cores, dt)}
+
+
+PEAK_HBM_GBPS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured with a float4 copy)
+
+
+def memory_path_roofline(batch, size):
+    """HBM roofline of the memory path (north star: 'achieved HBM GB/s on the memory-read path'): every kernel of Memory_sup.read / write
+    and the two fused up-sample + CE losses at the workload's shapes, each launch bracketed by its own pair of HIP events on the stream
+    it is launched on (torch's current stream), algorithmic bytes per launch from SURVEY 8(d) / DESIGN section 4."""
+    import glob
+    import torch
+    from pinthememory_amd import synth
+    from pinthememory_amd.hip import kernels as K
+    B, h, d, m, H = batch, size // 16, 256, 19, size
+    N = B * h * h
+    g = torch.Generator().manual_seed(304)
+    x = torch.relu(torch.randn(B, h, h, d, generator=g)).cuda()
+    mem = synth.det_memory().cuda()
+    _, lab = synth.make_batch(B, H)
+    lab = lab.cuda()
+    qr, score, pmem = K.mem_read_fwd(x, mem)
+    dqr, dsx = torch.randn(qr.shape, generator=g).cuda(), torch.randn(score.shape, generator=g).cuda()
+    lg = score.view(B, h, h, m)
+    lo = K.upsample_ce_fwd(lg, lab, 1.0)
+    main = K.new((B, H // 4, H // 4, m), x, pitch_pad=True)
+    main.copy_(torch.randn(B, H // 4, H // 4, m, generator=g).cuda())
+    lo_main = K.upsample_ce_fwd(main, lab, 1.0)
+    z = K.mem_write_accum(x, lab, m)
+    cases = [     # (name, reference lines, algorithmic bytes per launch, launch)
+        ('mem_read_fwd', 'memory.py:317-336', N * d * 4 + m * d * 4 + N * 2 * d * 4 + 2 * N * m * 4, lambda: K.mem_read_fwd(x, mem)),
+        ('mem_read_bwd', 'memory.py:317-336 (autograd)', N * 2 * d * 4 + 2 * N * d * 4 + 2 * N * m * 4, lambda: K.mem_read_bwd(x, mem, pmem, dqr, dsx)),
+        ('mem_colsoftmax', 'memory.py:186', 2 * N * m * 4, lambda: K.mem_colsoftmax(score)),
+        ('mem_write_accum', 'memory.py:219-231', N * d * 4 + B * 4 * h * h * 8 + (m + 1) * (d + 1) * 4, lambda: K.mem_write_accum(x, lab, m)),
+        ('readloss_fwd', 'memory.py:173-176', B * H * H * 8 + N * m * 4, lambda: K.upsample_ce_fwd(lg, lab, 1.0)),
+        ('readloss_bwd', 'memory.py:173-176 (autograd)', B * H * H * 8 + 2 * N * m * 4, lambda: K.upsample_ce_bwd(lg, lab, lo, None, 1.0)),
+        ('main_ce_fwd', 'deepv3plus.py:575-578', B * H * H * 8 + B * (H // 4) ** 2 * m * 4, lambda: K.upsample_ce_fwd(main, lab, 1.0)),
+        ('main_ce_bwd', 'deepv3plus.py:575-578 (autograd)', B * H * H * 8 + 2 * B * (H // 4) ** 2 * m * 4, lambda: K.upsample_ce_bwd(main, lab, lo_main, None, 1.0)),
+    ]
+    del z
+    counters = {}
+    try:
+        pj = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_memory_path_hbm_counters.json')))[-1]
+        counters = json.load(open(pj))['kernels']          # {kernel symbol: {FETCH_SIZE_KB_per_launch, WRITE_SIZE_KB_per_launch, hbm_MB_per_launch}}
+        src = 'profiles/' + os.path.basename(pj) + ': rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of tools/mem_probe.py; read = 2 x FETCH_SIZE (gfx950)'
+    except (OSError, KeyError, ValueError, IndexError):
+        src = None
+    rows = []
+    for name, ref, nbytes, fn in cases:
+        for _ in range(3):
+            fn()
+        reps = 10
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        torch.cuda.synchronize()
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in evs)[reps // 2]          # median launch
+        rows.append({'op': name, 'replaces': ref, 'algorithmic_MB': round(nbytes / 1e6, 2), 'launch_us': round(ms * 1e3, 1),
+                     'achieved': round(nbytes / ms / 1e6, 1), 'frac': round(nbytes / ms / 1e6 / PEAK_HBM_GBPS, 4)})
+    head = dict(rows[0])
+    out = {'bound': 'hbm', 'kernel': 'mem_read_fwd (memory.py:317-336: normalise, q.M^T, softmax over slots, P.M, concat) at %d queries x 256 x 19 slots' % N,
+           'achieved': head['achieved'], 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': head['frac'], 'launch_us': head['launch_us'],
+           'algorithmic_MB': head['algorithmic_MB'],
+           'traffic': next((round(v['hbm_MB_per_launch'] * 1e6) for k, v in counters.items() if k.startswith('mem_read_fwd')), None), 'traffic_source': src,
+           'measured': 'median of 10 launches, each bracketed by its own HIP event pair on the launch stream, after the timed region; one launch may include the '
+                       'second-stage kernels of the op (fixed-order reductions)',
+           'all_memory_path_ops': rows}
+    return out
 
 
 def main():
@@ -138,6 +241,9 @@ def main():
     if multi:
         mynn.set_bnfunc(torch.nn.SyncBatchNorm)        # train.py:95 converts to SyncBN under DDP
     net = synth.load_det_weights(deepv3plus.DeepR50V3PlusD(synth.model_args(gumbel_off=False), 19, crit, crit)).to(dev)
+    if multi:                                          # train.py:95: every BatchNorm, incl. the two inside Memory_sup (memory.py:76,105)
+        net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
+        assert not any(type(m) is torch.nn.BatchNorm2d for m in net.modules())
     opt, sched = harness.make_optimizer(net)
     buckets = D.GradBuckets(net.parameters()) if multi else None
     x, y = synth.make_batch(a.batch, a.size, seed=304 + rank)          # rank r: its own 8 images (config 4)
@@ -242,6 +348,11 @@ def main():
                           'step_mfma_frac': round(gf_img * a.batch * world * a.steps / 1e3 / dt / (peak * world), 4),
                           'final_loss': round(float(losses['total']), 5)},
                'roofline': roof}
+        if roof is not None:
+            try:
+                roof['memory_read'] = memory_path_roofline(a.batch, a.size)
+            except Exception as e:      # noqa: BLE001 -- the metric line must not depend on the side measurement
+                roof['memory_read'] = {'error': repr(e)}
         if not a.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(a.cpu_batch, a.size)
         else:

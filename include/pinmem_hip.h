@@ -86,7 +86,8 @@ int pm_profile_read(int mode, int bm, int bn, int km, int nst, double* total_ms,
  * moments layout: float[3*C] = mean[C] | m2[C] | count (replicated [C]). */
 size_t pm_bn_workspace(const pm_tensor* x);
 int pm_bn_stats(const pm_tensor* x, float* moments, void* ws, size_t ws_bytes, void* stream);
-/* pm_bn_stats + pm_bn_finalize in one call for local (non-synchronised) statistics: same values, one launch less per BN layer */
+/* pm_bn_stats + pm_bn_finalize in one call for local (non-synchronised) statistics: same values, one launch less per BN layer.
+ * PM_EINVAL for a single value per channel (torch: "Expected more than 1 value per channel when training"). */
 int pm_bn_stats_finalize(const pm_tensor* x, float eps, float* mean, float* invstd, float* running_mean /*nullable*/, float* running_var /*nullable*/,
                          float momentum, void* ws, size_t ws_bytes, void* stream);
 /* SyncBatchNorm (train.py:95): exact merge of the per-rank moments gathered over the process group, parts = float[world][3*C] */
@@ -107,7 +108,9 @@ int pm_bn_apply(const pm_tensor* x, const float* mean, const float* invstd, cons
 int pm_bn_bwd_reduce(const pm_tensor* dy, const pm_tensor* y /*relu == 1 only*/, const pm_tensor* x, const float* mean, const float* invstd,
                      const float* gamma /*relu == 2 only*/, const float* beta /*relu == 2 only*/, int relu, const pm_tensor* gmask /*nullable*/,
                      float* sums, void* ws, size_t ws_bytes, void* stream);
-/* dx = gamma*invstd*(dyz - sum_dy/count - xhat*sum_dy_xhat/count); dres = dyz (nullable); count = global element count */
+/* dx = gamma*invstd*(dyz - sum_dy/count - xhat*sum_dy_xhat/count); dres = dyz (nullable); count = global element count.
+ * count <= 0: the count is read from the device at sums[2*C] (SyncBatchNorm all-reduces [sums | local count] in one exchange, so ranks
+ * with uneven batches normalise by the true global count, as torch.nn.SyncBatchNorm does). */
 int pm_bn_bwd_apply(const pm_tensor* dy, const pm_tensor* y /*relu == 1 only*/, const pm_tensor* x, const float* mean, const float* invstd,
                     const float* gamma, const float* beta /*relu == 2 only*/, const float* sums, float count, int relu, const pm_tensor* dx,
                     const pm_tensor* dres /*nullable*/, void* stream);

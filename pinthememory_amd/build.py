@@ -10,12 +10,26 @@ SOURCES = ['misc.hip', 'conv_igemm.hip', 'winograd.hip', 'bn.hip', 'pool_resize.
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast', '-Wall', '-Wno-unused-function']
 
 
+STAMP = LIB + '.stamp'
+
+
+def _fingerprint():
+    """sha256 over the flags and every source / header the library is built from. Content, not mtimes: a snapshot copied to another box
+    (gpurun) carries the prebuilt .so with arbitrary timestamps and must not be rebuilt there, while an edited source always is."""
+    import hashlib
+    h = hashlib.sha256(' '.join(FLAGS).encode())
+    for path in sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(HERE, '..', 'include', 'pinmem_hip.h')]:
+        h.update(os.path.basename(path).encode())
+        with open(path, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def _stale():
-    if not os.path.exists(LIB):
+    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, '..', 'include', 'pinmem_hip.h')]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as f:
+        return f.read().strip() != _fingerprint()
 
 
 def build(force=False, verbose=True):
@@ -34,6 +48,8 @@ def build(force=False, verbose=True):
         if p.wait() != 0:
             raise RuntimeError('hipcc failed on %s' % s)
     subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB])
+    with open(STAMP, 'w') as f:
+        f.write(_fingerprint())
     if verbose:
         print('built', LIB, file=sys.stderr)
     return LIB

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void bn_stats_final(const float* __restrict__ 
     mean[c] = m;
     invstd[c] = 1.f / sqrtf(var + eps);
     if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
-    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (m2 / (nf - 1.f));
+    if (running_var && nf > 1.f) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (m2 / (nf - 1.f));   // n == 1: no unbiased estimate (0 / 0)
   }
 }
 
@@ -109,7 +109,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ moments, int C, flo
   mean[c] = m;
   invstd[c] = 1.f / sqrtf(var + eps);
   if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
-  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (m2 / (n - 1.f));
+  if (running_var && n > 1.f) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (m2 / (n - 1.f));
 }
 
 // backward reductions: partial[blk][c][2] = sum(dyz), sum(dyz * xhat), dyz = dy masked by the ReLU of the forward pass.
@@ -194,7 +194,7 @@ __global__ void bn_merge_kernel(const float* __restrict__ parts, int W, int C, f
     mean[c] = m;
     invstd[c] = 1.f / sqrtf(var + eps);
     if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
-    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (m2 / (nf - 1.f));
+    if (running_var && nf > 1.f) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (m2 / (nf - 1.f));   // n == 1: no unbiased estimate (0 / 0)
   }
 }
 
@@ -255,6 +255,8 @@ extern "C" int pm_bn_stats_finalize(const pm_tensor* x, float eps, float* mean, 
   PM_REQUIRE(ws && ws_bytes >= pm_bn_workspace(x), PM_EWORKSPACE, "bn_stats_finalize: workspace too small");
   const long P = pm_pixels(x);
   PM_REQUIRE(P > 0, PM_EINVAL, "bn_stats_finalize: empty tensor");
+  // torch.nn.BatchNorm2d in training mode: "Expected more than 1 value per channel when training" (B = 1 through ASPP's image-pooling branch)
+  PM_REQUIRE(P > 1, PM_EINVAL, "bn_stats_finalize: expected more than 1 value per channel when training, got %ld", P);
   const int rows = chunk_rows(P, x->c), nb = pm_cdiv(P, rows);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_stats_partial, dim3(nb, pm_cdiv(x->c, CB)), dim3(256), 0, st, (const float*)x->ptr, (long)x->pitch, P, x->c, rows, (float*)ws);
@@ -361,7 +363,7 @@ extern "C" int pm_bn_bwd_apply(const pm_tensor* dy, const pm_tensor* y, const pm
   if (int e = check_bn(dy, "bn_bwd_apply")) return e;
   if (int e = check_bn(x, "bn_bwd_apply")) return e;
   if (int e = check_bn(dx, "bn_bwd_apply")) return e;
-  PM_REQUIRE(pm_same_shape(dy, x) && pm_same_shape(dx, x) && mean && invstd && gamma && sums && count > 0.f, PM_EINVAL, "bn_bwd_apply: bad args");
+  PM_REQUIRE(pm_same_shape(dy, x) && pm_same_shape(dx, x) && mean && invstd && gamma && sums, PM_EINVAL, "bn_bwd_apply: bad args");
   PM_REQUIRE(relu >= 0 && relu <= 2, PM_EINVAL, "bn_bwd_apply: relu mode %d (0 none, 1 mask from y, 2 mask rebuilt from x)", relu);
   PM_REQUIRE(relu != 1 || (y && pm_vec4(y) && pm_same_shape(y, x)), PM_EINVAL, "bn_bwd_apply: relu mode 1 needs the forward output");
   PM_REQUIRE(relu != 2 || beta, PM_EINVAL, "bn_bwd_apply: relu mode 2 needs beta");
@@ -371,8 +373,12 @@ extern "C" int pm_bn_bwd_apply(const pm_tensor* dy, const pm_tensor* y, const pm
   const long a = dy->pitch, b = relu == 1 ? y->pitch : 0, c = x->pitch, d = dx->pitch, e2 = dres ? dres->pitch : 0;
   const bool from_x = relu == 2;
   const int C = x->c;
-  const float inv_n = 1.f / count;
+  // count <= 0: the element count lives on the device at sums[2 * C] -- SyncBatchNorm all-reduces it with the two sums, so ranks with
+  // different batch sizes normalise by the true global count (torch.nn.SyncBatchNorm gathers the counts the same way)
+  const bool dev_count = !(count > 0.f);
+  const float host_inv_n = dev_count ? 0.f : 1.f / count;
   return pm_ew_launch(true, pm_pixels(x), C, (hipStream_t)stream, "bn_bwd_apply", [=] __device__(long p, int ch) {
+    const float inv_n = dev_count ? 1.f / sums[2 * C] : host_inv_n;
     float4 g = PM_LD4(pd + p * a + ch);
     if (po) {
       const float4 o = PM_LD4(po + p * b + ch);

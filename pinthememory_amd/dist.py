@@ -117,9 +117,16 @@ class GradBuckets:
     """C1: flat gradient arena + bucketed asynchronous all-reduce(mean).
 
     Parameters' .grad become views into one flat fp32 buffer (reverse registration order ~ backward order); a
-    post-accumulate hook fires a bucket's all-reduce on a side stream as soon as its last gradient is written, so
-    the exchange overlaps the rest of backward. xGMI is point-to-point: few large buckets (default 32 MiB) keep
-    every link busy without latency-bound small messages.
+    post-accumulate hook fires a bucket's all-reduce as soon as its last gradient is written. xGMI is point-to-point: few large
+    buckets (default 32 MiB) keep every link busy without latency-bound small messages.
+
+    ONE communicator per step. RCCL only guarantees progress across communicators when their kernels start in the same order on every
+    rank, which two streams do not promise -- so the buckets never run on a second communicator beside the SyncBN / memory-slot
+    exchanges. With the direct same-stream communicator (rccl.py) in use the bucket all-reduce is enqueued on the compute stream
+    through it, in program order with every other collective of the step (181 MB over 7 xGMI links is 0.3-2 ms of a ~70 ms step,
+    and the weight-gradient side stream keeps the matrix cores busy meanwhile). Without it (gloo tests, PM_DIRECT_RCCL=0, agreed
+    fall-back) every collective of the step -- these buckets and the BN / memory exchanges alike -- goes through torch's process
+    group, again one communicator; there the bucket runs asynchronously on a side stream.
     """
 
     def __init__(self, params, bucket_bytes=32 << 20, group=None):
@@ -166,7 +173,10 @@ class GradBuckets:
     def _launch(self, b):
         start, end, _ = self.buckets[b]
         chunk = self.flat[start:end]
-        if self.stream is not None:
+        comm = _direct(chunk, self.group)
+        if comm is not None:            # same communicator and stream as the BN / memory exchanges: ordered by the stream itself
+            comm.all_reduce_sum_(chunk)
+        elif self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
                 self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))

@@ -185,11 +185,14 @@ def scale_shift_act(x, scale, shift, residual=None, relu=False):
     return y
 
 
-def bn_bwd_reduce(dy, y, x, mean, invstd, relu, gamma=None, beta=None, want_gmask=False):
-    """relu: 0 / False none, 1 / True mask from the forward output y, 2 mask rebuilt from x (needs gamma, beta). -> (sums, dy * mask or None)"""
+def bn_bwd_reduce(dy, y, x, mean, invstd, relu, gamma=None, beta=None, want_gmask=False, with_count=False):
+    """relu: 0 / False none, 1 / True mask from the forward output y, 2 mask rebuilt from x (needs gamma, beta). -> (sums, dy * mask or None).
+    with_count: sums gets a third section [2c] = this rank's element count (SyncBatchNorm all-reduces it together with the sums)."""
     relu = int(relu)
     c = x.shape[3]
-    sums = torch.empty(2 * c, dtype=torch.float32, device=x.device)
+    sums = torch.empty(2 * c + (1 if with_count else 0), dtype=torch.float32, device=x.device)
+    if with_count:
+        sums[2 * c:].fill_(float(x.shape[0] * x.shape[1] * x.shape[2]))
     xd = tdesc(x)
     lib = _lib()
     nb = lib.pm_bn_workspace(byref(xd))

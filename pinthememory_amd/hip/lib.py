@@ -101,9 +101,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    if not os.environ.get('PM_LIB'):
         from .. import build as _build
-        _build.build()
+        _build.build()          # content-fingerprint gated: a no-op unless a source changed since the .so was built (never a stale binary)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the header and the library drift apart

@@ -158,16 +158,16 @@ def _bn_train_bwd(dv, o, y, mean, invstd, gamma, beta, relu, group, want_dres, h
     c = y.shape[3]
     mode = 0 if not relu else (1 if has_res else 2)
     hand_over = mode == 1 and want_dres
-    sums, gm = K.bn_bwd_reduce(dv, o, y, mean, invstd, mode, gamma, beta, want_gmask=hand_over)
+    sums, gm = K.bn_bwd_reduce(dv, o, y, mean, invstd, mode, gamma, beta, want_gmask=hand_over, with_count=group is not None)
     if group is not None:
-        sums = D.all_reduce_sum(sums, group)
-    count = float(y.shape[0] * y.shape[1] * y.shape[2]) * (D.group_size(group) if group is not None else 1)
+        sums = D.all_reduce_sum(sums, group)       # [sum dy | sum dy * xhat | count]: the global count travels with the sums (uneven batches)
+    count = float(y.shape[0] * y.shape[1] * y.shape[2]) if group is None else -1.0
     if hand_over:
         dy, _ = K.bn_bwd_apply(gm, None, y, mean, invstd, gamma, sums, count, 0, False)
         dres = gm
     else:
         dy, dres = K.bn_bwd_apply(dv, o, y, mean, invstd, gamma, sums, count, mode, want_dres, beta)
-    return dy, dres, sums[c:], sums[:c]
+    return dy, dres, sums[c:2 * c], sums[:c]
 
 
 class _Bottleneck(torch.autograd.Function):

@@ -181,7 +181,8 @@ def test_direct_rccl_communicator_one_rank():
 # ---- GPU: the whole N > 1 code path in a one-rank RCCL group must reproduce the plain single-process step bit for bit ---------------
 _STEP_PROBE = r'''
 import hashlib, os, sys, torch
-force = sys.argv[2] == '1'
+mode = sys.argv[2]                 # '0' plain single process | '1' N > 1 path with the build's GradBuckets | '2' N > 1 path under the reference's DDP wrapper
+force = mode != '0'
 if force:
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=sys.argv[1], RANK='0', WORLD_SIZE='1', PM_DIST_FORCE='1')
@@ -194,15 +195,25 @@ if force:
 crit = torch.nn.CrossEntropyLoss(reduction='mean', ignore_index=255)
 net = synth.load_det_weights(deepv3plus.DeepR50V3PlusD(synth.model_args(), 19, crit, crit)).cuda()
 net.dsn[3].p = 0.0
+if force:                          # train.py:95: every BatchNorm incl. Memory_sup's two becomes a SyncBatchNorm
+    net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
+    assert not any(type(m) is torch.nn.BatchNorm2d for m in net.modules())
+    assert sum(isinstance(m, torch.nn.SyncBatchNorm) for m in net.modules()) == 65
 opt, sched = harness.make_optimizer(net)
-buckets = D.GradBuckets(net.parameters()) if force else None
+buckets = D.GradBuckets(net.parameters()) if mode == '1' else None
+if mode == '2':                    # network/__init__.py:25-33: DistributedDataParallel(net, device_ids=[gpuid], find_unused_parameters=True)
+    from pinthememory_amd.network import warp_network_in_dataparallel
+    from pinthememory_amd.hip import ops
+    assert ops.OVERLAP_WGRAD       # the weight gradients still run on the side stream; DDP's reducer sees them after the _Defer join
+    net = warp_network_in_dataparallel(net, 0)
 x, y = synth.make_batch(2, 128)
 x, y = x.cuda(), y.cuda()
 for _ in range(2):
     out = harness.agg_train_step(net, opt, x, y, sched=sched, buckets=buckets)
 torch.cuda.synchronize()
 h = hashlib.sha256()
-for p in list(net.parameters()) + [net.memory.m_items] + [b for b in net.buffers() if b.dtype == torch.float32]:
+core = net.module if hasattr(net, 'module') else net
+for p in list(core.parameters()) + [core.memory.m_items] + [b for b in core.buffers() if b.dtype == torch.float32]:
     h.update(p.detach().float().contiguous().cpu().numpy().tobytes())
 if force:
     from pinthememory_amd import rccl
@@ -215,15 +226,17 @@ print('STEP_DIGEST', h.hexdigest(), '%.6f' % out['total'].item())
 
 @pytest.mark.gpu
 def test_one_rank_rccl_step_equals_plain_step():
-    """SyncBN moments through all-gather + merge, bucketed gradient all-reduce on the side stream, memory-slot all-reduce: with one
-    rank every exchange is the identity, so parameters, buffers and memory after two agg steps carry the same bits as the plain path."""
+    """SyncBN moments through all-gather + merge (incl. the memory's own two BatchNorms, converted as train.py:95 does), bucketed gradient
+    all-reduce on the step's single communicator, memory-slot all-reduce: with one rank every exchange is the identity, so parameters,
+    buffers and memory after two agg steps carry the same bits as the plain path -- with the build's GradBuckets (mode 1) and with the
+    network wrapped by the reference's own `warp_network_in_dataparallel` (DDP reducer over the side-stream weight gradients, mode 2)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     digests = []
-    for force in ('0', '1'):
+    for force in ('0', '1', '2'):
         r = subprocess.run([sys.executable, '-c', _STEP_PROBE, str(_free_port()), force], cwd=root, capture_output=True, text=True, timeout=600)
         lines = [l for l in r.stdout.splitlines() if l.startswith('STEP_DIGEST')]
         assert lines, r.stdout[-2000:] + r.stderr[-4000:]
         digests.append(lines[0].split()[1:])
-    assert digests[0] == digests[1], digests
+    assert digests[0] == digests[1] == digests[2], digests

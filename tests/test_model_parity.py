@@ -43,7 +43,7 @@ def test_config1_eval_forward_vs_oracle_and_golden(env, golden):
     assert (got[1][0].cpu() - want[1][0]).abs().max().item() < 1e-5          # softmax over queries
     assert (got[1][1].cpu() - want[1][1]).abs().max().item() < 1e-4          # softmax over slots
     assert (got[1][2].cpu() - want[1][2]).abs().max().item() < LOGIT_TOL
-    # bot_aspp features are O(1e3) with the deterministic weights: compare relative to their scale
+    # compared relative to the feature scale
     assert (got[2].cpu() - want[2]).abs().max().item() < 1e-5 * want[2].abs().max().item()
     g = golden('config1_v3plus_eval256.npz')                                 # captured from the imported reference
     assert np.abs(lg[:, :, ::8, ::8].numpy() - g['sub']).max() < LOGIT_TOL
@@ -81,8 +81,9 @@ def test_ragged_input_size_vs_oracle(env):
 
 def _oracle(env, dtype, x, y, step):
     """CPU oracle in `dtype` on the same inputs: fp32 is the reference's arithmetic, fp64 the ground truth that tells how
-    much of any difference is fp32 round-off (train-mode BN at tiny batch amplifies 1e-7 to percents in the trunk
-    gradients: the reference's own 1-thread and 8-thread fp32 gradients differ by 2-30 % there)."""
+    much of any difference is fp32 round-off. With the damped residual branches of synth.det_state_dict the reference's own fp32
+    gradients sit ~1e-3 (median 8e-4, worst 3e-3 at bs=2, 128^2) from the fp64 run: the floor is ReLU units within round-off of zero
+    taking the other branch, sqrt(2 p(0) eps_fwd) (tools/grad_conditioning.py); with gamma ~ 1 everywhere it was 35 %."""
     synth, o_h = env['synth'], env['o_harness']
     net = synth.load_det_weights(env['o_deeplab'].DeepR50V3PlusD(synth.model_args(), 19, CRIT, CRIT)).to(dtype)
     net.memory.m_items = net.memory.m_items.to(dtype)
@@ -127,6 +128,22 @@ def _relerr(a, b):
     return (a - b).norm().item() / (b.norm().item() + 1e-300)
 
 
+# Fixed gradient gates (relative to each tensor's norm, against the fp64 oracle). The floor under them is not the implementation but
+# fp32 itself: a ReLU unit whose pre-activation lies within the forward round-off of zero takes the other branch and changes the
+# gradient behind it; the reference's own fp32 arithmetic measures worst 3e-3 / median 8e-4 on this batch (tools/grad_conditioning.py).
+GRAD_TOL_MAX, GRAD_TOL_MEDIAN = 1e-2, 2e-3
+
+
+def _grad_stats(hip, ref, key):
+    """[(relative error, name)] of hip[key] vs ref[key] over the float tensors with a non-vanishing reference, worst first."""
+    out = []
+    for k, t in ref[key].items():
+        if t.dtype == torch.int64 or t.norm().item() < 1e-7:
+            continue
+        out.append((_relerr(hip[key][k], t), k))
+    return sorted(out, reverse=True)
+
+
 def _as_good_as_fp32(hip, o32, truth, key, floor, factor=3.0):
     """HIP must be as close to the fp64 truth as the reference's own fp32 arithmetic is (x`factor` + a round-off floor)."""
     bad = []
@@ -140,8 +157,10 @@ def _as_good_as_fp32(hip, o32, truth, key, floor, factor=3.0):
     return bad
 
 
-def test_train_forward_backward_vs_oracle(env):
-    """Train-mode forward (batch-stat BN, memory read + non-detached write) and EVERY parameter gradient."""
+def test_train_forward_backward_vs_oracle(env, capsys):
+    """Train-mode forward (batch-stat BN, memory read + non-detached write) and EVERY parameter gradient: fixed bounds against the fp64
+    oracle (every gradient within GRAD_TOL_MAX of its norm, the median within GRAD_TOL_MEDIAN, loss-fed heads within 1e-4) and, on top,
+    never further from the truth than 3x the reference's own fp32 arithmetic."""
     x, y = env['synth'].make_batch(2, 128)
     truth, o32, hip = _oracle(env, torch.float64, x, y, False), _oracle(env, torch.float32, x, y, False), _hip(env, x, y, False)
     for k, t in truth['losses'].items():
@@ -151,9 +170,14 @@ def test_train_forward_backward_vs_oracle(env):
     assert (hip['m_items'] - truth['m_items']).abs().max().item() <= 3 * e_o + 2e-6, e_o
     bad = _as_good_as_fp32(hip, o32, truth, 'grads', floor=2e-5)
     assert not bad, bad[:8]
-    # heads fed directly by a loss are well conditioned: there the fixed fp32 tolerance applies
+    st, so = _grad_stats(hip, truth, 'grads'), _grad_stats(o32, truth, 'grads')
+    with capsys.disabled():
+        print('\n[grads vs fp64, bs=2 128^2] hip: worst %s median %.2e | fp32 oracle: worst %s median %.2e'
+              % ([(round(e, 5), k) for e, k in st[:3]], st[len(st) // 2][0], [(round(e, 5), k) for e, k in so[:3]], so[len(so) // 2][0]))
+    assert st[0][0] < GRAD_TOL_MAX and st[len(st) // 2][0] < GRAD_TOL_MEDIAN, st[:6]
+    # heads fed directly by a loss see no ReLU-flip noise: fp32 round-off only
     for k in ('dsn.4.weight', 'dsn.0.weight', 'final2.0.weight', 'memory.clsfier.weight'):
-        assert _relerr(hip['grads'][k], truth['grads'][k]) < 1e-3, k
+        assert _relerr(hip['grads'][k], truth['grads'][k]) < 1e-4, k
 
 
 def test_agg_train_step_vs_oracle_and_golden(env, golden):
@@ -435,3 +459,136 @@ def test_pooled_multiscale_flip_eval_vs_oracle(env):
     top2 = None
     agree = (c.cpu() == c_ref).float().mean().item()
     assert agree > 0.999, agree
+
+
+# ---- production shapes against the oracle (VERDICT r1 "next round" item 1b / 1c) -----------------------------------------------------
+def test_config2_production_size_step_vs_oracle(env, capsys):
+    """BASELINE configs[1] at its real crop: one reference-faithful agg iteration at bs=2, 768x768 -- every layer at the map sizes it has
+    in production (192^2 / 96^2 / 48^2: all Winograd layers incl. ASPP d6 / d12 / d18 with every tap in range, final1 on 192^2) --
+    HIP vs the CPU oracle's fp32 arithmetic on the host cores: five losses to 2e-4, the committed memory to 1e-4, every post-step
+    parameter / buffer to 1e-4 of its norm, plus the 1x3x768x768 eval forward (logits < 1e-3, margin-gated argmax)."""
+    synth = env['synth']
+    x, y = synth.make_batch(2, 768)
+    o32, hip = _oracle(env, torch.float32, x, y, True), _hip(env, x, y, True)
+    for k, t in o32['losses'].items():
+        assert abs(hip['losses'][k].item() - t.item()) < 2e-4 * max(1.0, abs(t.item())), (k, hip['losses'][k].item(), t.item())
+    dm = (hip['m_items'] - o32['m_items']).abs().max().item()
+    st = _grad_stats(hip, o32, 'state')
+    with capsys.disabled():
+        print('\n[768^2 step] max|m_items - oracle| %.2e; worst post-step state rel. errors %s' % (dm, [(round(e, 6), k) for e, k in st[:4]]))
+    assert dm < 1e-4, dm
+    assert st[0][0] < 1e-4, st[:6]
+
+
+def test_config2_production_size_eval_vs_oracle(env):
+    synth = env['synth']
+    args = synth.model_args()
+    ref = synth.load_det_weights(env['o_deeplab'].DeepR50V3PlusD(args, 19, CRIT, CRIT)).eval()
+    net = synth.load_det_weights(env['deepv3plus'].DeepR50V3PlusD(args, 19, CRIT, CRIT)).cuda().eval()
+    x, _ = synth.make_batch(1, 768, seed=305)
+    with torch.no_grad():
+        want, got = ref(x), net(x.cuda())
+    lg = got[0].cpu()
+    assert lg.shape == want[0].shape == (1, 19, 768, 768)
+    assert (lg - want[0]).abs().max().item() < LOGIT_TOL
+    ok, frac, safe = argmax_gate(lg, want[0])
+    assert ok and frac > 0.9995, (frac, safe)
+    assert (got[1][1].cpu() - want[1][1]).abs().max().item() < 1e-4          # softmax over the slots, 48 x 48 queries
+    assert (got[1][0].cpu() - want[1][0]).abs().max().item() < 1e-5          # softmax over the queries
+
+
+def test_config5_real_1024_tile_vs_oracle(env):
+    """BASELINE configs[4]: one real 1 x 3 x 1024 x 1024 sliding-window tile (eval.py:379-390) through DeepR101V2D -- the 128 x 128
+    maps of output stride 8 with the d6 / d12 / d18 / d24 ASPP branches fully in range (deepv2.py:44-58) -- against the CPU oracle."""
+    synth = env['synth']
+    args = synth.model_args()
+    ref = synth.load_det_weights(env['o_deeplab'].DeepR101V2D(args, 19, CRIT, CRIT)).eval()
+    net = synth.load_det_weights(env['deepv2'].DeepR101V2D(args, 19, CRIT, CRIT)).cuda().eval()
+    x, _ = synth.make_batch(1, 1024, seed=77)
+    with torch.no_grad():
+        want, got = ref(x)[0], net(x.cuda())[0].cpu()
+    assert got.shape == want.shape == (1, 19, 1024, 1024)
+    assert (got - want).abs().max().item() < LOGIT_TOL, (got - want).abs().max().item()
+    ok, frac, safe = argmax_gate(got, want)
+    assert ok and frac > 0.9995, (frac, safe)
+
+
+# ---- SURVEY 8(f) rank 2 on the GPU: a reference-style checkpoint restored into the HIP model -----------------------------------------
+def test_reference_checkpoint_restored_on_gpu_vs_oracle(env, tmp_path):
+    """utils/misc.py:195-216 writes {'state_dict' ('module.'-prefixed), 'optimizer', 'scheduler', 'epoch', 'mean_iu', 'memory'}; the file
+    is restored (optimizer.py:45-70) into the oracle and into the HIP model from the SAME bytes. Then: identical eval logits (1e-3,
+    margin-gated argmax), the memory read from the restored m_items, and one training step continuing from the restored optimizer
+    state (momentum buffers, LR schedule position) with the same losses and post-step parameters."""
+    from pinthememory_amd import checkpoint
+    synth, o_h, h = env['synth'], env['o_harness'], env['harness']
+    args = synth.model_args()
+    x, y = synth.make_batch(2, 128, seed=21)
+    # a reference-side training run of two iterations writes the checkpoint (momentum buffers filled, scheduler advanced)
+    src = synth.load_det_weights(env['o_deeplab'].DeepR50V3PlusD(args, 19, CRIT, CRIT))
+    src.dsn[3].p = 0.0
+    opt, sched = o_h.make_optimizer(src)
+    for _ in range(2):
+        o_h.agg_train_step(src, opt, x, y, sched=sched)
+    path = str(tmp_path / 'last_cityscapes_epoch_7_mean-iu_0.43210.pth')
+    torch.save({'state_dict': {'module.' + k: v for k, v in src.state_dict().items()}, 'optimizer': opt.state_dict(), 'scheduler': sched.state_dict(),
+                'epoch': 7, 'mean_iu': 0.4321, 'memory': src.memory.m_items.detach()}, path)
+
+    ref = env['o_deeplab'].DeepR50V3PlusD(args, 19, CRIT, CRIT)
+    ref.dsn[3].p = 0.0
+    r_opt, r_sched = o_h.make_optimizer(ref)
+    ck = torch.load(path, map_location='cpu')
+    ref.load_state_dict({k[len('module.'):]: v for k, v in ck['state_dict'].items()})
+    r_opt.load_state_dict(ck['optimizer']), r_sched.load_state_dict(ck['scheduler'])
+    ref.memory.m_items = ck['memory']
+
+    net = env['deepv3plus'].DeepR50V3PlusD(args, 19, CRIT, CRIT).cuda()
+    net.dsn[3].p = 0.0
+    n_opt, n_sched = h.make_optimizer(net)
+    net, n_opt, n_sched, epoch, miou = checkpoint.restore_snapshot(net, n_opt, n_sched, path, restore_optimizer_bool=True)
+    assert (epoch, miou) == (7, 0.4321) and net.memory.m_items.is_cuda
+    assert torch.equal(net.memory.m_items.cpu(), ck['memory']) and n_sched.last_epoch == r_sched.last_epoch == 2
+    assert all(torch.equal(a.cpu(), b) for a, b in zip(net.state_dict().values(), ref.state_dict().values()))
+    assert net.final1[0].weight.permute(0, 2, 3, 1).is_contiguous()          # KRSC layout survives the restore
+
+    ref.eval(), net.eval()
+    with torch.no_grad():
+        want, got = ref(x), net(x.cuda())
+    assert (got[0].cpu() - want[0]).abs().max().item() < LOGIT_TOL
+    ok, frac, _ = argmax_gate(got[0].cpu(), want[0])
+    assert ok and frac > 0.9995
+    assert (got[1][1].cpu() - want[1][1]).abs().max().item() < 1e-4
+    lw, lg = o_h.agg_train_step(ref, r_opt, x, y, sched=r_sched), h.agg_train_step(net, n_opt, x.cuda(), y.cuda(), sched=n_sched)
+    for k in lw:
+        assert abs(lg[k].item() - lw[k].item()) < 2e-4 * max(1.0, abs(lw[k].item())), k
+    got_sd, want_sd = net.state_dict(), ref.state_dict()
+    worst = max((_relerr(got_sd[k].double().cpu(), want_sd[k].double()), k) for k in want_sd if want_sd[k].dtype != torch.int64)
+    assert worst[0] < 2e-4, worst
+    assert (net.memory.m_items.cpu() - ref.memory.m_items).abs().max().item() < 1e-4
+    assert n_opt.param_groups[0]['lr'] == r_opt.param_groups[0]['lr']
+
+
+# ---- SURVEY 8(f) rank 4: the input edge --------------------------------------------------------------------------------------------
+def test_prepare_batch_domain_merge_and_u8_edge(env):
+    """train.py:297-307: the loader hands over [B, D, 3, H, W] images / [B, D, H, W] masks (datasets/multi_loader.py:81-102); the batch the
+    network sees is the domain-merged view. `prepare_batch` must reproduce the reference's reshape order (domain index fastest within a
+    sample), and the uint8 edge (ToTensor + Normalize + MaskToTensor on the GPU, transforms/transforms.py:95-97) must give the network the
+    same tensors as the host-side fp32 pipeline: bit-equal labels, images to 1 ulp of the normalisation, same logits."""
+    h, synth = env['harness'], env['synth']
+    B, Dm, H, W = 2, 2, 64, 96
+    g = torch.Generator().manual_seed(9)
+    img_u8 = torch.randint(0, 256, (B, Dm, H, W, 3), generator=g, dtype=torch.uint8)
+    lab_u8 = torch.randint(0, 19, (B, Dm, H, W), generator=g, dtype=torch.uint8)
+    lab_u8[:, :, :4] = 255
+    mean, std = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
+    inputs = ((img_u8.float() / 255.0 - mean) / std).permute(0, 1, 4, 2, 3).contiguous()          # ToTensor + Normalize, [B, D, 3, H, W]
+    gts = lab_u8.long()                                                                          # MaskToTensor
+    x, gt, aux = h.prepare_batch(inputs, gts)
+    assert x.shape == (B * Dm, 3, H, W) and gt.shape == (B * Dm, H, W) and x.is_cuda and gt.dtype == torch.int64 and aux is gt
+    assert torch.equal(x.cpu(), inputs.view(-1, 3, H, W)) and torch.equal(gt.cpu(), gts.view(-1, H, W))       # train.py:302-305 order
+    x8, gt8 = h.prepare_batch_u8(img_u8, lab_u8)
+    assert torch.equal(gt8.cpu(), gts.view(-1, H, W))
+    assert x8.shape == (B * Dm, 4, H, W) and (x8[:, :3].cpu() - inputs.view(-1, 3, H, W)).abs().max().item() < 1e-6 and x8[:, 3].abs().max().item() == 0
+    net = synth.load_det_weights(env['deepv3plus'].DeepR50V3PlusD(synth.model_args(), 19, CRIT, CRIT)).cuda().eval()
+    with torch.no_grad():
+        a, b = net(x)[0], net(x8)[0]
+    assert (a - b).abs().max().item() < 1e-4
