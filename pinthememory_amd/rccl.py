@@ -70,12 +70,13 @@ class DirectComm:
         box = [None]                  # None = "rank 0 could not create the id": EVERY rank then raises and reaches the agreed fall-back of get()
         if self.rank == 0:
             rc = lib.ncclGetUniqueId(ctypes.byref(uid))
-            box = [bytes(uid.internal) if rc == 0 else None]
+            box = [ctypes.string_at(ctypes.addressof(uid), 128) if rc == 0 else None]     # all 128 bytes (a c_char field read stops at the first NUL)
         if self.world > 1:            # always broadcast, also after a rank-0 failure: no rank may be left waiting in it
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         if box[0] is None:
             raise RuntimeError('ncclGetUniqueId failed on rank 0')
-        ctypes.memmove(uid.internal, box[0], 128)
+        assert len(box[0]) == 128
+        ctypes.memmove(ctypes.addressof(uid), box[0], 128)
         self.comm = ctypes.c_void_p()
         _check(lib.ncclCommInitRank(ctypes.byref(self.comm), self.world, uid, self.rank), 'ncclCommInitRank')
 

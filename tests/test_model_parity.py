@@ -168,12 +168,12 @@ def test_train_forward_backward_vs_oracle(env, capsys):
         assert abs(hip['losses'][k].item() - o32['losses'][k].item()) < 2e-4 * max(1, abs(t.item())), k
     e_o = (o32['m_items'] - truth['m_items']).abs().max().item()
     assert (hip['m_items'] - truth['m_items']).abs().max().item() <= 3 * e_o + 2e-6, e_o
-    bad = _as_good_as_fp32(hip, o32, truth, 'grads', floor=2e-5)
-    assert not bad, bad[:8]
     st, so = _grad_stats(hip, truth, 'grads'), _grad_stats(o32, truth, 'grads')
     with capsys.disabled():
         print('\n[grads vs fp64, bs=2 128^2] hip: worst %s median %.2e | fp32 oracle: worst %s median %.2e'
               % ([(round(e, 5), k) for e, k in st[:3]], st[len(st) // 2][0], [(round(e, 5), k) for e, k in so[:3]], so[len(so) // 2][0]))
+    bad = _as_good_as_fp32(hip, o32, truth, 'grads', floor=GRAD_TOL_MEDIAN)
+    assert not bad, bad[:8]
     assert st[0][0] < GRAD_TOL_MAX and st[len(st) // 2][0] < GRAD_TOL_MEDIAN, st[:6]
     # heads fed directly by a loss see no ReLU-flip noise: fp32 round-off only
     for k in ('dsn.4.weight', 'dsn.0.weight', 'final2.0.weight', 'memory.clsfier.weight'):
