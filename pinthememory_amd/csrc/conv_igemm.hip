@@ -92,6 +92,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   constexpr bool A_KC = (MODE != MODE_WGRAD);  // A tile stored [BM][LDK] (k contiguous) else [BK][BM]
   constexpr bool B_KC = (MODE == MODE_FWD);    // B tile stored [BN][LDK] else [BK][BN]
   constexpr bool FAST = (KM == K_FAST) && (MODE != MODE_WGRAD);
+  // TR: MFMA operands swapped, every 32x32 tile is accumulated transposed and stored with 16-byte vectors (see the epilogue). Taken for the
+  // data gradient, whose epilogue is the busiest (dx, usually with the fused skip-gradient read): +10...+20 % on its layer1 / layer2
+  // launches; forward and weight-gradient tiles measured 3-15 % slower that way (32-byte pieces of 32 rows per store instruction: twice
+  // the L1 -> L2 write requests of the 2 x 128-byte row form) and keep the row form.
+  constexpr bool TR = (MODE == MODE_DGRAD);
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_FLOATS = A_KC ? BM * LDK : BK * BM;
   constexpr int B_FLOATS = B_KC ? BN * LDK : BK * BN;
@@ -405,7 +410,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int n = 0; n < TN; ++n)
-            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[n][j], acc[i][n], 0, 0, 0);
+            acc[i][n] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(fb[n][j], fa[i][j], acc[i][n], 0, 0, 0)      // tile held transposed (see the epilogue)
+                           : __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[n][j], acc[i][n], 0, 0, 0);
     } else {
       if (kg & 1) return;                       // bf16: two 16-k blocks per slab, issued on the even groups
       const int kk = (kg >> 1) * 16 + half * 8;  // this lane-half's 8 consecutive k of the 16-k block
@@ -441,7 +447,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int n = 0; n < TN; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[n], acc[i][n], 0, 0, 0);
+        for (int n = 0; n < TN; ++n)
+          acc[i][n] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[n], fa[i], acc[i][n], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[n], acc[i][n], 0, 0, 0);
     }
   };
   auto compute = [&](int buf) {
@@ -499,32 +506,113 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   }
 
   // ---- epilogue -------------------------------------------------------------------------------------------------
+  if constexpr (!TR) {   // row form: a lane holds one output column and 16 rows of it (the MFMA's native C layout)
+    float* Cb = a.C + by * a.c_bs + (a.ksplit > 1 ? (long)z * a.c_split : 0);
+    const bool plain = a.ksplit > 1 || !(a.bias || a.scale || a.residual || a.relu);
+    const bool full = m0 + BM <= a.M && n0 + BN <= a.Nn;
+    const int rbase = m0 + wm * (BM / WM) + 4 * half, cbase = n0 + wn * (BN / WN) + l31;
+    if (full) {  // interior tile: straight-line epilogue specialised on the (wave-uniform) fused operations, no per-element predicate
+      auto run = [&](auto AFF, auto RES, auto RELU) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int n = 0; n < TN; ++n) {
+            const int col = cbase + n * 32;
+            float bi = 0.f, sc = 1.f, sh = 0.f;
+            if constexpr (decltype(AFF)::value) {
+              if (a.bias) bi = a.bias[col];
+              if (a.scale) sc = a.scale[col], sh = a.shift[col];
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              const long row = rbase + i * 32 + (q & 3) + 8 * (q >> 2);
+              float v = acc[i][n][q];
+              if constexpr (decltype(AFF)::value) v = (v + bi) * sc + sh;
+              if constexpr (decltype(RES)::value) v += a.residual[row * a.res_pitch + col];
+              if constexpr (decltype(RELU)::value) v = fmaxf(v, 0.f);
+              Cb[row * a.c_pitch + col] = v;
+            }
+          }
+      };
+      using T1 = std::true_type;
+      using T0 = std::false_type;
+      const bool aff = !plain && (a.bias || a.scale), res = !plain && a.residual, relu = !plain && a.relu;
+      if (!aff && !res && !relu) run(T0{}, T0{}, T0{});
+      else if (!aff && res && !relu) run(T0{}, T1{}, T0{});       // dgrad + fused skip gradient
+      else if (aff && !res && !relu) run(T1{}, T0{}, T0{});       // conv + bias
+      else if (aff && !res && relu) run(T1{}, T0{}, T1{});        // eval: conv + folded BN + ReLU
+      else if (aff && res && relu) run(T1{}, T1{}, T1{});         // eval: bottleneck tail
+      else if (aff && res && !relu) run(T1{}, T1{}, T0{});
+      else if (!aff && res && relu) run(T0{}, T1{}, T1{});
+      else run(T0{}, T0{}, T1{});
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int n = 0; n < TN; ++n) {
+        const int col = cbase + n * 32;
+        const bool cok = col < a.Nn;
+        float bi = 0.f, sc = 1.f, sh = 0.f;
+        if (!plain && cok) {
+          if (a.bias) bi = a.bias[col];
+          if (a.scale) sc = a.scale[col], sh = a.shift[col];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = rbase + i * 32 + (q & 3) + 8 * (q >> 2);
+          if (row < a.M && cok) {
+            float v = acc[i][n][q];
+            if (!plain) {
+              v = (v + bi) * sc + sh;
+              if (a.residual) v += a.residual[(long)row * a.res_pitch + col];
+              if (a.relu) v = fmaxf(v, 0.f);
+            }
+            Cb[(long)row * a.c_pitch + col] = v;
+          }
+        }
+      }
+    return;
+  } else {
+    // Data gradient: the MFMAs ran with their operands swapped (D' = B-fragment x A-fragment = the 32x32 tile TRANSPOSED), so a lane
+    // holds ONE output row (m = lane & 31) and, per register quad g, FOUR CONSECUTIVE output columns 8 g + 4 (lane >> 5) + (0..3): every
+    // store (and every load of the fused skip gradient) is a 16-byte vector -- 16 + 16 memory instructions per lane and tile instead of
+    // 64 + 64. The products and the k order of every sum are unchanged: bit-identical to the row form.
   float* Cb = a.C + by * a.c_bs + (a.ksplit > 1 ? (long)z * a.c_split : 0);
   const bool plain = a.ksplit > 1 || !(a.bias || a.scale || a.residual || a.relu);
   const bool full = m0 + BM <= a.M && n0 + BN <= a.Nn;
-  const int rbase = m0 + wm * (BM / WM) + 4 * half, cbase = n0 + wn * (BN / WN) + l31;
-  if (full) {  // interior tile: straight-line epilogue specialised on the (wave-uniform) fused operations, no per-element predicate
+  const int rbase = m0 + wm * (BM / WM) + l31, cbase = n0 + wn * (BN / WN) + 4 * half;
+  // 16-byte path: rows of C (and of the residual) 16-byte aligned, column count a multiple of four (a quad is then all in or all out)
+  const bool vec = ((a.c_pitch | a.Nn | (a.residual ? a.res_pitch : 0)) & 3) == 0 && ((reinterpret_cast<uintptr_t>(Cb) | reinterpret_cast<uintptr_t>(a.residual)) & 15) == 0;
+  if (full && vec) {  // interior tile: straight-line epilogue specialised on the (wave-uniform) fused operations, no per-element predicate
     auto run = [&](auto AFF, auto RES, auto RELU) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i) {
+        const long row = rbase + i * 32;
 #pragma unroll
-        for (int n = 0; n < TN; ++n) {
-          const int col = cbase + n * 32;
-          float bi = 0.f, sc = 1.f, sh = 0.f;
-          if constexpr (decltype(AFF)::value) {
-            if (a.bias) bi = a.bias[col];
-            if (a.scale) sc = a.scale[col], sh = a.shift[col];
-          }
+        for (int n = 0; n < TN; ++n)
 #pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            const long row = rbase + i * 32 + (q & 3) + 8 * (q >> 2);
-            float v = acc[i][n][q];
-            if constexpr (decltype(AFF)::value) v = (v + bi) * sc + sh;
-            if constexpr (decltype(RES)::value) v += a.residual[row * a.res_pitch + col];
-            if constexpr (decltype(RELU)::value) v = fmaxf(v, 0.f);
-            Cb[row * a.c_pitch + col] = v;
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int col = cbase + n * 32 + 8 * g4;
+            float v[4] = {acc[i][n][4 * g4], acc[i][n][4 * g4 + 1], acc[i][n][4 * g4 + 2], acc[i][n][4 * g4 + 3]};
+            if constexpr (decltype(AFF)::value) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                if (a.bias) v[e] += a.bias[col + e];
+                if (a.scale) v[e] = v[e] * a.scale[col + e] + a.shift[col + e];
+              }
+            }
+            if constexpr (decltype(RES)::value) {
+              const float4 q = PM_LD4(a.residual + row * a.res_pitch + col);
+              v[0] += q.x, v[1] += q.y, v[2] += q.z, v[3] += q.w;
+            }
+            if constexpr (decltype(RELU)::value) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            PM_ST4(Cb + row * a.c_pitch + col, make_float4(v[0], v[1], v[2], v[3]));
           }
-        }
+      }
     };
     using T1 = std::true_type;
     using T0 = std::false_type;
@@ -540,30 +628,35 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
     return;
   }
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < TM; ++i) {
+    const int row = rbase + i * 32;
+    if (row >= a.M) continue;
 #pragma unroll
-    for (int n = 0; n < TN; ++n) {
-      const int col = cbase + n * 32;
-      const bool cok = col < a.Nn;
-      float bi = 0.f, sc = 1.f, sh = 0.f;
-      if (!plain && cok) {
-        if (a.bias) bi = a.bias[col];
-        if (a.scale) sc = a.scale[col], sh = a.shift[col];
-      }
+    for (int n = 0; n < TN; ++n)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = rbase + i * 32 + (q & 3) + 8 * (q >> 2);
-        if (row < a.M && cok) {
-          float v = acc[i][n][q];
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int col = cbase + n * 32 + 8 * g4;
+        float v[4] = {acc[i][n][4 * g4], acc[i][n][4 * g4 + 1], acc[i][n][4 * g4 + 2], acc[i][n][4 * g4 + 3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (col + e >= a.Nn) continue;
           if (!plain) {
-            v = (v + bi) * sc + sh;
-            if (a.residual) v += a.residual[(long)row * a.res_pitch + col];
-            if (a.relu) v = fmaxf(v, 0.f);
+            const float bi = a.bias ? a.bias[col + e] : 0.f, sc = a.scale ? a.scale[col + e] : 1.f, sh = a.scale ? a.shift[col + e] : 0.f;
+            v[e] = (v[e] + bi) * sc + sh;
+            if (a.residual) v[e] += a.residual[(long)row * a.res_pitch + col + e];
+            if (a.relu) v[e] = fmaxf(v[e], 0.f);
           }
-          Cb[(long)row * a.c_pitch + col] = v;
+        }
+        if (vec) {
+          if (col < a.Nn) PM_ST4(Cb + (long)row * a.c_pitch + col, make_float4(v[0], v[1], v[2], v[3]));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (col + e < a.Nn) Cb[(long)row * a.c_pitch + col + e] = v[e];
         }
       }
-    }
+  }
+  }
 }
 
 // split-K combine: C[row][col] = epilogue( sum_z ws[z][row][col] ), fixed z order (deterministic).

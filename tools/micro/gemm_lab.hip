@@ -1,0 +1,330 @@
+// GEMM laboratory (GPU box): C[b][M][N] = A[b][M][K] * B[b][N][K]^T, fp32 MFMA 32x32x2, the pointwise fast path of conv_igemm.hip
+// (every 1x1 convolution and every batched Winograd GEMM) rebuilt with compile-time knobs so that the cost of each phase can be
+// isolated on the real shapes:  hipcc --offload-arch=gfx950 -O3 -std=c++17 gemm_lab.hip -o gemm_lab && ./gemm_lab
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include <algorithm>
+#include <string>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+__device__ __forceinline__ float4 bload(__amdgpu_buffer_rsrc_t r, int off) {
+  const v4f v = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+// knobs
+//  BM, BN      block tile (4 waves as 2 x 2, each wave (BM/2) x (BN/2))
+//  BKK         K-slab per LDS stage (32 / 64)
+//  NST         LDS stages (1: two barriers per slab, 2: one)
+//  PERSIST     0: one tile per block; 1: persistent blocks, next tile's first slab prefetched under the epilogue
+//  ABL         ablation: 0 full | 1 no global loads | 2 no epilogue stores | 3 no loads + no stores | 4 no MFMA
+template <int BM, int BN, int BKK, int NST, int PERSIST, int ABL, int MINW, int TR = 0, int PF2 = 0>
+__global__ __launch_bounds__(256, MINW) void gemm_lab(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K,
+                                                      long a_bs, long b_bs, long c_bs, int tiles_m, int tiles_n, int batch) {
+  constexpr int LDK = BKK + 4;
+  constexpr int KG = BKK / 4;          // float4 groups per row
+  constexpr int RP = 256 / KG;         // rows per pass
+  constexpr int A_N = BM / RP, B_N = BN / RP;
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int A_FLOATS = BM * LDK, B_FLOATS = BN * LDK, STAGE = A_FLOATS + B_FLOATS;
+  extern __shared__ __align__(16) float smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+  const int g = t % KG, r = t / KG;
+  const int ntile = tiles_m * tiles_n;
+  const int total = ntile * batch;
+  float4 ra[A_N], rb[B_N], ra2[A_N], rb2[B_N];
+  f32x16 acc[TM][TN];
+
+  auto tile_of = [&](int w, int& m0, int& n0, int& by) {
+    by = w / ntile;
+    const int lid = PERSIST ? (w - by * ntile) : xcd_remap(w - by * ntile, ntile);
+    m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
+  };
+  auto issue_into = [&](float4 (&ra)[A_N], float4 (&rb)[B_N], int m0, int n0, int by, int k0) {
+    if (ABL == 1 || ABL == 3) return;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + by * a_bs), 0, M * K * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B + by * b_bs), 0, N * K * 4, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < A_N; ++i) {
+      const int m = m0 + r + RP * i;
+      ra[i] = bload(rA, m < M ? (m * K + k0 + g * 4) * 4 : 0x7fffffff);
+    }
+#pragma unroll
+    for (int i = 0; i < B_N; ++i) {
+      const int n = n0 + r + RP * i;
+      rb[i] = bload(rB, n < N ? (n * K + k0 + g * 4) * 4 : 0x7fffffff);
+    }
+  };
+  auto issue = [&](int m0, int n0, int by, int k0) { issue_into(ra, rb, m0, n0, by, k0); };
+  auto stash_from = [&](float4 (&ra)[A_N], float4 (&rb)[B_N], int buf) {
+    float* As = smem + buf * STAGE;
+    float* Bs = As + A_FLOATS;
+#pragma unroll
+    for (int i = 0; i < A_N; ++i) *reinterpret_cast<float4*>(As + (r + RP * i) * LDK + g * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_N; ++i) *reinterpret_cast<float4*>(Bs + (r + RP * i) * LDK + g * 4) = rb[i];
+  };
+  auto stash = [&](int buf) { stash_from(ra, rb, buf); };
+  auto compute = [&](int buf) {
+    const float* As = smem + buf * STAGE;
+    const float* Bs = As + A_FLOATS;
+#pragma unroll
+    for (int kg = 0; kg < BKK / 8; ++kg) {
+      const int kk = kg * 8 + half * 4;
+      float4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4*>(As + (wm * (BM / 2) + i * 32 + l31) * LDK + kk);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) fb[i] = *reinterpret_cast<const float4*>(Bs + (wn * (BN / 2) + i * 32 + l31) * LDK + kk);
+      if (ABL == 4) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa[i].x), "v"(fa[i].y), "v"(fa[i].z), "v"(fa[i].w));
+#pragma unroll
+        for (int i = 0; i < TN; ++i) asm volatile("" ::"v"(fb[i].x), "v"(fb[i].y), "v"(fb[i].z), "v"(fb[i].w));
+        continue;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int n = 0; n < TN; ++n) {
+            const float a = j == 0 ? fa[i].x : (j == 1 ? fa[i].y : (j == 2 ? fa[i].z : fa[i].w));
+            const float b = j == 0 ? fb[n].x : (j == 1 ? fb[n].y : (j == 2 ? fb[n].z : fb[n].w));
+            acc[i][n] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc[i][n], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][n], 0, 0, 0);
+          }
+    }
+  };
+  auto zero = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+  };
+  auto epilogue = [&](int m0, int n0, int by) {
+    float* Cb = C + by * c_bs;
+    if (TR) {   // D' = (C tile)^T: lane l31 = row m, registers 4g..4g+3 = columns 8g + 4 half + (0..3): one 16-byte store each
+      const int row0 = m0 + wm * (BM / 2) + l31, col0 = n0 + wn * (BN / 2) + 4 * half;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int row = row0 + i * 32, col = col0 + n * 32 + 8 * g4;
+            const float4 v = make_float4(acc[i][n][4 * g4], acc[i][n][4 * g4 + 1], acc[i][n][4 * g4 + 2], acc[i][n][4 * g4 + 3]);
+            if (ABL == 2 || ABL == 3) asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+            else if (row < M && col < N) *reinterpret_cast<float4*>(Cb + (long)row * N + col) = v;
+          }
+      return;
+    }
+    const int rbase = m0 + wm * (BM / 2) + 4 * half, cbase = n0 + wn * (BN / 2) + l31;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int n = 0; n < TN; ++n) {
+        const int col = cbase + n * 32;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = rbase + i * 32 + (q & 3) + 8 * (q >> 2);
+          if (ABL == 2 || ABL == 3) asm volatile("" ::"v"(acc[i][n][q]));
+          else if (row < M && col < N) Cb[(long)row * N + col] = acc[i][n][q];
+        }
+      }
+  };
+
+  const int nk = K / BKK;
+  if (!PERSIST) {
+    int m0, n0, by;
+    tile_of(blockIdx.x, m0, n0, by);
+    zero();
+    issue(m0, n0, by, 0);
+    stash(0);
+    __syncthreads();
+    if (NST == 1 && PF2) {      // loads run two slabs ahead of the MFMAs (two register sets, loop unrolled by two)
+      if (nk > 1) issue_into(ra2, rb2, m0, n0, by, BKK);
+      int kt = 0;
+      for (; kt + 2 < nk; kt += 2) {
+        issue_into(ra, rb, m0, n0, by, (kt + 2) * BKK);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(0);
+        __syncthreads();
+        stash_from(ra2, rb2, 0);
+        __syncthreads();
+        if (kt + 3 < nk) issue_into(ra2, rb2, m0, n0, by, (kt + 3) * BKK);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(0);
+        __syncthreads();
+        stash_from(ra, rb, 0);
+        __syncthreads();
+      }
+      if (kt + 1 < nk) {       // nk even: slab nk-1 is still in ra2
+        compute(0);
+        __syncthreads();
+        stash_from(ra2, rb2, 0);
+        __syncthreads();
+      }
+      compute(0);
+    } else if (NST == 1) {
+      for (int kt = 0; kt < nk - 1; ++kt) {
+        issue(m0, n0, by, (kt + 1) * BKK);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(0);
+        __syncthreads();
+        stash(0);
+        __syncthreads();
+      }
+      compute(0);
+    } else {
+      for (int kt = 0; kt < nk - 1; ++kt) {
+        issue(m0, n0, by, (kt + 1) * BKK);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(kt & 1);
+        stash((kt + 1) & 1);
+        __syncthreads();
+      }
+      compute((nk - 1) & 1);
+    }
+    epilogue(m0, n0, by);
+  } else {
+    // persistent: block b walks tiles b, b + G, ...; consecutive blocks take consecutive tiles (same A row panel -> same XCD L2 is lost,
+    // the tile order is XCD-strided instead); the first slab of the next tile is in flight while the epilogue stores
+    int w = blockIdx.x;
+    if (w >= total) return;
+    int m0, n0, by;
+    tile_of(w, m0, n0, by);
+    issue(m0, n0, by, 0);
+    while (true) {
+      zero();
+      stash(0);
+      __syncthreads();
+      for (int kt = 0; kt < nk - 1; ++kt) {
+        issue(m0, n0, by, (kt + 1) * BKK);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(NST == 1 ? 0 : (kt & 1));
+        if (NST == 1) __syncthreads();
+        stash(NST == 1 ? 0 : ((kt + 1) & 1));
+        __syncthreads();
+      }
+      const int wn_ = w + gridDim.x;
+      int m1 = 0, n1 = 0, b1 = 0;
+      if (wn_ < total) {
+        tile_of(wn_, m1, n1, b1);
+        issue(m1, n1, b1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      compute(NST == 1 ? 0 : ((nk - 1) & 1));
+      epilogue(m0, n0, by);
+      if (wn_ >= total) break;
+      __syncthreads();      // everyone is done reading the last slab before the next tile's first stash
+      w = wn_, m0 = m1, n0 = n1, by = b1;
+    }
+  }
+}
+
+struct Shape { const char* name; int M, N, K, batch; };
+
+template <int BM, int BN, int BKK, int NST, int PERSIST, int ABL, int MINW, int TR = 0, int PF2 = 0>
+double run(const Shape& s, const float* A, const float* B, float* C, int per_cu, int iters = 20, size_t extra_lds = 0) {
+  const int tiles_m = (s.M + BM - 1) / BM, tiles_n = (s.N + BN - 1) / BN;
+  const int total = tiles_m * tiles_n * s.batch;
+  const size_t smem = (size_t)NST * (BM + BN) * (BKK + 4) * sizeof(float) + extra_lds;
+  auto kern = gemm_lab<BM, BN, BKK, NST, PERSIST, ABL, MINW, TR, PF2>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  const int grid = PERSIST ? std::min(total, 256 * per_cu) : total;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, 0, A, B, C, s.M, s.N, s.K, (long)s.M * s.K, (long)s.N * s.K, (long)s.M * s.N, tiles_m, tiles_n, s.batch);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < iters; ++i)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, 0, A, B, C, s.M, s.N, s.K, (long)s.M * s.K, (long)s.N * s.K, (long)s.M * s.N, tiles_m, tiles_n, s.batch);
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  CK(hipGetLastError());
+  return ms / iters * 1e3;   // us
+}
+
+static void fill(float* d, size_t n, unsigned seed) {
+  std::vector<float> h(n);
+  unsigned x = seed * 2654435761u + 12345u;
+  for (size_t i = 0; i < n; ++i) { x = x * 1664525u + 1013904223u; h[i] = ((x >> 8) & 0xffff) / 32768.f - 1.f; }
+  CK(hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
+}
+
+static double check(const Shape& s, const float* dA, const float* dB, const float* dC) {
+  // spot check 64 outputs of batch 0 and the last batch against a double dot product
+  std::vector<float> hA((size_t)s.M * s.K), hB((size_t)s.N * s.K), hC((size_t)s.M * s.N);
+  double worst = 0;
+  for (int b : {0, s.batch - 1}) {
+    CK(hipMemcpy(hA.data(), dA + (size_t)b * s.M * s.K, hA.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hB.data(), dB + (size_t)b * s.N * s.K, hB.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hC.data(), dC + (size_t)b * s.M * s.N, hC.size() * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 64; ++i) {
+      const int m = (int)((i * 2654435761u) % (unsigned)s.M), n = (int)((i * 40503u + 7) % (unsigned)s.N);
+      double ref = 0;
+      for (int k = 0; k < s.K; ++k) ref += (double)hA[(size_t)m * s.K + k] * hB[(size_t)n * s.K + k];
+      worst = std::max(worst, std::abs(ref - hC[(size_t)m * s.N + n]));
+    }
+  }
+  return worst;
+}
+
+int main(int argc, char** argv) {
+  const Shape shapes[] = {
+      {"wino 256->256 @48 (b36)", 18432, 256, 256, 36},      // final1.3 / layer3 conv2 class
+      {"wino 512->512 @48 d2 (b36)", 1152, 512, 512, 36},     // layer4 conv2
+      {"wino 2048->256 (b36)", 1152, 256, 2048, 36},          // ASPP d6/d12
+      {"1x1 512->2048 @48", 18432, 2048, 512, 1},             // layer4 conv3
+      {"1x1 1024->256 @48", 18432, 256, 1024, 1},             // layer3 conv1
+      {"1x1 64->256 @192", 294912, 256, 64, 1},               // layer1 conv3 (HBM-bound)
+  };
+  size_t maxA = 0, maxB = 0, maxC = 0;
+  for (const Shape& s : shapes) {
+    maxA = std::max(maxA, (size_t)s.M * s.K * s.batch), maxB = std::max(maxB, (size_t)s.N * s.K * s.batch), maxC = std::max(maxC, (size_t)s.M * s.N * s.batch);
+  }
+  float *A, *B, *C;
+  CK(hipMalloc(&A, maxA * 4)); CK(hipMalloc(&B, maxB * 4)); CK(hipMalloc(&C, maxC * 4));
+  fill(A, maxA, 1); fill(B, maxB, 2);
+  printf("%-30s %-44s %9s %8s\n", "shape", "variant", "us", "TF");
+  for (const Shape& s : shapes) {
+    const double fl = 2.0 * s.M * s.N * s.K * s.batch;
+    auto rep = [&](const char* v, double us) { printf("%-30s %-44s %9.1f %8.1f\n", s.name, v, us, fl / us * 1e-6); fflush(stdout); };
+    rep("128x128 nst1 (production)", run<128, 128, 32, 1, 0, 0, 2>(s, A, B, C, 0));
+    rep("128x128 nst1 occ2", run<128, 128, 32, 1, 0, 0, 2>(s, A, B, C, 0, 20, 20000));
+    rep("128x128 nst1 TR (float4 stores)", run<128, 128, 32, 1, 0, 0, 2, 1>(s, A, B, C, 0));
+    printf("   max |err| vs fp64 dot: %.3g\n", check(s, A, B, C));
+    rep("128x128 nst1 TR occ2", run<128, 128, 32, 1, 0, 0, 2, 1>(s, A, B, C, 0, 20, 20000));
+    rep("128x128 nst1 TR PF2", run<128, 128, 32, 1, 0, 0, 2, 1, 1>(s, A, B, C, 0));
+    printf("   max |err| vs fp64 dot: %.3g\n", check(s, A, B, C));
+    rep("128x128 nst1 PF2", run<128, 128, 32, 1, 0, 0, 2, 0, 1>(s, A, B, C, 0));
+    rep("128x128 nst1 TR persistent x2", run<128, 128, 32, 1, 1, 0, 2, 1>(s, A, B, C, 2));
+    printf("   max |err| vs fp64 dot: %.3g\n", check(s, A, B, C));
+    rep("128x128 nst1 TR persistent x3", run<128, 128, 32, 1, 1, 0, 2, 1>(s, A, B, C, 3));
+    rep("128x128 nst2 TR persistent x2", run<128, 128, 32, 2, 1, 0, 2, 1>(s, A, B, C, 2));
+    rep("64x64 nst1 (production 1x1)", run<64, 64, 32, 1, 0, 0, 2>(s, A, B, C, 0));
+    rep("64x64 nst1 TR", run<64, 64, 32, 1, 0, 0, 2, 1>(s, A, B, C, 0));
+    rep("64x64 nst1 TR occ5", run<64, 64, 32, 1, 0, 0, 2, 1>(s, A, B, C, 0, 20, 10000));
+    rep("64x64 nst1 TR PF2", run<64, 64, 32, 1, 0, 0, 2, 1, 1>(s, A, B, C, 0));
+    rep("64x128 nst1 TR", run<64, 128, 32, 1, 0, 0, 2, 1>(s, A, B, C, 0));
+    rep("128x64 nst1 TR", run<128, 64, 32, 1, 0, 0, 2, 1>(s, A, B, C, 0));
+    rep("128x128 nst1 TR no-loads", run<128, 128, 32, 1, 0, 1, 2, 1>(s, A, B, C, 0));
+  }
+  return 0;
+}
