@@ -37,8 +37,10 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=2)
     ap.add_argument('--no-profile', action='store_true', help='do not bracket conv launches with HIP events')
-    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
-                    help='f32 = BASELINE configs[1] (the metric; default). bf16 = configs[2]: conv operands rounded to bf16 for the bf16 MFMA, fp32 accumulate/storage')
+    ap.add_argument('--dtype', choices=['f32', 'bf16', 'bf16_staged'], default='f32',
+                    help='f32 = BASELINE configs[1] (the metric; default). bf16 = configs[2]: every convolution converts its operands to bf16 in HBM, bf16 LDS tiles '
+                         '(64 k per row), bf16 MFMA with fp32 accumulation; activations between layers stay fp32. bf16_staged = the first form of that tier '
+                         '(fp32 tiles in LDS rounded per fragment), kept for A/B')
     ap.add_argument('--workload', choices=['train', 'config5'], default='train',
                     help="train = the metric (default). config5 = side measurement of BASELINE configs[4]: ResNet-101 DeepLabV2 sliding-window "
                          "evaluation of 1024x2048 images (crop 1024, overlap 1/3 -> 3 tiles x 2 flips, eval.py:148-274), single GPU")
@@ -237,7 +239,8 @@ def main():
     from pinthememory_amd.network import deepv3plus, mynn
     crit = torch.nn.CrossEntropyLoss(reduction='mean', ignore_index=255)
     K.set_conv_precision(a.dtype)
-    peak = PEAK_TFLOPS_BF16_MFMA if a.dtype == 'bf16' else PEAK_TFLOPS_F32_MFMA
+    bf16 = a.dtype != 'f32'
+    peak = PEAK_TFLOPS_BF16_MFMA if bf16 else PEAK_TFLOPS_F32_MFMA
     if multi:
         mynn.set_bnfunc(torch.nn.SyncBatchNorm)        # train.py:95 converts to SyncBN under DDP
     net = synth.load_det_weights(deepv3plus.DeepR50V3PlusD(synth.model_args(gumbel_off=False), 19, crit, crit)).to(dev)
@@ -301,17 +304,18 @@ def main():
                 for bn in (128, 64, 32):
                     for km in (0, 1, 2):
                         for nst in (2, 1):
-                            r = K.profile_read(mode=mode, bm=bm, bn=bn, km=km, nst=nst)
-                            if r[2] and (best is None or r[0] > best[0][0]):
-                                best = (r, (mode, bm, bn, km, nst))
+                            for prec in ((0,) if not bf16 else (2, 1)):
+                                r = K.profile_read(mode=mode, bm=bm, bn=bn, km=km, nst=nst, prec=prec)
+                                if r[2] and (best is None or r[0] > best[0][0]):
+                                    best = (r, (mode, bm, bn, km, nst), prec)
         tot_ms, tot_fl, tot_n = K.profile_read(clear=True)
         if best:
-            (ms, fl, n), (mode, bm, bn, km, nst) = best
+            (ms, fl, n), (mode, bm, bn, km, nst), kprec = best
             ach = fl / (ms * 1e-3) / 1e12
-            sym = 'conv_igemm_kernel<%d, %d, %d, %s, %d, %d, %d>' % (mode, bm, bn, '4, 1' if bn == 32 else '2, 2', km, 1 if a.dtype == 'bf16' else 0, nst)
+            sym = 'conv_igemm_kernel<%d, %d, %d, %s, %d, %d, %d>' % (mode, bm, bn, '4, 1' if bn == 32 else '2, 2', km, kprec, nst)
             what = '%s, %dx%dx32 tile, %s K-state, %s LDS, %s; direct convolutions and the batched Winograd F(4x4,3x3) / F(2x2,3x3) GEMMs; FLOPs = 2*M*N*K executed' % (
                 ('forward', 'data gradient', 'weight gradient')[mode], bm, bn, ('wave-uniform', 'per-lane', 'per-lane looping')[km],
-                'double-buffered' if nst == 2 else 'single-stage', 'v_mfma_f32_32x32x16_bf16' if a.dtype == 'bf16' else 'v_mfma_f32_32x32x2_f32')
+                'double-buffered' if nst == 2 else 'single-stage', ('v_mfma_f32_32x32x2_f32', 'v_mfma_f32_32x32x16_bf16 on fp32 tiles rounded per fragment', 'v_mfma_f32_32x32x16_bf16 on bf16 tiles (bf16 operands in HBM)')[kprec])
             traffic, traffic_src = None, None      # HBM bytes per launch of that symbol, from the committed PMC passes of this command
             try:
                 import glob
@@ -339,8 +343,8 @@ def main():
                'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
                'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
                'config': {'workload': '%s: ResNet-50 DeepLabV3+ + memory, bs=%d/GPU %dx%d synthetic, %s reference-faithful agg train step '
-                                      '(fwd + bwd + SGD + eval-mode memory-commit fwd%s)' % ('configs[2]' if a.dtype == 'bf16' else 'configs[1]', a.batch, a.size, a.size,
-                                                                                            'bf16-MFMA (fp32 accumulate/storage)' if a.dtype == 'bf16' else 'fp32',
+                                      '(fwd + bwd + SGD + eval-mode memory-commit fwd%s)' % ('configs[2]' if bf16 else 'configs[1]', a.batch, a.size, a.size,
+                                                                                            'bf16-MFMA convolutions (bf16 operands in HBM and LDS, fp32 accumulation; fp32 activations between layers)' if a.dtype == 'bf16' else ('bf16-MFMA (fp32 tiles staged, rounded per fragment)' if bf16 else 'fp32'),
                                                                                             ', decoder skipped in the commit fwd' if a.truncate_second_forward else ''),
                           'global_batch': a.batch * world, 'crop': a.size, 'parallelism': 'dp%d' % world,
                           'conv_tflop_per_step': round(gf_img * a.batch / 1e3, 3),

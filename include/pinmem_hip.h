@@ -80,6 +80,8 @@ int pm_set_winograd(int mode);
 int pm_profile_enable(int on);
 int pm_profile_dump(const char* csv_path);   /* one line per recorded launch: mode,bm,bn,km,nst,prec,M,N,K,batch,ksplit,ms,gflop */
 int pm_profile_read(int mode, int bm, int bn, int km, int nst, double* total_ms, double* total_flops, int64_t* launches, int clear);
+/* the same, additionally keyed by the operand form of the instantiation (prec 0 / 1 / 2 of pm_conv_params; negative = any) */
+int pm_profile_read_prec(int mode, int bm, int bn, int km, int nst, int prec, double* total_ms, double* total_flops, int64_t* launches, int clear);
 
 /* ---- K4 BatchNorm2d (mynn.py:8-14 -> nn.BatchNorm2d / SyncBatchNorm, eps 1e-5, momentum 0.1) -------------------
  * stats: per-channel shifted sums -> (count, mean, M2) so that ranks can be merged exactly (SyncBN, train.py:95).

@@ -1,0 +1,135 @@
+// configs[2] (BASELINE.json: "bf16 with MFMA conv kernels"): operand preparation for the bf16 tier of the convolution kernels.
+// The activations / gradients of the network stay fp32 in HBM between layers (BatchNorm statistics, losses and the memory need them);
+// each convolution call converts its two GEMM operands to bf16 IN HBM with one streaming pass (round to nearest even), so that the
+// implicit-GEMM kernel gathers bf16 rows (half the bytes), stages bf16 tiles in LDS (64 k-values per 128-byte row) and feeds
+// v_mfma_f32_32x32x16_bf16 straight from ds_read_b128 fragments; accumulation and the epilogue stay fp32.
+//   pm_bf16_cast_rows      x[P][pitch] fp32 -> xb[P][Cp] bf16, channels C..Cp-1 zero (Cp = C rounded up to 64: a K-slab never straddles a tap)
+//   pm_bf16_cast_weights   w[Cout][T][Cin] fp32 (KRSC) -> wb[Cout][T][Cp]                       (forward)
+//                          or the rotated / transposed filter wr[Cin][T][Coutp], tap t <- T-1-t   (data gradient = forward conv of dy)
+//   pm_bf16_transpose_taps x[N][H][W][C] fp32 -> xt[T][C][N*Ho*Wo] bf16: per tap the input pixel each output pixel sees (0 outside the
+//                          image), pixel-contiguous; and dy[P][Cout] -> dyt[Cout][P]. The weight gradient dw[co][(t, ci)] = sum_p
+//                          dyt[co][p] xt[t][ci][p] is then a plain k-contiguous GEMM over pixels for the same kernel.
+// Replaces nothing in the reference by itself: it is the operand edge of nn.Conv2d under the bf16 tier (Resnet.py:145-150, deepv3plus.py:72-81,398-424).
+#include "pm_common.h"
+
+namespace {
+
+__device__ __forceinline__ unsigned short f2bf(float f) {      // round to nearest even; NaN stays NaN
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ unsigned pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+
+// thread -> 8 consecutive channels of one pixel: two 16-byte loads, one 16-byte store
+__global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict__ x, long pitch, int C, int Cp, long P, unsigned short* __restrict__ out) {
+  const int g8 = Cp / 8;
+  const long total = P * g8;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long p = i / g8;
+    const int c = (int)(i - p * g8) * 8;
+    float v[8];
+    if (c + 8 <= C) {
+      const float4 a = PM_LD4(x + p * pitch + c), b = PM_LD4(x + p * pitch + c + 4);
+      v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = c + e < C ? x[p * pitch + c + e] : 0.f;
+    }
+    uint4 o;
+    o.x = pack2(v[0], v[1]), o.y = pack2(v[2], v[3]), o.z = pack2(v[4], v[5]), o.w = pack2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(out + p * Cp + c) = o;
+  }
+}
+
+// weights are small (<= 19 MB): one element per thread
+__global__ __launch_bounds__(256) void cast_weights_kernel(const float* __restrict__ w, int Cout, int T, int Cin, int Cp, int rotate, unsigned short* __restrict__ out) {
+  // forward:  out[co][t][c]  (c < Cp)  = w[co][t][c]
+  // rotate:   out[ci][t][c]  (c < Cp)  = w[c][T-1-t][ci]      (c runs over Cout)
+  const int R = rotate ? Cin : Cout, Cs = rotate ? Cout : Cin;
+  const long total = (long)R * T * Cp;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % Cp);
+    const int t = (int)((i / Cp) % T);
+    const int r = (int)(i / ((long)Cp * T));
+    float v = 0.f;
+    if (c < Cs) v = rotate ? w[((long)c * T + (T - 1 - t)) * Cin + r] : w[((long)r * T + t) * Cin + c];
+    out[i] = f2bf(v);
+  }
+}
+
+// Pixel-contiguous bf16 operands of the weight gradient. Block = 64 output pixels x 64 channels of ONE tap: the 64 source rows are read as
+// coalesced channel vectors, transposed through LDS, and written as 64 rows (channels) of 64 consecutive pixels (128 bytes each).
+// T == 1 with stride 1 / pad 0 is the plain transpose (dy -> dyt, and x of a 1x1 convolution).
+struct TapGeom {
+  int N, H, W, Ho, Wo, kw, stride, pad, dil;
+};
+__global__ __launch_bounds__(256) void transpose_taps_kernel(const float* __restrict__ x, long pitch, int C, TapGeom g, long P, unsigned short* __restrict__ out) {
+  __shared__ float tile[64][65];
+  const int tap = blockIdx.z;
+  const long p0 = (long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  const int ky = tap / g.kw, kx = tap - ky * g.kw;
+  // load: thread -> (pixel r + 16 i, channel group q): 16 float4 per pixel row
+  const int q = threadIdx.x & 15, r = threadIdx.x >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long p = p0 + r + 16 * i;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p < P) {
+      const int ox = (int)(p % g.Wo), oy = (int)((p / g.Wo) % g.Ho), n = (int)(p / ((long)g.Wo * g.Ho));
+      const int iy = oy * g.stride - g.pad + ky * g.dil, ix = ox * g.stride - g.pad + kx * g.dil;
+      const int c = c0 + q * 4;
+      if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W) {
+        const float* src = x + ((long)(n * g.H + iy) * g.W + ix) * pitch + c;
+        if (c + 4 <= C) v = PM_LD4(src);
+        else {
+          if (c < C) v.x = src[0];
+          if (c + 1 < C) v.y = src[1];
+          if (c + 2 < C) v.z = src[2];
+        }
+      }
+    }
+    tile[r + 16 * i][q * 4] = v.x, tile[r + 16 * i][q * 4 + 1] = v.y, tile[r + 16 * i][q * 4 + 2] = v.z, tile[r + 16 * i][q * 4 + 3] = v.w;
+  }
+  __syncthreads();
+  // store: thread -> (channel cc + 32 j, pixel group of 8): eight 16-byte stores cover one channel row of the tile
+  const int pg = threadIdx.x & 7, cc = threadIdx.x >> 3;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = c0 + cc + 32 * j;
+    if (c >= C) continue;
+    const long p = p0 + pg * 8;
+    if (p >= P) continue;                                  // P % 8 == 0 is required by the host (whole 16-byte groups)
+    uint4 o;
+    const float* t = &tile[pg * 8][cc + 32 * j];
+    o.x = pack2(t[0], t[65]), o.y = pack2(t[2 * 65], t[3 * 65]), o.z = pack2(t[4 * 65], t[5 * 65]), o.w = pack2(t[6 * 65], t[7 * 65]);
+    *reinterpret_cast<uint4*>(out + ((long)tap * C + c) * P + p) = o;
+  }
+}
+
+}  // namespace
+
+int pm_bf16_cast_rows(const float* x, long pitch, int C, int Cp, long P, void* out, hipStream_t st) {
+  const long total = P * (Cp / 8);
+  if (total == 0) return PM_OK;
+  hipLaunchKernelGGL(cast_rows_kernel, dim3((int)std::min<long>((total + 255) / 256, 256 * 16)), dim3(256), 0, st, x, pitch, C, Cp, P, (unsigned short*)out);
+  return pm_check_launch("bf16_cast_rows");
+}
+
+int pm_bf16_cast_weights(const float* w, int Cout, int T, int Cin, int Cp, bool rotate, void* out, hipStream_t st) {
+  const long total = (long)(rotate ? Cin : Cout) * T * Cp;
+  hipLaunchKernelGGL(cast_weights_kernel, dim3((int)std::min<long>((total + 255) / 256, 256 * 16)), dim3(256), 0, st, w, Cout, T, Cin, Cp, rotate ? 1 : 0,
+                     (unsigned short*)out);
+  return pm_check_launch("bf16_cast_weights");
+}
+
+int pm_bf16_transpose_taps(const float* x, long pitch, int C, int N, int H, int W, int Ho, int Wo, int kh, int kw, int stride, int pad, int dil, void* out,
+                           hipStream_t st) {
+  const long P = (long)N * Ho * Wo;
+  const TapGeom g = {N, H, W, Ho, Wo, kw, stride, pad, dil};
+  hipLaunchKernelGGL(transpose_taps_kernel, dim3((unsigned)((P + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)(kh * kw)), dim3(256), 0, st, x, pitch, C, g, P,
+                     (unsigned short*)out);
+  return pm_check_launch("bf16_transpose_taps");
+}

@@ -379,7 +379,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   auto compute_kg = [&](int buf, int kg) {   // one 8-k group (fp32) or one 16-k block (bf16: kg = 0, 2 cover the slab)
     const float* As = smem + buf * STAGE;
     const float* Bs = As + A_FLOATS;
-    if constexpr (PREC == 0) {
+    if constexpr (PREC == 2) {
+      // bf16 operands in HBM and LDS (bf16.hip): the tensors enter as fp32-typed views with half the channels, so one float4 of a
+      // k-contiguous LDS row is 8 consecutive bf16 k-values -- exactly this lane-half's operand of v_mfma_f32_32x32x16_bf16. Gather,
+      // LDS layout (128-byte rows = 64 k, padded to 144 B) and epilogue are the fp32 code unchanged; 8 x fewer MFMA cycles per slab.
+      static_assert(A_KC && B_KC, "bf16 tiles need k-contiguous operands (forward form)");
+      const int kk = kg * 8 + half * 4;
+      bf16x8 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(As + (wm * (BM / WM) + i * 32 + l31) * LDK + kk));
+#pragma unroll
+      for (int i = 0; i < TN; ++i) fb[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(Bs + (wn * (BN / WN) + i * 32 + l31) * LDK + kk));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+          acc[i][n] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[n], fa[i], acc[i][n], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[n], acc[i][n], 0, 0, 0);
+    } else if constexpr (PREC == 0) {
       const int kk = kg * 8 + half * 4;  // this lane-half's 4 consecutive k of the 8-k group
       float fa[TM][4], fb[TN][4];
 #pragma unroll
@@ -943,6 +959,9 @@ void launch_prec(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
 }
 template <int MODE, int BM, int BN, int WM, int WN, int KM>
 void launch_inst(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
+  if constexpr (MODE == MODE_FWD && KM == K_FAST && BN >= 64) {
+    if (k.prec == 2) return launch_prec<MODE, BM, BN, WM, WN, KM, 2>(k, grid, smem, st);
+  }
   if (k.prec == 1) launch_prec<MODE, BM, BN, WM, WN, KM, 1>(k, grid, smem, st);
   else launch_prec<MODE, BM, BN, WM, WN, KM, 0>(k, grid, smem, st);
 }
@@ -1017,7 +1036,7 @@ void fill_geom(ConvK& k, const pm_tensor* x, const pm_tensor* y, const pm_conv_p
   k.Ho = y->h, k.Wo = y->w, k.Cout = y->c, k.y_pitch = y->pitch;
   k.kh = p->kh, k.kw = p->kw, k.stride = p->stride, k.pad = p->pad, k.dil = p->dil;
   k.sshift = p->stride == 2 ? 1 : 0;
-  k.prec = p->prec == 1 ? 1 : 0;
+  k.prec = p->prec != 0 ? 1 : 0;   // prec 2 call sites that cannot take the bf16-operand route fall back to the staged-fp32 bf16 MFMA form
   k.T_eff = p->kh * p->kw, k.tk_w = p->kw, k.ky0 = k.kx0 = 0, k.ksy = k.ksx = 1;
   k.sub = k.sub_cy = k.sub_cx = 0, k.Hc = x->h, k.Wc = x->w;
   k.bias = k.scale = k.shift = k.residual = nullptr;
@@ -1042,7 +1061,7 @@ struct WinoPlan {
 WinoPlan wino_plan(const pm_tensor* xin, int cout, const pm_conv_params* p, bool wgrad = false) {
   WinoPlan wp{};
   if (wgrad && (long)xin->c * cout < 256 * 256) return wp;   // two transforms + slabs per GEMM: pays from 256 x 256 channels up
-  if (g_wino_mode == 0 || p->kh != 3 || p->kw != 3 || p->stride != 1 || p->pad != p->dil || p->prec == 1) return wp;
+  if (g_wino_mode == 0 || p->kh != 3 || p->kw != 3 || p->stride != 1 || p->pad != p->dil || p->prec != 0) return wp;
   const int cin = xin->c;
   if (cin < 128 || cout < 128 || (cout & 3) || (cin & 3)) return wp;
   // multiplies per output relative to the direct algorithm: (m+2)^2 / (9 m^2) x the padding of the sub-lattices to whole tiles
@@ -1142,6 +1161,69 @@ int wino_wgrad(const pm_tensor* x, const pm_tensor* dy, float* dw, const WinoPla
   return pm_wino_dw_xf(slab, q.pl.ksplit, cout, x->c, wp.Kp, wp.g.m, dw, st);
 }
 
+// ---- prec = 2: bf16 operands in HBM (bf16.hip) + bf16 LDS tiles, forward and stride-1 data gradient -----------------------------
+// The convolution is handed to the implicit-GEMM kernel as an fp32-typed problem with HALF the input channels: a float of the view is a
+// pair of bf16 channels, a 32-float K-slab is 64 bf16 k-values. Input channels are padded to a multiple of 64 (zero-filled by the cast)
+// so that a slab never straddles a tap and the wave-uniform K-state (K_FAST) applies to every layer.
+struct Bf16Plan {
+  bool use;
+  int Cp;                    // padded input channels (bf16 elements)
+  long M, Nn, Kf;            // GEMM extents, K in float units (= taps * Cp / 2)
+  size_t xb_bytes, wb_bytes;
+  Plan pl;
+};
+Bf16Plan bf16_plan(const pm_tensor* xin, const pm_tensor* yout, const pm_conv_params* p) {
+  Bf16Plan b{};
+  if (p->prec != 2 || xin->c < 32) return b;                      // the 3(4)-channel stem would be padded 16x
+  b.Cp = (xin->c + 63) / 64 * 64;
+  const long T = (long)p->kh * p->kw;
+  b.M = pm_pixels(yout), b.Nn = yout->c, b.Kf = T * b.Cp / 2;
+  const size_t xb = (size_t)pm_pixels(xin) * b.Cp * 2, wb = (size_t)yout->c * T * b.Cp * 2;
+  if (xb >= (1ull << 31) || wb >= (1ull << 31)) return b;         // 32-bit byte offsets
+  b.xb_bytes = pm_align_up(xb, 256), b.wb_bytes = pm_align_up(wb, 256);
+  b.pl = make_plan(MODE_FWD, b.M, b.Nn, b.Kf, true);
+  if (b.pl.bn < 64) return b;                                     // no bf16 instantiation of the 128 x 32 tile
+  b.use = true;
+  return b;
+}
+inline size_t bf16_ws(const Bf16Plan& b) { return b.xb_bytes + b.wb_bytes + pm_align_up(b.pl.ws_bytes, 256); }
+
+// xin: the tensor the GEMM gathers from (x for the forward pass, dy for the data gradient); `rotate`: w is read as the rotated /
+// transposed filter; pe: geometry of the convolution actually run (the data gradient of a stride-1 convolution is a stride-1
+// convolution of dy with pad' = dil (k - 1) - pad).
+int conv_bf16(const pm_tensor* xin, const float* w, int w_cout, int w_cin, bool rotate, const pm_tensor* yout, const pm_conv_params* pe, const Bf16Plan& b,
+              const pm_conv_epilogue& e0, void* ws, hipStream_t st) {
+  char* xb = (char*)ws;
+  char* wb = xb + b.xb_bytes;
+  float* slab = (float*)(wb + b.wb_bytes);
+  const int T = pe->kh * pe->kw;
+  if (int e = pm_bf16_cast_rows((const float*)xin->ptr, xin->pitch, xin->c, b.Cp, pm_pixels(xin), xb, st)) return e;
+  if (int e = pm_bf16_cast_weights(w, w_cout, T, w_cin, b.Cp, rotate, wb, st)) return e;
+  const pm_tensor xv = {xb, xin->n, xin->h, xin->w, b.Cp / 2, b.Cp / 2};     // fp32-typed view: one float = two bf16 channels
+  ConvK k;
+  fill_geom(k, &xv, yout, pe);
+  k.prec = 2;
+  k.A = (const float*)xb, k.B = (const float*)wb;
+  k.M = (int)b.M, k.Nn = (int)b.Nn, k.K = (int)b.Kf;
+  k.a_bytes = (unsigned)((size_t)pm_pixels(xin) * b.Cp * 2), k.b_bytes = (unsigned)((size_t)yout->c * T * b.Cp * 2), k.kmode = K_FAST;
+  const double flops = 2.0 * (double)b.M * (double)b.Nn * (double)T * (double)xin->c;
+  if (b.pl.ksplit > 1) {
+    k.C = slab, k.c_pitch = b.Nn, k.c_split = b.M * b.Nn;
+    if (int e = launch<MODE_FWD>(k, b.pl, st, 1, flops)) return e;
+    return splitk_reduce(slab, b.pl.ksplit, b.M, b.Nn, (float*)yout->ptr, (long)yout->pitch, e0.bias, e0.scale, e0.shift, e0.residual, (long)e0.residual_pitch,
+                         e0.relu, st);
+  }
+  k.C = (float*)yout->ptr, k.c_pitch = yout->pitch, k.c_split = 0;
+  k.bias = e0.bias, k.scale = e0.scale, k.shift = e0.shift, k.residual = e0.residual, k.res_pitch = e0.residual_pitch, k.relu = e0.relu;
+  return launch<MODE_FWD>(k, b.pl, st, 1, flops);
+}
+inline pm_conv_params dgrad_as_fwd(const pm_conv_params* p) {
+  pm_conv_params q = *p;
+  q.stride = 1, q.pad = p->dil * (p->kh - 1) - p->pad;
+  return q;
+}
+inline bool dgrad_bf16_ok(const pm_conv_params* p) { return p->prec == 2 && p->stride == 1 && p->kh == p->kw && p->dil * (p->kh - 1) - p->pad >= 0; }
+
 void gemm_dims(int which, const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p, long& M, long& Nn, long& K) {
   const long T = (long)p->kh * p->kw;
   if (which == MODE_FWD) M = pm_pixels(y), Nn = y->c, K = T * x->c;
@@ -1162,11 +1244,18 @@ extern "C" int pm_profile_enable(int on) {
 }
 // Sums (and clears) the records of one kernel instantiation conv_igemm_kernel<mode, bm, bn, .., km>: mode 0 fwd / 1 dgrad /
 // 2 wgrad, bm x bn the block tile, km the K-state variant, nst the LDS stage count. Negative values act as wildcards. Synchronises on the recorded events only.
+extern "C" int pm_profile_read_prec(int mode, int bm, int bn, int km, int nst, int prec, double* total_ms, double* total_flops, int64_t* launches, int clear);
 extern "C" int pm_profile_read(int mode, int bm, int bn, int km, int nst, double* total_ms, double* total_flops, int64_t* launches, int clear) {
+  return pm_profile_read_prec(mode, bm, bn, km, nst, -1, total_ms, total_flops, launches, clear);
+}
+// the same with the operand form of the instantiation as a sixth key (prec: 0 fp32, 1 bf16 staged, 2 bf16 operands; negative = any)
+extern "C" int pm_profile_read_prec(int mode, int bm, int bn, int km, int nst, int prec, double* total_ms, double* total_flops, int64_t* launches, int clear) {
   double ms = 0.0, fl = 0.0;
   int64_t n = 0;
   for (const ProfRec& r : g_prof) {
-    if ((mode >= 0 && r.mode != mode) || (bm >= 0 && r.bm != bm) || (bn >= 0 && r.bn != bn) || (km >= 0 && r.km != km) || (nst >= 0 && r.nst != nst)) continue;
+    if ((mode >= 0 && r.mode != mode) || (bm >= 0 && r.bm != bm) || (bn >= 0 && r.bn != bn) || (km >= 0 && r.km != km) || (nst >= 0 && r.nst != nst) ||
+        (prec >= 0 && r.prec != prec))
+      continue;
     float t = 0.f;
     if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
     ms += t, fl += r.flops, ++n;
@@ -1208,9 +1297,18 @@ extern "C" size_t pm_conv_workspace(const pm_tensor* x, const pm_tensor* y, cons
     for (int cls = 0; cls < 4; ++cls) {
       const S2Class c = s2_class(cls, x, p);
       tmp = std::max(tmp, (size_t)c.M * x->c * sizeof(float));
-      if (c.M > 0 && c.nky * c.nkx > 0) slab = std::max(slab, make_plan(MODE_DGRAD, c.M, x->c, (long)c.nky * c.nkx * y->c, p->prec == 1).ws_bytes);
+      if (c.M > 0 && c.nky * c.nkx > 0) slab = std::max(slab, make_plan(MODE_DGRAD, c.M, x->c, (long)c.nky * c.nkx * y->c, p->prec != 0).ws_bytes);
     }
     return pm_align_up(4 * pm_align_up(tmp, 256) + slab + 256, 256);
+  }
+  if (which == MODE_FWD && p->prec == 2) {
+    const Bf16Plan b = bf16_plan(x, y, p);
+    if (b.use) return bf16_ws(b);
+  }
+  if (which == MODE_DGRAD && dgrad_bf16_ok(p)) {
+    const pm_conv_params q = dgrad_as_fwd(p);
+    const Bf16Plan b = bf16_plan(y, x, &q);
+    if (b.use) return bf16_ws(b);
   }
   if (which == MODE_FWD || which == MODE_DGRAD) {
     const WinoPlan wp = which == MODE_FWD ? wino_plan(x, y->c, p) : wino_plan(y, x->c, p);
@@ -1223,7 +1321,7 @@ extern "C" size_t pm_conv_workspace(const pm_tensor* x, const pm_tensor* y, cons
   }
   long M, Nn, K;
   gemm_dims(which, x, y, p, M, Nn, K);
-  size_t b = make_plan(which, M, Nn, K, p->prec == 1).ws_bytes;
+  size_t b = make_plan(which, M, Nn, K, p->prec != 0).ws_bytes;
   if (which == MODE_WGRAD) b += bias_part;
   return pm_align_up(b, 256);
 }
@@ -1243,9 +1341,19 @@ extern "C" int pm_conv_fwd(const pm_tensor* x, const float* w, const pm_tensor* 
       return wino_conv(x, w, y->c, x->c, false, y, wp, e1, ws, (hipStream_t)stream, keep);
     }
   }
+  if (p->prec == 2) {
+    const Bf16Plan b = bf16_plan(x, y, p);
+    if (b.use) {
+      pm_conv_epilogue e2 = {nullptr, nullptr, nullptr, nullptr, 0, 0};
+      if (ep) e2 = *ep;
+      PM_REQUIRE((e2.scale == nullptr) == (e2.shift == nullptr), PM_EINVAL, "conv_fwd: scale and shift go together");
+      PM_REQUIRE(ws && ws_bytes >= bf16_ws(b), PM_EWORKSPACE, "conv_fwd(bf16): workspace %zu < %zu", ws_bytes, bf16_ws(b));
+      return conv_bf16(x, w, y->c, x->c, false, y, p, b, e2, ws, (hipStream_t)stream);
+    }
+  }
   long M, Nn, K;
   gemm_dims(MODE_FWD, x, y, p, M, Nn, K);
-  Plan pl = make_plan(MODE_FWD, M, Nn, K, p->prec == 1);
+  Plan pl = make_plan(MODE_FWD, M, Nn, K, p->prec != 0);
   PM_REQUIRE(pl.ws_bytes <= ws_bytes && (pl.ws_bytes == 0 || ws), PM_EWORKSPACE, "conv_fwd: workspace %zu < %zu", ws_bytes, pl.ws_bytes);
   ConvK k;
   fill_geom(k, x, y, p);
@@ -1293,7 +1401,7 @@ extern "C" int pm_conv_bwd_data(const pm_tensor* dy, const float* w, const pm_te
       valid[cls] = c.M > 0 && c.nky * c.nkx > 0;
       if (!valid[cls]) continue;
       const long Kc = (long)c.nky * c.nkx * dy->c;
-      const Plan pl = make_plan(MODE_DGRAD, c.M, dx->c, Kc, p->prec == 1);
+      const Plan pl = make_plan(MODE_DGRAD, c.M, dx->c, Kc, p->prec != 0);
       ConvK k;
       fill_geom(k, dx, dy, p);
       k.A = (const float*)dy->ptr, k.B = w;
@@ -1319,6 +1427,15 @@ extern "C" int pm_conv_bwd_data(const pm_tensor* dy, const float* w, const pm_te
                        add_pitch);
     return pm_check_launch("dgrad_s2_interleave");
   }
+  if (dgrad_bf16_ok(p)) {      // data gradient of a stride-1 convolution = forward convolution of dy with the rotated / transposed filter
+    const pm_conv_params q = dgrad_as_fwd(p);
+    const Bf16Plan b = bf16_plan(dy, dx, &q);
+    if (b.use) {
+      PM_REQUIRE(ws && ws_bytes >= bf16_ws(b), PM_EWORKSPACE, "conv_bwd_data(bf16): workspace %zu < %zu", ws_bytes, bf16_ws(b));
+      const pm_conv_epilogue e1 = {nullptr, nullptr, nullptr, addp, add_pitch, 0};
+      return conv_bf16(dy, w, dy->c, dx->c, true, dx, &q, b, e1, ws, st0);
+    }
+  }
   {
     const WinoPlan wp = wino_plan(dy, dx->c, p);
     if (wp.use) {
@@ -1329,7 +1446,7 @@ extern "C" int pm_conv_bwd_data(const pm_tensor* dy, const float* w, const pm_te
   }
   long M, Nn, K;
   gemm_dims(MODE_DGRAD, dx, dy, p, M, Nn, K);
-  Plan pl = make_plan(MODE_DGRAD, M, Nn, K, p->prec == 1);
+  Plan pl = make_plan(MODE_DGRAD, M, Nn, K, p->prec != 0);
   PM_REQUIRE(pl.ws_bytes <= ws_bytes && (pl.ws_bytes == 0 || ws), PM_EWORKSPACE, "conv_bwd_data: workspace %zu < %zu", ws_bytes, pl.ws_bytes);
   ConvK k;
   fill_geom(k, dx, dy, p);
@@ -1353,7 +1470,7 @@ extern "C" int pm_conv_bwd_weight(const pm_tensor* x, const pm_tensor* dy, float
   PM_REQUIRE(dw && pm_aligned16(dw), PM_EINVAL, "conv_bwd_weight: dw null or unaligned");
   long M, Nn, K;
   gemm_dims(MODE_WGRAD, x, dy, p, M, Nn, K);
-  Plan pl = make_plan(MODE_WGRAD, M, Nn, K, p->prec == 1);
+  Plan pl = make_plan(MODE_WGRAD, M, Nn, K, p->prec != 0);
   const size_t need = pm_conv_workspace(x, dy, p, MODE_WGRAD);
   PM_REQUIRE(need <= ws_bytes && ws, PM_EWORKSPACE, "conv_bwd_weight: workspace %zu < %zu", ws_bytes, need);
   const WinoPlan wp = wino_plan(x, dy->c, p, true);

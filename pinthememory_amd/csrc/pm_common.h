@@ -48,6 +48,12 @@ int pm_wino_output_xf(const float* M, int Cout, const pm_wino_geom& g, float* y,
 int pm_wino_dy_xf(const float* dy, long pitch, int Cout, const pm_wino_geom& g, float* Z, hipStream_t st);
 int pm_wino_dw_xf(const float* slab, int ks, int Cout, int Cin, int Kp, int m, float* dw, hipStream_t st);
 
+// ---- bf16 operand preparation of the convolution kernels (bf16.hip; prec = 2) ----------------------------------------------------------
+int pm_bf16_cast_rows(const float* x, long pitch, int C, int Cp, long P, void* out, hipStream_t st);
+int pm_bf16_cast_weights(const float* w, int Cout, int T, int Cin, int Cp, bool rotate, void* out, hipStream_t st);
+int pm_bf16_transpose_taps(const float* x, long pitch, int C, int N, int H, int W, int Ho, int Wo, int kh, int kw, int stride, int pad, int dil, void* out,
+                           hipStream_t st);
+
 // ---- device helpers -------------------------------------------------------------------------------------------
 __device__ __forceinline__ float pm_wave_sum(float v) {
 #pragma unroll

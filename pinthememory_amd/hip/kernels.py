@@ -14,12 +14,16 @@ def _lib():
     return L.load()
 
 
-CONV_PREC = 0      # 0: fp32 MFMA (parity path, BASELINE configs[1]); 1: bf16 MFMA operands, fp32 accumulate/storage (configs[2])
+# 0: fp32 MFMA (parity path, BASELINE configs[1]). 2: configs[2], the bf16 tier -- each convolution's operands are converted to bf16 in HBM
+# (one streaming pass, RNE), bf16 tiles of 64 k-values per row in LDS, v_mfma_f32_32x32x16_bf16 with fp32 accumulation; activations between
+# layers, BatchNorm, losses and the memory stay fp32. 1: the first form of that tier (fp32 tiles staged in LDS, rounded per fragment), which
+# prec 2 falls back to for the call sites it does not cover (3-channel stem, 19-class heads, stride-2 data gradients).
+CONV_PREC = 0
 
 
 def set_conv_precision(name):
     global CONV_PREC
-    CONV_PREC = {'f32': 0, 'fp32': 0, 'bf16': 1}[name]
+    CONV_PREC = {'f32': 0, 'fp32': 0, 'bf16': 2, 'bf16_staged': 1}[name]
 
 
 def new(shape, like, pitch_pad=False, zero_pad=True):
@@ -471,9 +475,9 @@ def profile_dump(path):
     check(_lib().pm_profile_dump(str(path).encode()), 'pm_profile_dump')
 
 
-def profile_read(mode=-1, bm=-1, bn=-1, km=-1, nst=-1, clear=False):
-    """-> (total_ms, total_flops, launches) of the conv_igemm_kernel<mode, bm, bn, .., km> launches recorded since the last clear."""
+def profile_read(mode=-1, bm=-1, bn=-1, km=-1, nst=-1, clear=False, prec=-1):
+    """-> (total_ms, total_flops, launches) of the conv_igemm_kernel<mode, bm, bn, .., km, prec, nst> launches recorded since the last clear."""
     import ctypes
     ms, fl, n = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int64(0)
-    check(_lib().pm_profile_read(mode, bm, bn, km, nst, byref(ms), byref(fl), byref(n), 1 if clear else 0), 'pm_profile_read')
+    check(_lib().pm_profile_read_prec(mode, bm, bn, km, nst, prec, byref(ms), byref(fl), byref(n), 1 if clear else 0), 'pm_profile_read_prec')
     return ms.value, fl.value, n.value

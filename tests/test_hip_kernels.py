@@ -404,10 +404,19 @@ def test_bn_merge(K):
     assert torch.equal(mean1, mean2) and torch.equal(inv1, inv2) and torch.equal(rm1, rm2) and torch.equal(rv1, rv2)
 
 
-@pytest.mark.parametrize('case', [CONV_CASES[1], CONV_CASES[3], CONV_CASES[5], CONV_CASES[8], CONV_CASES[9], CONV_CASES[10]])
-def test_conv_bf16_operands(K, case):
-    """BASELINE configs[2]: operands rounded to bf16 (RNE) feeding v_mfma_f32_32x32x16_bf16, fp32 accumulation.
-    Oracle: the same convolution in fp32 on inputs pre-rounded to bf16 -- only the accumulation order differs."""
+BF16_CASES = [CONV_CASES[1], CONV_CASES[3], CONV_CASES[5], CONV_CASES[8], CONV_CASES[9], CONV_CASES[10],
+              (2, 256, 24, 24, 128, 3, 1, 6, 6, False),        # dilated 3x3, every K-slab inside one tap
+              (1, 1280, 16, 16, 256, 1, 1, 0, 1, False),       # bot_aspp: long K
+              (2, 96, 19, 21, 80, 3, 1, 1, 1, False),          # channels padded 96 -> 128 by the cast, ragged tiles
+              (1, 512, 12, 12, 512, 3, 1, 2, 2, False)]
+
+
+@pytest.mark.parametrize('form', ['bf16', 'bf16_staged'])
+@pytest.mark.parametrize('case', BF16_CASES)
+def test_conv_bf16_operands(K, case, form):
+    """BASELINE configs[2]: operands rounded to bf16 (RNE) feeding v_mfma_f32_32x32x16_bf16, fp32 accumulation -- the bf16-operand form
+    (bf16 in HBM and LDS, csrc/bf16.hip) and the staged-fp32 form it falls back to. Oracle: the same convolution in fp32 on inputs
+    pre-rounded to bf16 -- only the accumulation order differs."""
     n, cin, h, w, cout, k, s, p, d, has_bias = case
     r16 = lambda t: t.bfloat16().float()
     x = rnd(n, cin, h, w, seed=1)
@@ -415,7 +424,7 @@ def test_conv_bf16_operands(K, case):
     xr, wr = r16(x).requires_grad_(True), r16(wt).requires_grad_(True)
     y_ref = F.conv2d(xr, wr, None, stride=s, padding=p, dilation=d)
     dy = rnd(*y_ref.shape, seed=4)
-    K.set_conv_precision('bf16')
+    K.set_conv_precision(form)
     try:
         xg, wg = nhwc(x), wt.permute(0, 2, 3, 1).contiguous().cuda()
         y = K.conv_fwd(xg, wg, s, p, d)

@@ -410,24 +410,32 @@ def test_batched_bn_fold_is_bit_identical(env):
         assert torch.equal(lg, out[False][0][0]) and torch.equal(mem, out[False][0][1])
 
 
-def test_config3_bf16_mfma_forward_and_step(env):
-    """BASELINE configs[2]: the same network with bf16-MFMA convolutions (operands rounded to bf16, fp32 accumulate / storage).
-    Gate: looser than fp32 by the operand precision -- eval logits within 2e-2 of the fp32 oracle relative to their range and
-    argmax identical wherever the oracle's top-2 margin exceeds 0.25; a train step runs and moves the losses like fp32 does."""
+@pytest.mark.parametrize('form', ['bf16', 'bf16_staged'])
+def test_config3_bf16_mfma_forward_and_step(env, form, capsys):
+    """BASELINE configs[2]: the same network with bf16-MFMA convolutions -- `bf16`: every convolution converts its operands to bf16 in HBM
+    (csrc/bf16.hip), bf16 LDS tiles, fp32 accumulation; `bf16_staged`: fp32 tiles rounded per fragment (the fall-back form). Activations between
+    layers, BatchNorm, losses and the memory stay fp32. Gate (looser than fp32 by the operand precision, 2^-9 per operand, through 53 layers):
+    eval logits within 1 % of their range of the fp32 oracle and argmax identical wherever the oracle's top-2 margin exceeds 0.1; a train step
+    reproduces the fp32 HIP step's losses to 1 %."""
     from pinthememory_amd.hip import kernels as K
     synth = env['synth']
     args = synth.model_args()
     ref = synth.load_det_weights(env['o_deeplab'].DeepR50V3PlusD(args, 19, CRIT, CRIT)).eval()
     net = synth.load_det_weights(env['deepv3plus'].DeepR50V3PlusD(args, 19, CRIT, CRIT)).cuda().eval()
     x, y = synth.make_batch(2, 192)
-    K.set_conv_precision('bf16')
+    K.set_conv_precision(form)
     try:
         with torch.no_grad():
             want, got = ref(x)[0], net(x.cuda())[0].cpu()
-        scale = want.abs().max().item()
-        assert (got - want).abs().max().item() < 2e-2 * scale, ((got - want).abs().max().item(), scale)
+        scale = (want.max() - want.min()).item()
+        err = (got - want).abs().max().item()
         top2 = want.topk(2, dim=1).values
-        safe = (top2[:, 0] - top2[:, 1]) > 0.25
+        safe = (top2[:, 0] - top2[:, 1]) > 0.1
+        agree = (got.argmax(1) == want.argmax(1)).float().mean().item()
+        with capsys.disabled():
+            print('\n[%s eval 2x192^2] max |logit err| %.3e = %.2e of the logit range %.2f; argmax agreement %.5f, safe fraction %.3f'
+                  % (form, err, err / scale, scale, agree, safe.float().mean().item()))
+        assert err < 1e-2 * scale, (err, scale)
         assert (got.argmax(1)[safe] == want.argmax(1)[safe]).all() and safe.float().mean().item() > 0.5
         net.train()
         net.dsn[3].p = 0.0
@@ -440,7 +448,12 @@ def test_config3_bf16_mfma_forward_and_step(env):
     opt32, _ = env['harness'].make_optimizer(net32)
     l32 = env['harness'].agg_train_step(net32, opt32, x.cuda(), y.cuda())
     for k in l32:
-        assert abs(l16[k].item() - l32[k].item()) < 3e-2 * max(1.0, abs(l32[k].item())), (k, l16[k].item(), l32[k].item())
+        assert abs(l16[k].item() - l32[k].item()) < 1e-2 * max(1.0, abs(l32[k].item())), (k, l16[k].item(), l32[k].item())
+    dm = (net.memory.m_items - net32.memory.m_items).abs().max().item()
+    with capsys.disabled():
+        print('[%s step] losses %s vs fp32 %s; max |m_items - fp32| %.2e' % (form, {k: round(v.item(), 4) for k, v in l16.items()},
+                                                                             {k: round(v.item(), 4) for k, v in l32.items()}, dm))
+    assert dm < 2e-2, dm
 
 
 def test_pooled_multiscale_flip_eval_vs_oracle(env):
