@@ -180,6 +180,8 @@ __global__ __launch_bounds__(256) void ce_bwd_rows_kernel(const CEGeom g, int XW
   float* L0 = G + (size_t)max_nx * CP;
   float* L1 = L0 + (size_t)nL * CP;
   float* TW = G + ((size_t)max_nx + 2 * (size_t)max_nl) * CP;   // per hi-res column: low-res index i0 (as float), weights w0, w1
+  int* first = reinterpret_cast<int*>(TW + 3 * (size_t)max_nx);   // first[k]: first staged hi-res column whose i0 >= x0 - 1 + k, k in [0, XW + 2]
+  for (int k = threadIdx.x; k < XW + 3; k += 256) first[k] = nX;
   // labels of this thread's (up to three) hi-res pixels: requested now, so that they arrive while the logit rows are being staged
   const int64_t* lrow = g.labels + ((long)b * g.H + Y) * g.W + Xlo;
   int64_t labs[3];
@@ -197,6 +199,10 @@ __global__ __launch_bounds__(256) void ce_bwd_rows_kernel(const CEGeom g, int XW
     float* out = G + j * CP;
     const pm_lerp lx = pm_ac_lerp(g.sx, X, g.w);
     TW[3 * j] = (float)lx.i0, TW[3 * j + 1] = lx.i1 == lx.i0 ? lx.w0 + lx.w1 : lx.w0, TW[3 * j + 2] = lx.i1 == lx.i0 ? 0.f : lx.w1;
+    {   // i0 is non-decreasing in X: column j opens the range of every low-res index in (i0(j - 1), i0(j)]
+      const int prev = j == 0 ? x0 - 2 : pm_ac_lerp(g.sx, X - 1, g.w).i0;
+      for (int xx = max(prev + 1, x0 - 1); xx <= min(lx.i0, x0 + XW + 1); ++xx) first[xx - (x0 - 1)] = j;
+    }
     if (lab == 255) {
 #pragma unroll
       for (int c = 0; c < (C_ > 0 ? C_ : MAXC); ++c)
@@ -225,14 +231,12 @@ __global__ __launch_bounds__(256) void ce_bwd_rows_kernel(const CEGeom g, int XW
   const int nout = (x1 - x0) * C;
   for (int o = threadIdx.x; o < nout; o += 256) {
     const int xl = o / C, c = o - xl * C, x = x0 + xl;
-    int lo, hi;
-    support(g.sx, x, g.W, lo, hi);
+    // low-res column x collects w1 of the hi-res columns with i0 == x - 1, then w0 of those with i0 == x: two contiguous runs, walked in
+    // ascending order (the same order and the same products as a scan over the whole support with zero weights elsewhere)
+    const int j0 = first[xl], j1 = first[xl + 1], j2 = first[xl + 2];
     float acc = 0.f;
-    for (int X = lo; X <= hi; ++X) {   // tap weight of hi-res column X on low-res column x, from the table built in phase A
-      const int j = X - Xlo, i0 = (int)TW[3 * j];
-      const float wgt = (i0 == x ? TW[3 * j + 1] : 0.f) + (i0 + 1 == x ? TW[3 * j + 2] : 0.f);
-      acc += wgt * G[j * CP + c];
-    }
+    for (int j = j0; j < j1; ++j) acc += TW[3 * j + 2] * G[j * CP + c];
+    for (int j = j1; j < j2; ++j) acc += TW[3 * j + 1] * G[j * CP + c];
     T[(((long)b * g.H + Y) * g.w + x) * C + c] = acc;
   }
 }
@@ -269,7 +273,7 @@ inline int bwd_seg(const CEGeom& g, int& max_nx) {
       support(g.sx, std::min(g.w, x0 + xw) - 1, g.W, tmp, hi);
       max_nx = std::max(max_nx, hi - lo + 1);
     }
-    if ((((size_t)max_nx + 2 * (size_t)(xw + 3)) * cp + 3 * (size_t)max_nx) * sizeof(float) <= 60 * 1024 || xw == 1) return xw;
+    if ((((size_t)max_nx + 2 * (size_t)(xw + 3)) * cp + 3 * (size_t)max_nx + (size_t)xw + 3) * sizeof(float) <= 60 * 1024 || xw == 1) return xw;
     xw = std::max(1, xw / 2);
   }
 }
@@ -335,7 +339,7 @@ extern "C" int pm_upsample_ce_bwd(const pm_tensor* logits, float inv_temp, const
     const int xa = lo_i0(lo), xb = std::min(lo_i0(hi) + 1, g.w - 1);
     max_nl = std::max(max_nl, xb - xa + 1);
   }
-  const size_t lds = (((size_t)max_nx + 2 * (size_t)max_nl) * (g.C | 1) + 3 * (size_t)max_nx) * sizeof(float);
+  const size_t lds = (((size_t)max_nx + 2 * (size_t)max_nl) * (g.C | 1) + 3 * (size_t)max_nx + (size_t)xw + 3) * sizeof(float);
   PM_REQUIRE(lds <= 64 * 1024, PM_EUNSUPPORTED, "upsample_ce_bwd: one low-res column is supported by %d hi-res columns (LDS)", max_nx);
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(pm_cdiv(g.w, xw), H, g.n);

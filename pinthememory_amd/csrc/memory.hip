@@ -299,79 +299,87 @@ __global__ __launch_bounds__(256) void mem_write_update_bwd_kernel(const float* 
   if (dmem_in) dmem_in[j * D + c] = den != 0.f ? du * mu : du;
 }
 
-// Memory read on the matrix cores. One wave owns 32 query rows: S = X M^T (32 x 256 . 256 x 32, slots padded to 32) with the rows
-// streamed straight from global memory into MFMA operand registers (lane = (row, k-half): float4 pieces of its own row, which also
-// gives ||x||^2 with one cross-lane add), the 32 x 32 score tile transposed through LDS so that every lane holds its row's slots for
-// the softmax, then  agg = P M  (32 x 32 . 32 x 256) again on the MFMA with P fed from registers. ~220 MFMAs per 32 rows instead of
-// 20 six-step wave reductions per row; the slots live in LDS for the whole block.
+// Memory read on the matrix cores: one wave (= one 64-thread block) owns 32 query rows, and x is fetched from HBM exactly once.
+//   * the 32 rows are loaded as 32 fully coalesced 1 KB wave instructions into LDS (Xs, 33 KB), next to the m slots (Ms, 20 KB): 53 KB
+//     per block, three blocks per CU -- the 576 blocks of the flagship (18 432 rows) are resident at once;
+//   * both products run TRANSPOSED (operands swapped): S^T = M X^T and agg^T = M^T P^T, so the MFMA result layout hands lane
+//     (row = lane & 31, half = lane >> 5) 16 of its OWN row's 32 (padded) slots / four consecutive output channels per register quad:
+//     the softmax over the slots is 16 in-lane values + one exchange with the partner half-lane (no LDS transpose, no barrier), P is
+//     already the B operand of the second product, and [agg] leaves as 16-byte stores;
+//   * qhat = x / ||x|| is produced from the LDS copy (the previous version re-read x from L2: 1.25 x the algorithmic traffic).
+// The single wave never synchronises with anyone: LDS accesses of one wave are ordered by the hardware.
 typedef float mr_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int MR_LDK = D + 4;     // 1040-byte rows: conflict-free ds_read_b128 fragments (bank step 4 per row)
 template <int M_>
-__global__ __launch_bounds__(256) void mem_read_fwd_mfma_kernel(const float* __restrict__ x, long xp, long rows, const float* __restrict__ mem, int m_rt,
-                                                                const float* __restrict__ noise, float* __restrict__ qr, long qp,
-                                                                float* __restrict__ score, float* __restrict__ pm) {
-  constexpr int LDK = D + 4;
+__global__ __launch_bounds__(64) void mem_read_fwd_mfma_kernel(const float* __restrict__ x, long xp, long rows, const float* __restrict__ mem, int m_rt,
+                                                               const float* __restrict__ noise, float* __restrict__ qr, long qp,
+                                                               float* __restrict__ score, float* __restrict__ pm) {
+  constexpr int LDK = MR_LDK;
+  constexpr int MM = M_ > 0 ? M_ : MAXM;
   const int M = M_ > 0 ? M_ : m_rt;
-  __shared__ __align__(16) float Ms[MAXM * LDK];   // slot-major, rows >= M are zero
-  __shared__ float Ss[4][32][33];
-  __shared__ float Nr[4][32];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, half = lane >> 5;
-  for (int i = t; i < MAXM * (D / 4); i += 256) {
-    const int r = i / (D / 4), c4 = i - r * (D / 4);
-    *reinterpret_cast<float4*>(Ms + r * LDK + c4 * 4) = r < M ? PM_LD4(mem + (long)r * D + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  __syncthreads();
-  for (long base = (long)blockIdx.x * 128; base < rows; base += (long)gridDim.x * 128) {   // uniform trip count per block
-    const long row0 = base + wave * 32;
-    const long myrow = min(row0 + l31, rows - 1);          // rows past the end are computed on the last row and never stored
-    const float* xr = x + myrow * xp + 4 * half;
+  extern __shared__ __align__(16) float mr_smem[];
+  float* Xs = mr_smem;                  // [32][LDK]
+  float* Ms = mr_smem + 32 * LDK;       // [M][LDK]
+  const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
+  for (int r = 0; r < M; ++r) *reinterpret_cast<float4*>(Ms + r * LDK + lane * 4) = PM_LD4(mem + (long)r * D + lane * 4);
+  for (long row0 = (long)blockIdx.x * 32; row0 < rows; row0 += (long)gridDim.x * 32) {
+#pragma unroll
+    for (int it0 = 0; it0 < 32; it0 += 8) {   // 8 independent 1 KB row loads in flight
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = PM_LD4(x + min(row0 + it0 + u, rows - 1) * xp + lane * 4);   // rows past the end: a copy of the last row, never stored
+#pragma unroll
+      for (int u = 0; u < 8; ++u) *reinterpret_cast<float4*>(Xs + (it0 + u) * LDK + lane * 4) = v[u];
+    }
+    const long myrow = min(row0 + l31, rows - 1);
+    const bool live = row0 + l31 < rows;
+    const int mslot = min(l31, M - 1);                     // lanes beyond the slots read a valid row and multiply by zero below
+    const float mz = l31 < M ? 1.f : 0.f;
     mr_f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
     float n2 = 0.f;
-#pragma unroll 16
+#pragma unroll 8
     for (int g = 0; g < D / 8; ++g) {
-      const float4 a = PM_LD4(xr + 8 * g);
+      const float4 a = *reinterpret_cast<const float4*>(Xs + l31 * LDK + 8 * g + 4 * half);      // lane & 31 = query row
+      float4 b = *reinterpret_cast<const float4*>(Ms + mslot * LDK + 8 * g + 4 * half);           // lane & 31 = slot
+      b.x *= mz, b.y *= mz, b.z *= mz, b.w *= mz;
       n2 += dot4(a, a);
-      const float4 b = *reinterpret_cast<const float4*>(Ms + l31 * LDK + 8 * g + 4 * half);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc, 0, 0, 0);                          // S^T[slot][row]: operands swapped
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc, 0, 0, 0);
     }
     n2 += __shfl_xor(n2, 32, 64);
     const float nrm = fmaxf(sqrtf(n2), EPS);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) Ss[wave][(q & 3) + 8 * (q >> 2) + 4 * half][l31] = acc[q];   // acc[q]: row from (q, half), slot = lane % 32
-    if (half == 0) Nr[wave][l31] = nrm;
-    __syncthreads();
-    // this lane's row: cosine scores and softmax over the slots (the two half-lanes of a row do the same work)
-    float pr[MAXM];
-    const bool mine = half == 0 && row0 + l31 < rows;
+    // acc[q] = <x_row, m_slot> for slot s = (q & 3) + 8 (q >> 2) + 4 half of this lane's own row
+    float pr[16];
     float mx = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < (M_ > 0 ? M_ : MAXM); ++j)
-      if (j < M) {
-        float sv = Ss[wave][l31][j] / nrm;
-        if (mine) score[myrow * M + j] = sv;
-        if (noise) sv += noise[myrow * M + j];
-        pr[j] = sv;
+    for (int q = 0; q < 16; ++q) {
+      const int sl = (q & 3) + 8 * (q >> 2) + 4 * half;
+      if ((q & 3) + 8 * (q >> 2) < MM && sl < M) {          // first test: compile-time pruning of register quads beyond the slots
+        float sv = acc[q] / nrm;
+        if (live) score[myrow * M + sl] = sv;
+        if (noise) sv += noise[myrow * M + sl];
+        pr[q] = sv;
         mx = fmaxf(mx, sv);
-      }
-    float se = 0.f;
-#pragma unroll
-    for (int j = 0; j < (M_ > 0 ? M_ : MAXM); ++j)
-      if (j < M) pr[j] = expf(pr[j] - mx), se += pr[j];
-#pragma unroll
-    for (int j = 0; j < MAXM; ++j) {
-      if (j < (M_ > 0 ? M_ : MAXM) && j < M) {
-        pr[j] = pr[j] / se;
-        if (mine) pm[myrow * M + j] = pr[j];
       } else {
-        pr[j] = 0.f;
+        pr[q] = -INFINITY;
       }
     }
-    // agg = P M, 128 channels per pass
-    constexpr int KG = ((M_ > 0 ? M_ : MAXM) + 7) / 8;
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float se = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) pr[q] = pr[q] == -INFINITY ? 0.f : expf(pr[q] - mx), se += pr[q];
+    se += __shfl_xor(se, 32, 64);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int sl = (q & 3) + 8 * (q >> 2) + 4 * half;
+      pr[q] = pr[q] / se;
+      if ((q & 3) + 8 * (q >> 2) < MM && sl < M && live) pm[myrow * M + sl] = pr[q];
+    }
+    // agg^T = M^T P^T, 128 channels per pass: step q multiplies slot (q&3) + 8 (q>>2) [+ 4 in the upper half-wave]; padding slots carry P = 0
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       mr_f32x16 ag[4];
@@ -380,36 +388,29 @@ __global__ __launch_bounds__(256) void mem_read_fwd_mfma_kernel(const float* __r
 #pragma unroll
         for (int q = 0; q < 16; ++q) ag[n][q] = 0.f;
 #pragma unroll
-      for (int g = 0; g < KG; ++g)
+      for (int q = 0; q < 16; ++q) {
+        if ((q & 3) + 8 * (q >> 2) >= MM) continue;        // both slots of this step are padding
+        const float* bp = Ms + min((q & 3) + 8 * (q >> 2) + 4 * half, M - 1) * LDK + pass * 128 + l31;   // lane & 31 = channel here
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float a = half ? pr[(8 * g + 4 + j) & (MAXM - 1)] : pr[8 * g + j];
-          const float* bp = Ms + (8 * g + 4 * half + j) * LDK + pass * 128 + l31;
+        for (int n = 0; n < 4; ++n) ag[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bp[n * 32], pr[q], ag[n], 0, 0, 0);
+      }
+      if (live) {
+        float* dst = qr + myrow * qp + D + pass * 128 + 4 * half;
 #pragma unroll
-          for (int n = 0; n < 4; ++n) ag[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[n * 32], ag[n], 0, 0, 0);
-        }
+        for (int n = 0; n < 4; ++n)
 #pragma unroll
-      for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const long r = row0 + (q & 3) + 8 * (q >> 2) + 4 * half;
-          if (r < rows) qr[r * qp + D + pass * 128 + n * 32 + l31] = ag[n][q];
-        }
-    }
-    // qhat = x / ||x||, one row (1 KB) per wave instruction
-#pragma unroll
-    for (int it0 = 0; it0 < 32; it0 += 8) {   // 8 independent row loads in flight
-      float4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = PM_LD4(x + min(row0 + it0 + u, rows - 1) * xp + lane * 4);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const long r = row0 + it0 + u;
-        const float nr = Nr[wave][it0 + u];
-        if (r < rows) PM_ST4(qr + r * qp + lane * 4, make_float4(v[u].x / nr, v[u].y / nr, v[u].z / nr, v[u].w / nr));
+          for (int g4 = 0; g4 < 4; ++g4)
+            PM_ST4(dst + n * 32 + 8 * g4, make_float4(ag[n][4 * g4], ag[n][4 * g4 + 1], ag[n][4 * g4 + 2], ag[n][4 * g4 + 3]));
       }
     }
-    __syncthreads();
+    // qhat = x / ||x|| from the LDS copy, one row (1 KB) per wave instruction; the row's norm lives in lane (row & 31)
+#pragma unroll 8
+    for (int u = 0; u < 32; ++u) {
+      const long r = row0 + u;
+      const float nr = __shfl(nrm, u, 64);
+      const float4 v = *reinterpret_cast<const float4*>(Xs + u * LDK + lane * 4);
+      if (r < rows) PM_ST4(qr + r * qp + lane * 4, make_float4(v.x / nr, v.y / nr, v.z / nr, v.w / nr));
+    }
   }
 }
 
@@ -425,12 +426,13 @@ extern "C" int pm_mem_read_fwd(const pm_tensor* x, const float* mem, int m, cons
   PM_REQUIRE(m >= 1 && m <= MAXM && pm_pixels(x) == pm_pixels(qr), PM_EINVAL, "mem_read_fwd: bad slots/rows");
   const long rows = pm_pixels(x);
   hipStream_t st = (hipStream_t)stream;
-  const int nb = (int)std::min<long>((rows + 127) / 128, 256 * 3);
+  const int nb = (int)std::min<long>((rows + 31) / 32, 256 * 3 * 4);
+  const size_t lds = (size_t)(32 + m) * MR_LDK * sizeof(float);
   if (m == 19)
-    hipLaunchKernelGGL(mem_read_fwd_mfma_kernel<19>, dim3(nb), dim3(256), 0, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, noise, (float*)qr->ptr,
+    hipLaunchKernelGGL(mem_read_fwd_mfma_kernel<19>, dim3(nb), dim3(64), lds, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, noise, (float*)qr->ptr,
                        (long)qr->pitch, score, p_mem);
   else
-    hipLaunchKernelGGL(mem_read_fwd_mfma_kernel<0>, dim3(nb), dim3(256), 0, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, noise, (float*)qr->ptr,
+    hipLaunchKernelGGL(mem_read_fwd_mfma_kernel<0>, dim3(nb), dim3(64), lds, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, noise, (float*)qr->ptr,
                        (long)qr->pitch, score, p_mem);
   return pm_check_launch("mem_read_fwd");
 }
