@@ -29,17 +29,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 //  NST         LDS stages (1: two barriers per slab, 2: one)
 //  PERSIST     0: one tile per block; 1: persistent blocks, next tile's first slab prefetched under the epilogue
 //  ABL         ablation: 0 full | 1 no global loads | 2 no epilogue stores | 3 no loads + no stores | 4 no MFMA
-template <int BM, int BN, int BKK, int NST, int PERSIST, int ABL, int MINW, int TR = 0, int PF2 = 0>
-__global__ __launch_bounds__(256, MINW) void gemm_lab(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K,
+template <int BM, int BN, int BKK, int NST, int PERSIST, int ABL, int MINW, int TR = 0, int PF2 = 0, int WAVES = 4>
+__global__ __launch_bounds__(WAVES * 64, MINW) void gemm_lab(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K,
                                                       long a_bs, long b_bs, long c_bs, int tiles_m, int tiles_n, int batch) {
   constexpr int LDK = BKK + 4;
   constexpr int KG = BKK / 4;          // float4 groups per row
-  constexpr int RP = 256 / KG;         // rows per pass
+  constexpr int NT = WAVES * 64;
+  constexpr int RP = NT / KG;          // rows per pass
   constexpr int A_N = BM / RP, B_N = BN / RP;
-  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int WSPLIT = WAVES == 4 ? 2 : 1;   // waves per tile dimension
+  constexpr int TM = BM / WSPLIT / 32, TN = BN / WSPLIT / 32;
   constexpr int A_FLOATS = BM * LDK, B_FLOATS = BN * LDK, STAGE = A_FLOATS + B_FLOATS;
   extern __shared__ __align__(16) float smem[];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = WAVES == 4 ? wave >> 1 : 0, wn = WAVES == 4 ? wave & 1 : 0, half = lane >> 5, l31 = lane & 31;
   const int g = t % KG, r = t / KG;
   const int ntile = tiles_m * tiles_n;
   const int total = ntile * batch;
@@ -84,9 +86,9 @@ __global__ __launch_bounds__(256, MINW) void gemm_lab(const float* __restrict__ 
       const int kk = kg * 8 + half * 4;
       float4 fa[TM], fb[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4*>(As + (wm * (BM / 2) + i * 32 + l31) * LDK + kk);
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4*>(As + (wm * (BM / WSPLIT) + i * 32 + l31) * LDK + kk);
 #pragma unroll
-      for (int i = 0; i < TN; ++i) fb[i] = *reinterpret_cast<const float4*>(Bs + (wn * (BN / 2) + i * 32 + l31) * LDK + kk);
+      for (int i = 0; i < TN; ++i) fb[i] = *reinterpret_cast<const float4*>(Bs + (wn * (BN / WSPLIT) + i * 32 + l31) * LDK + kk);
       if (ABL == 4) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa[i].x), "v"(fa[i].y), "v"(fa[i].z), "v"(fa[i].w));
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_lab(const float* __restrict__ 
   auto epilogue = [&](int m0, int n0, int by) {
     float* Cb = C + by * c_bs;
     if (TR) {   // D' = (C tile)^T: lane l31 = row m, registers 4g..4g+3 = columns 8g + 4 half + (0..3): one 16-byte store each
-      const int row0 = m0 + wm * (BM / 2) + l31, col0 = n0 + wn * (BN / 2) + 4 * half;
+      const int row0 = m0 + wm * (BM / WSPLIT) + l31, col0 = n0 + wn * (BN / WSPLIT) + 4 * half;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_lab(const float* __restrict__ 
           }
       return;
     }
-    const int rbase = m0 + wm * (BM / 2) + 4 * half, cbase = n0 + wn * (BN / 2) + l31;
+    const int rbase = m0 + wm * (BM / WSPLIT) + 4 * half, cbase = n0 + wn * (BN / WSPLIT) + l31;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -237,22 +239,22 @@ __global__ __launch_bounds__(256, MINW) void gemm_lab(const float* __restrict__ 
 
 struct Shape { const char* name; int M, N, K, batch; };
 
-template <int BM, int BN, int BKK, int NST, int PERSIST, int ABL, int MINW, int TR = 0, int PF2 = 0>
+template <int BM, int BN, int BKK, int NST, int PERSIST, int ABL, int MINW, int TR = 0, int PF2 = 0, int WAVES = 4>
 double run(const Shape& s, const float* A, const float* B, float* C, int per_cu, int iters = 20, size_t extra_lds = 0) {
   const int tiles_m = (s.M + BM - 1) / BM, tiles_n = (s.N + BN - 1) / BN;
   const int total = tiles_m * tiles_n * s.batch;
   const size_t smem = (size_t)NST * (BM + BN) * (BKK + 4) * sizeof(float) + extra_lds;
-  auto kern = gemm_lab<BM, BN, BKK, NST, PERSIST, ABL, MINW, TR, PF2>;
+  auto kern = gemm_lab<BM, BN, BKK, NST, PERSIST, ABL, MINW, TR, PF2, WAVES>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   const int grid = PERSIST ? std::min(total, 256 * per_cu) : total;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 3; ++i)
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, 0, A, B, C, s.M, s.N, s.K, (long)s.M * s.K, (long)s.N * s.K, (long)s.M * s.N, tiles_m, tiles_n, s.batch);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), smem, 0, A, B, C, s.M, s.N, s.K, (long)s.M * s.K, (long)s.N * s.K, (long)s.M * s.N, tiles_m, tiles_n, s.batch);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0, 0));
   for (int i = 0; i < iters; ++i)
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, 0, A, B, C, s.M, s.N, s.K, (long)s.M * s.K, (long)s.N * s.K, (long)s.M * s.N, tiles_m, tiles_n, s.batch);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), smem, 0, A, B, C, s.M, s.N, s.K, (long)s.M * s.K, (long)s.N * s.K, (long)s.M * s.N, tiles_m, tiles_n, s.batch);
   CK(hipEventRecord(e1, 0));
   CK(hipEventSynchronize(e1));
   float ms = 0;
@@ -306,25 +308,16 @@ int main(int argc, char** argv) {
   for (const Shape& s : shapes) {
     const double fl = 2.0 * s.M * s.N * s.K * s.batch;
     auto rep = [&](const char* v, double us) { printf("%-30s %-44s %9.1f %8.1f\n", s.name, v, us, fl / us * 1e-6); fflush(stdout); };
-    rep("128x128 nst1 (production)", run<128, 128, 32, 1, 0, 0, 2>(s, A, B, C, 0));
-    rep("128x128 nst1 occ2", run<128, 128, 32, 1, 0, 0, 2>(s, A, B, C, 0, 20, 20000));
-    rep("128x128 nst1 TR (float4 stores)", run<128, 128, 32, 1, 0, 0, 2, 1>(s, A, B, C, 0));
+    rep("128x128 nst1 4 waves (production wino)", run<128, 128, 32, 1, 0, 0, 2>(s, A, B, C, 0));
+    rep("64x64 nst1 4 waves (production 1x1)", run<64, 64, 32, 1, 0, 0, 2>(s, A, B, C, 0));
+    rep("64x64 nst1 LONE WAVE", run<64, 64, 32, 1, 0, 0, 1, 0, 0, 1>(s, A, B, C, 0));
     printf("   max |err| vs fp64 dot: %.3g\n", check(s, A, B, C));
-    rep("128x128 nst1 TR occ2", run<128, 128, 32, 1, 0, 0, 2, 1>(s, A, B, C, 0, 20, 20000));
-    rep("128x128 nst1 TR PF2", run<128, 128, 32, 1, 0, 0, 2, 1, 1>(s, A, B, C, 0));
-    printf("   max |err| vs fp64 dot: %.3g\n", check(s, A, B, C));
-    rep("128x128 nst1 PF2", run<128, 128, 32, 1, 0, 0, 2, 0, 1>(s, A, B, C, 0));
-    rep("128x128 nst1 TR persistent x2", run<128, 128, 32, 1, 1, 0, 2, 1>(s, A, B, C, 2));
-    printf("   max |err| vs fp64 dot: %.3g\n", check(s, A, B, C));
-    rep("128x128 nst1 TR persistent x3", run<128, 128, 32, 1, 1, 0, 2, 1>(s, A, B, C, 3));
-    rep("128x128 nst2 TR persistent x2", run<128, 128, 32, 2, 1, 0, 2, 1>(s, A, B, C, 2));
-    rep("64x64 nst1 (production 1x1)", run<64, 64, 32, 1, 0, 0, 2>(s, A, B, C, 0));
-    rep("64x64 nst1 TR", run<64, 64, 32, 1, 0, 0, 2, 1>(s, A, B, C, 0));
-    rep("64x64 nst1 TR occ5", run<64, 64, 32, 1, 0, 0, 2, 1>(s, A, B, C, 0, 20, 10000));
-    rep("64x64 nst1 TR PF2", run<64, 64, 32, 1, 0, 0, 2, 1, 1>(s, A, B, C, 0));
-    rep("64x128 nst1 TR", run<64, 128, 32, 1, 0, 0, 2, 1>(s, A, B, C, 0));
-    rep("128x64 nst1 TR", run<128, 64, 32, 1, 0, 0, 2, 1>(s, A, B, C, 0));
-    rep("128x128 nst1 TR no-loads", run<128, 128, 32, 1, 0, 1, 2, 1>(s, A, B, C, 0));
+    rep("64x64 nst2 LONE WAVE", run<64, 64, 32, 2, 0, 0, 1, 0, 0, 1>(s, A, B, C, 0));
+    rep("64x64 nst1 LONE WAVE TR", run<64, 64, 32, 1, 0, 0, 1, 1, 0, 1>(s, A, B, C, 0));
+    rep("64x128 nst1 LONE WAVE", run<64, 128, 32, 1, 0, 0, 1, 0, 0, 1>(s, A, B, C, 0));
+    rep("128x64 nst1 LONE WAVE", run<128, 64, 32, 1, 0, 0, 1, 0, 0, 1>(s, A, B, C, 0));
+    rep("64x64 bk64 nst1 LONE WAVE", run<64, 64, 64, 1, 0, 0, 1, 0, 0, 1>(s, A, B, C, 0));
+    rep("64x64 nst1 LONE WAVE no-loads no-stores", run<64, 64, 32, 1, 0, 3, 1, 0, 0, 1>(s, A, B, C, 0));
   }
   return 0;
 }
