@@ -53,6 +53,7 @@ struct ConvK {
   const float* residual;
   long res_pitch;
   int relu;
+  int stage_ep;               // 1: epilogue staged through LDS (16-byte row stores); 0: per-element stores (PM_STAGE_EP=0, A/B)
 };
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -527,6 +528,54 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
     const bool plain = a.ksplit > 1 || !(a.bias || a.scale || a.residual || a.relu);
     const bool full = m0 + BM <= a.M && n0 + BN <= a.Nn;
     const int rbase = m0 + wm * (BM / WM) + 4 * half, cbase = n0 + wn * (BN / WN) + l31;
+    // Staged form (every 16-byte-aligned output): each wave parks 32 rows of its tile in LDS (the A / B stages are dead by now) and
+    // stores WHOLE row segments -- (BN / WN) / 4 lanes per row, 16 bytes per lane, full 128-byte lines -- instead of 16 four-byte stores
+    // per MFMA tile and lane. A finished tile is bound by the ISSUE of its stores, not by bandwidth: 64 -> 16 store instructions per
+    // lane and 128 x 128 tile (tools/micro/gemm_lab.hip: +4 ... +18 % on the store-heavy shapes, never slower). The fused epilogue
+    // operands are read as 16-byte vectors of the same row segments; values and their evaluation order are unchanged.
+    const bool vec = a.stage_ep && ((a.c_pitch | a.Nn | (a.residual ? a.res_pitch : 0)) & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(Cb) | reinterpret_cast<uintptr_t>(a.residual)) & 15) == 0;
+    if (vec) {
+      constexpr int WC = BN / WN, LDC = WC + 4, LPR = WC / 4, RPI = 64 / LPR;   // columns per wave, padded pitch, lanes per row, rows per instruction
+      static_assert(32 % RPI == 0, "row segments must tile the 32-row slab");
+      __syncthreads();                                  // every wave is done reading the last K-slab
+      float* Ws = smem + wave * 32 * LDC;
+      const int rr0 = lane / LPR, cc = (lane % LPR) * 4;
+      const int col = n0 + wn * WC + cc;
+      const bool cok = col < a.Nn;                      // Nn % 4 == 0: the quad is all in or all out
+      const bool aff = !plain && (a.bias || a.scale), res = !plain && a.residual, relu = !plain && a.relu;
+      float bi[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+      if (aff && cok) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (a.bias) bi[e] = a.bias[col + e];
+          if (a.scale) sc[e] = a.scale[col + e], sh[e] = a.shift[col + e];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) Ws[((q & 3) + 8 * (q >> 2) + 4 * half) * LDC + n * 32 + l31] = acc[i][n][q];
+#pragma unroll
+        for (int r0 = 0; r0 < 32; r0 += RPI) {
+          const int rr = r0 + rr0;
+          const long row = m0 + wm * (BM / WM) + i * 32 + rr;
+          float4 v = *reinterpret_cast<const float4*>(Ws + rr * LDC + cc);
+          if (row < a.M && cok) {
+            if (aff) v.x = (v.x + bi[0]) * sc[0] + sh[0], v.y = (v.y + bi[1]) * sc[1] + sh[1], v.z = (v.z + bi[2]) * sc[2] + sh[2], v.w = (v.w + bi[3]) * sc[3] + sh[3];
+            if (res) {
+              const float4 qv = PM_LD4(a.residual + row * a.res_pitch + col);
+              v.x += qv.x, v.y += qv.y, v.z += qv.z, v.w += qv.w;
+            }
+            if (relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+            PM_ST4(Cb + row * a.c_pitch + col, v);
+          }
+        }
+      }
+      return;
+    }
     if (full) {  // interior tile: straight-line epilogue specialised on the (wave-uniform) fused operations, no per-element predicate
       auto run = [&](auto AFF, auto RES, auto RELU) {
 #pragma unroll
@@ -939,7 +988,8 @@ void launch_nst(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
     return true;
   }();
   (void)attr_set;
-  hipLaunchKernelGGL((conv_igemm_kernel<MODE, BM, BN, WM, WN, KM, PREC, NST>), grid, dim3(256), smem / (NST == 1 ? 2 : 1), st, k);
+  const size_t ep_bytes = (size_t)4 * 32 * (BN / WN + 4) * sizeof(float);      // staged epilogue: four wave slabs
+  hipLaunchKernelGGL((conv_igemm_kernel<MODE, BM, BN, WM, WN, KM, PREC, NST>), grid, dim3(256), std::max(smem / (NST == 1 ? 2 : 1), ep_bytes), st, k);
 }
 // longest reduction (in K-steps per block) that takes the single-stage variant; PM_NST1_STEPS overrides it for tuning runs
 inline int nst1_max_steps() {
@@ -990,6 +1040,9 @@ int launch(const ConvK& k0, const Plan& p, hipStream_t st, int batch = 1, double
   k.ksplit = p.ksplit;
   k.kper = p.kper;
   dim3 grid(p.tiles_m * p.tiles_n, batch, p.ksplit);
+  // staged epilogue: in situ +3 ... +6 % on the convolutions whose output streams to HBM (every unbatched launch), -2 ... -4 % on the
+  // batched Winograd GEMMs whose product M[p] stays in L2 / Infinity Cache for the output transform (tools/gpu_env_ab2.sh PM_STAGE_EP)
+  if (batch != 1 && !getenv("PM_STAGE_EP")) k.stage_ep = 0;
   ProfRec rec;
   if (g_prof_on) {
     (void)hipEventCreate(&rec.a), (void)hipEventCreate(&rec.b);
@@ -1041,6 +1094,8 @@ void fill_geom(ConvK& k, const pm_tensor* x, const pm_tensor* y, const pm_conv_p
   k.sub = k.sub_cy = k.sub_cx = 0, k.Hc = x->h, k.Wc = x->w;
   k.bias = k.scale = k.shift = k.residual = nullptr;
   k.res_pitch = 0, k.relu = 0;
+  static const int stage_ep = getenv("PM_STAGE_EP") ? atoi(getenv("PM_STAGE_EP")) : 1;
+  k.stage_ep = stage_ep;
   k.a_bs = k.b_bs = k.c_bs = 0;
 }
 

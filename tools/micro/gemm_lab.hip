@@ -104,7 +104,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void gemm_lab(const float* __rest
           for (int n = 0; n < TN; ++n) {
             const float a = j == 0 ? fa[i].x : (j == 1 ? fa[i].y : (j == 2 ? fa[i].z : fa[i].w));
             const float b = j == 0 ? fb[n].x : (j == 1 ? fb[n].y : (j == 2 ? fb[n].z : fb[n].w));
-            acc[i][n] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc[i][n], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][n], 0, 0, 0);
+            acc[i][n] = TR == 1 ? __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc[i][n], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][n], 0, 0, 0);
           }
     }
   };
@@ -118,7 +118,29 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void gemm_lab(const float* __rest
   };
   auto epilogue = [&](int m0, int n0, int by) {
     float* Cb = C + by * c_bs;
-    if (TR) {   // D' = (C tile)^T: lane l31 = row m, registers 4g..4g+3 = columns 8g + 4 half + (0..3): one 16-byte store each
+    if (TR == 2) {   // stage each wave's 32-row slab through LDS and store whole rows: 4 rows x 256 B per instruction (BN/2 = 64 columns)
+      constexpr int WC = BN / WSPLIT, LDC = WC + 4;
+      float* Ws = smem + wave * 32 * LDC;           // wave-private; the A / B stages are dead (caller synchronised)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) Ws[((q & 3) + 8 * (q >> 2) + 4 * half) * LDC + n * 32 + l31] = acc[i][n][q];
+        // 64 lanes -> WC/4 lanes per row
+        constexpr int LPR = WC / 4, RPI = 64 / LPR;   // lanes per row, rows per instruction
+#pragma unroll
+        for (int r0 = 0; r0 < 32; r0 += RPI) {
+          const int rr = r0 + lane / LPR, cc = (lane % LPR) * 4;
+          const float4 v = *reinterpret_cast<const float4*>(Ws + rr * LDC + cc);
+          const int row = m0 + wm * (BM / WSPLIT) + i * 32 + rr, col = n0 + wn * WC + cc;
+          if (ABL == 2 || ABL == 3) asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+          else if (row < M && col < N) *reinterpret_cast<float4*>(Cb + (long)row * N + col) = v;
+        }
+      }
+      return;
+    }
+    if (TR == 1) {   // D' = (C tile)^T: lane l31 = row m, registers 4g..4g+3 = columns 8g + 4 half + (0..3): one 16-byte store each
       const int row0 = m0 + wm * (BM / WSPLIT) + l31, col0 = n0 + wn * (BN / WSPLIT) + 4 * half;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -200,6 +222,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void gemm_lab(const float* __rest
       }
       compute((nk - 1) & 1);
     }
+    if (TR == 2) __syncthreads();
     epilogue(m0, n0, by);
   } else {
     // persistent: block b walks tiles b, b + G, ...; consecutive blocks take consecutive tiles (same A row panel -> same XCD L2 is lost,
@@ -308,16 +331,18 @@ int main(int argc, char** argv) {
   for (const Shape& s : shapes) {
     const double fl = 2.0 * s.M * s.N * s.K * s.batch;
     auto rep = [&](const char* v, double us) { printf("%-30s %-44s %9.1f %8.1f\n", s.name, v, us, fl / us * 1e-6); fflush(stdout); };
-    rep("128x128 nst1 4 waves (production wino)", run<128, 128, 32, 1, 0, 0, 2>(s, A, B, C, 0));
-    rep("64x64 nst1 4 waves (production 1x1)", run<64, 64, 32, 1, 0, 0, 2>(s, A, B, C, 0));
-    rep("64x64 nst1 LONE WAVE", run<64, 64, 32, 1, 0, 0, 1, 0, 0, 1>(s, A, B, C, 0));
+    rep("128x128 nst1 (production wino)", run<128, 128, 32, 1, 0, 0, 2>(s, A, B, C, 0));
+    rep("128x128 nst1 LDS-staged row stores", run<128, 128, 32, 1, 0, 0, 2, 2>(s, A, B, C, 0));
     printf("   max |err| vs fp64 dot: %.3g\n", check(s, A, B, C));
-    rep("64x64 nst2 LONE WAVE", run<64, 64, 32, 2, 0, 0, 1, 0, 0, 1>(s, A, B, C, 0));
-    rep("64x64 nst1 LONE WAVE TR", run<64, 64, 32, 1, 0, 0, 1, 1, 0, 1>(s, A, B, C, 0));
-    rep("64x128 nst1 LONE WAVE", run<64, 128, 32, 1, 0, 0, 1, 0, 0, 1>(s, A, B, C, 0));
-    rep("128x64 nst1 LONE WAVE", run<128, 64, 32, 1, 0, 0, 1, 0, 0, 1>(s, A, B, C, 0));
-    rep("64x64 bk64 nst1 LONE WAVE", run<64, 64, 64, 1, 0, 0, 1, 0, 0, 1>(s, A, B, C, 0));
-    rep("64x64 nst1 LONE WAVE no-loads no-stores", run<64, 64, 32, 1, 0, 3, 1, 0, 0, 1>(s, A, B, C, 0));
+    rep("128x128 nst1 TR", run<128, 128, 32, 1, 0, 0, 2, 1>(s, A, B, C, 0));
+    rep("64x64 nst1 (production 1x1)", run<64, 64, 32, 1, 0, 0, 2>(s, A, B, C, 0));
+    rep("64x64 nst1 LDS-staged row stores", run<64, 64, 32, 1, 0, 0, 2, 2>(s, A, B, C, 0));
+    printf("   max |err| vs fp64 dot: %.3g\n", check(s, A, B, C));
+    rep("64x64 nst1 TR", run<64, 64, 32, 1, 0, 0, 2, 1>(s, A, B, C, 0));
+    rep("64x128 nst1", run<64, 128, 32, 1, 0, 0, 2>(s, A, B, C, 0));
+    rep("64x128 nst1 LDS-staged row stores", run<64, 128, 32, 1, 0, 0, 2, 2>(s, A, B, C, 0));
+    rep("128x128 nst1 no-stores", run<128, 128, 32, 1, 0, 2, 2>(s, A, B, C, 0));
+    rep("64x64 nst1 no-stores", run<64, 64, 32, 1, 0, 2, 2>(s, A, B, C, 0));
   }
   return 0;
 }
