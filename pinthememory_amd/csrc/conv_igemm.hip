@@ -93,11 +93,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   constexpr bool A_KC = (MODE != MODE_WGRAD);  // A tile stored [BM][LDK] (k contiguous) else [BK][BM]
   constexpr bool B_KC = (MODE == MODE_FWD);    // B tile stored [BN][LDK] else [BK][BN]
   constexpr bool FAST = (KM == K_FAST) && (MODE != MODE_WGRAD);
-  // TR: MFMA operands swapped, every 32x32 tile is accumulated transposed and stored with 16-byte vectors (see the epilogue). Taken for the
-  // data gradient, whose epilogue is the busiest (dx, usually with the fused skip-gradient read): +10...+20 % on its layer1 / layer2
-  // launches; forward and weight-gradient tiles measured 3-15 % slower that way (32-byte pieces of 32 rows per store instruction: twice
-  // the L1 -> L2 write requests of the 2 x 128-byte row form) and keep the row form.
-  constexpr bool TR = (MODE == MODE_DGRAD);
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_FLOATS = A_KC ? BM * LDK : BK * BM;
   constexpr int B_FLOATS = B_KC ? BN * LDK : BK * BN;
@@ -395,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int n = 0; n < TN; ++n)
-          acc[i][n] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[n], fa[i], acc[i][n], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[n], acc[i][n], 0, 0, 0);
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[n], acc[i][n], 0, 0, 0);
     } else if constexpr (PREC == 0) {
       const int kk = kg * 8 + half * 4;  // this lane-half's 4 consecutive k of the 8-k group
       float fa[TM][4], fb[TN][4];
@@ -427,8 +422,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int n = 0; n < TN; ++n)
-            acc[i][n] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(fb[n][j], fa[i][j], acc[i][n], 0, 0, 0)      // tile held transposed (see the epilogue)
-                           : __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[n][j], acc[i][n], 0, 0, 0);
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[n][j], acc[i][n], 0, 0, 0);
     } else {
       if (kg & 1) return;                       // bf16: two 16-k blocks per slab, issued on the even groups
       const int kk = (kg >> 1) * 16 + half * 8;  // this lane-half's 8 consecutive k of the 16-k block
@@ -465,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int n = 0; n < TN; ++n)
-          acc[i][n] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[n], fa[i], acc[i][n], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[n], acc[i][n], 0, 0, 0);
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[n], acc[i][n], 0, 0, 0);
     }
   };
   auto compute = [&](int buf) {
@@ -523,161 +517,81 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   }
 
   // ---- epilogue -------------------------------------------------------------------------------------------------
-  if constexpr (!TR) {   // row form: a lane holds one output column and 16 rows of it (the MFMA's native C layout)
-    float* Cb = a.C + by * a.c_bs + (a.ksplit > 1 ? (long)z * a.c_split : 0);
-    const bool plain = a.ksplit > 1 || !(a.bias || a.scale || a.residual || a.relu);
-    const bool full = m0 + BM <= a.M && n0 + BN <= a.Nn;
-    const int rbase = m0 + wm * (BM / WM) + 4 * half, cbase = n0 + wn * (BN / WN) + l31;
-    // Staged form (every 16-byte-aligned output): each wave parks 32 rows of its tile in LDS (the A / B stages are dead by now) and
-    // stores WHOLE row segments -- (BN / WN) / 4 lanes per row, 16 bytes per lane, full 128-byte lines -- instead of 16 four-byte stores
-    // per MFMA tile and lane. A finished tile is bound by the ISSUE of its stores, not by bandwidth: 64 -> 16 store instructions per
-    // lane and 128 x 128 tile (tools/micro/gemm_lab.hip: +4 ... +18 % on the store-heavy shapes, never slower). The fused epilogue
-    // operands are read as 16-byte vectors of the same row segments; values and their evaluation order are unchanged.
-    const bool vec = a.stage_ep && ((a.c_pitch | a.Nn | (a.residual ? a.res_pitch : 0)) & 3) == 0 &&
-                     ((reinterpret_cast<uintptr_t>(Cb) | reinterpret_cast<uintptr_t>(a.residual)) & 15) == 0;
-    if (vec) {
-      constexpr int WC = BN / WN, LDC = WC + 4, LPR = WC / 4, RPI = 64 / LPR;   // columns per wave, padded pitch, lanes per row, rows per instruction
-      static_assert(32 % RPI == 0, "row segments must tile the 32-row slab");
-      __syncthreads();                                  // every wave is done reading the last K-slab
-      float* Ws = smem + wave * 32 * LDC;
-      const int rr0 = lane / LPR, cc = (lane % LPR) * 4;
-      const int col = n0 + wn * WC + cc;
-      const bool cok = col < a.Nn;                      // Nn % 4 == 0: the quad is all in or all out
-      const bool aff = !plain && (a.bias || a.scale), res = !plain && a.residual, relu = !plain && a.relu;
-      float bi[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
-      if (aff && cok) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (a.bias) bi[e] = a.bias[col + e];
-          if (a.scale) sc[e] = a.scale[col + e], sh[e] = a.shift[col + e];
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int n = 0; n < TN; ++n)
-#pragma unroll
-          for (int q = 0; q < 16; ++q) Ws[((q & 3) + 8 * (q >> 2) + 4 * half) * LDC + n * 32 + l31] = acc[i][n][q];
-#pragma unroll
-        for (int r0 = 0; r0 < 32; r0 += RPI) {
-          const int rr = r0 + rr0;
-          const long row = m0 + wm * (BM / WM) + i * 32 + rr;
-          float4 v = *reinterpret_cast<const float4*>(Ws + rr * LDC + cc);
-          if (row < a.M && cok) {
-            if (aff) v.x = (v.x + bi[0]) * sc[0] + sh[0], v.y = (v.y + bi[1]) * sc[1] + sh[1], v.z = (v.z + bi[2]) * sc[2] + sh[2], v.w = (v.w + bi[3]) * sc[3] + sh[3];
-            if (res) {
-              const float4 qv = PM_LD4(a.residual + row * a.res_pitch + col);
-              v.x += qv.x, v.y += qv.y, v.z += qv.z, v.w += qv.w;
-            }
-            if (relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
-            PM_ST4(Cb + row * a.c_pitch + col, v);
-          }
-        }
-      }
-      return;
-    }
-    if (full) {  // interior tile: straight-line epilogue specialised on the (wave-uniform) fused operations, no per-element predicate
-      auto run = [&](auto AFF, auto RES, auto RELU) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int n = 0; n < TN; ++n) {
-            const int col = cbase + n * 32;
-            float bi = 0.f, sc = 1.f, sh = 0.f;
-            if constexpr (decltype(AFF)::value) {
-              if (a.bias) bi = a.bias[col];
-              if (a.scale) sc = a.scale[col], sh = a.shift[col];
-            }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-              const long row = rbase + i * 32 + (q & 3) + 8 * (q >> 2);
-              float v = acc[i][n][q];
-              if constexpr (decltype(AFF)::value) v = (v + bi) * sc + sh;
-              if constexpr (decltype(RES)::value) v += a.residual[row * a.res_pitch + col];
-              if constexpr (decltype(RELU)::value) v = fmaxf(v, 0.f);
-              Cb[row * a.c_pitch + col] = v;
-            }
-          }
-      };
-      using T1 = std::true_type;
-      using T0 = std::false_type;
-      const bool aff = !plain && (a.bias || a.scale), res = !plain && a.residual, relu = !plain && a.relu;
-      if (!aff && !res && !relu) run(T0{}, T0{}, T0{});
-      else if (!aff && res && !relu) run(T0{}, T1{}, T0{});       // dgrad + fused skip gradient
-      else if (aff && !res && !relu) run(T1{}, T0{}, T0{});       // conv + bias
-      else if (aff && !res && relu) run(T1{}, T0{}, T1{});        // eval: conv + folded BN + ReLU
-      else if (aff && res && relu) run(T1{}, T1{}, T1{});         // eval: bottleneck tail
-      else if (aff && res && !relu) run(T1{}, T1{}, T0{});
-      else if (!aff && res && relu) run(T0{}, T1{}, T1{});
-      else run(T0{}, T0{}, T1{});
-      return;
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int n = 0; n < TN; ++n) {
-        const int col = cbase + n * 32;
-        const bool cok = col < a.Nn;
-        float bi = 0.f, sc = 1.f, sh = 0.f;
-        if (!plain && cok) {
-          if (a.bias) bi = a.bias[col];
-          if (a.scale) sc = a.scale[col], sh = a.shift[col];
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int row = rbase + i * 32 + (q & 3) + 8 * (q >> 2);
-          if (row < a.M && cok) {
-            float v = acc[i][n][q];
-            if (!plain) {
-              v = (v + bi) * sc + sh;
-              if (a.residual) v += a.residual[(long)row * a.res_pitch + col];
-              if (a.relu) v = fmaxf(v, 0.f);
-            }
-            Cb[(long)row * a.c_pitch + col] = v;
-          }
-        }
-      }
-    return;
-  } else {
-    // Data gradient: the MFMAs ran with their operands swapped (D' = B-fragment x A-fragment = the 32x32 tile TRANSPOSED), so a lane
-    // holds ONE output row (m = lane & 31) and, per register quad g, FOUR CONSECUTIVE output columns 8 g + 4 (lane >> 5) + (0..3): every
-    // store (and every load of the fused skip gradient) is a 16-byte vector -- 16 + 16 memory instructions per lane and tile instead of
-    // 64 + 64. The products and the k order of every sum are unchanged: bit-identical to the row form.
+  // row form: a lane holds one output column and 16 rows of it (the MFMA's native C layout)
   float* Cb = a.C + by * a.c_bs + (a.ksplit > 1 ? (long)z * a.c_split : 0);
   const bool plain = a.ksplit > 1 || !(a.bias || a.scale || a.residual || a.relu);
   const bool full = m0 + BM <= a.M && n0 + BN <= a.Nn;
-  const int rbase = m0 + wm * (BM / WM) + l31, cbase = n0 + wn * (BN / WN) + 4 * half;
-  // 16-byte path: rows of C (and of the residual) 16-byte aligned, column count a multiple of four (a quad is then all in or all out)
-  const bool vec = ((a.c_pitch | a.Nn | (a.residual ? a.res_pitch : 0)) & 3) == 0 && ((reinterpret_cast<uintptr_t>(Cb) | reinterpret_cast<uintptr_t>(a.residual)) & 15) == 0;
-  if (full && vec) {  // interior tile: straight-line epilogue specialised on the (wave-uniform) fused operations, no per-element predicate
+  const int rbase = m0 + wm * (BM / WM) + 4 * half, cbase = n0 + wn * (BN / WN) + l31;
+  // Staged form (every 16-byte-aligned output): each wave parks 32 rows of its tile in LDS (the A / B stages are dead by now) and
+  // stores WHOLE row segments -- (BN / WN) / 4 lanes per row, 16 bytes per lane, full 128-byte lines -- instead of 16 four-byte stores
+  // per MFMA tile and lane. A finished tile is bound by the ISSUE of its stores, not by bandwidth: 64 -> 16 store instructions per
+  // lane and 128 x 128 tile (tools/micro/gemm_lab.hip: +4 ... +18 % on the store-heavy shapes, never slower). The fused epilogue
+  // operands are read as 16-byte vectors of the same row segments; values and their evaluation order are unchanged.
+  const bool vec = a.stage_ep && ((a.c_pitch | a.Nn | (a.residual ? a.res_pitch : 0)) & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(Cb) | reinterpret_cast<uintptr_t>(a.residual)) & 15) == 0;
+  if (vec) {
+    constexpr int WC = BN / WN, LDC = WC + 4, LPR = WC / 4, RPI = 64 / LPR;   // columns per wave, padded pitch, lanes per row, rows per instruction
+    static_assert(32 % RPI == 0, "row segments must tile the 32-row slab");
+    __syncthreads();                                  // every wave is done reading the last K-slab
+    float* Ws = smem + wave * 32 * LDC;
+    const int rr0 = lane / LPR, cc = (lane % LPR) * 4;
+    const int col = n0 + wn * WC + cc;
+    const bool cok = col < a.Nn;                      // Nn % 4 == 0: the quad is all in or all out
+    const bool aff = !plain && (a.bias || a.scale), res = !plain && a.residual, relu = !plain && a.relu;
+    float bi[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (aff && cok) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (a.bias) bi[e] = a.bias[col + e];
+        if (a.scale) sc[e] = a.scale[col + e], sh[e] = a.shift[col + e];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Ws[((q & 3) + 8 * (q >> 2) + 4 * half) * LDC + n * 32 + l31] = acc[i][n][q];
+#pragma unroll
+      for (int r0 = 0; r0 < 32; r0 += RPI) {
+        const int rr = r0 + rr0;
+        const long row = m0 + wm * (BM / WM) + i * 32 + rr;
+        float4 v = *reinterpret_cast<const float4*>(Ws + rr * LDC + cc);
+        if (row < a.M && cok) {
+          if (aff) v.x = (v.x + bi[0]) * sc[0] + sh[0], v.y = (v.y + bi[1]) * sc[1] + sh[1], v.z = (v.z + bi[2]) * sc[2] + sh[2], v.w = (v.w + bi[3]) * sc[3] + sh[3];
+          if (res) {
+            const float4 qv = PM_LD4(a.residual + row * a.res_pitch + col);
+            v.x += qv.x, v.y += qv.y, v.z += qv.z, v.w += qv.w;
+          }
+          if (relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+          PM_ST4(Cb + row * a.c_pitch + col, v);
+        }
+      }
+    }
+    return;
+  }
+  if (full) {  // interior tile: straight-line epilogue specialised on the (wave-uniform) fused operations, no per-element predicate
     auto run = [&](auto AFF, auto RES, auto RELU) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const long row = rbase + i * 32;
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int n = 0; n < TN; ++n)
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            const int col = cbase + n * 32 + 8 * g4;
-            float v[4] = {acc[i][n][4 * g4], acc[i][n][4 * g4 + 1], acc[i][n][4 * g4 + 2], acc[i][n][4 * g4 + 3]};
-            if constexpr (decltype(AFF)::value) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                if (a.bias) v[e] += a.bias[col + e];
-                if (a.scale) v[e] = v[e] * a.scale[col + e] + a.shift[col + e];
-              }
-            }
-            if constexpr (decltype(RES)::value) {
-              const float4 q = PM_LD4(a.residual + row * a.res_pitch + col);
-              v[0] += q.x, v[1] += q.y, v[2] += q.z, v[3] += q.w;
-            }
-            if constexpr (decltype(RELU)::value) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-            PM_ST4(Cb + row * a.c_pitch + col, make_float4(v[0], v[1], v[2], v[3]));
+        for (int n = 0; n < TN; ++n) {
+          const int col = cbase + n * 32;
+          float bi = 0.f, sc = 1.f, sh = 0.f;
+          if constexpr (decltype(AFF)::value) {
+            if (a.bias) bi = a.bias[col];
+            if (a.scale) sc = a.scale[col], sh = a.shift[col];
           }
-      }
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const long row = rbase + i * 32 + (q & 3) + 8 * (q >> 2);
+            float v = acc[i][n][q];
+            if constexpr (decltype(AFF)::value) v = (v + bi) * sc + sh;
+            if constexpr (decltype(RES)::value) v += a.residual[row * a.res_pitch + col];
+            if constexpr (decltype(RELU)::value) v = fmaxf(v, 0.f);
+            Cb[row * a.c_pitch + col] = v;
+          }
+        }
     };
     using T1 = std::true_type;
     using T0 = std::false_type;
@@ -693,35 +607,31 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
     return;
   }
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int row = rbase + i * 32;
-    if (row >= a.M) continue;
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int n = 0; n < TN; ++n)
+    for (int n = 0; n < TN; ++n) {
+      const int col = cbase + n * 32;
+      const bool cok = col < a.Nn;
+      float bi = 0.f, sc = 1.f, sh = 0.f;
+      if (!plain && cok) {
+        if (a.bias) bi = a.bias[col];
+        if (a.scale) sc = a.scale[col], sh = a.shift[col];
+      }
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int col = cbase + n * 32 + 8 * g4;
-        float v[4] = {acc[i][n][4 * g4], acc[i][n][4 * g4 + 1], acc[i][n][4 * g4 + 2], acc[i][n][4 * g4 + 3]};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (col + e >= a.Nn) continue;
+      for (int q = 0; q < 16; ++q) {
+        const int row = rbase + i * 32 + (q & 3) + 8 * (q >> 2);
+        if (row < a.M && cok) {
+          float v = acc[i][n][q];
           if (!plain) {
-            const float bi = a.bias ? a.bias[col + e] : 0.f, sc = a.scale ? a.scale[col + e] : 1.f, sh = a.scale ? a.shift[col + e] : 0.f;
-            v[e] = (v[e] + bi) * sc + sh;
-            if (a.residual) v[e] += a.residual[(long)row * a.res_pitch + col + e];
-            if (a.relu) v[e] = fmaxf(v[e], 0.f);
+            v = (v + bi) * sc + sh;
+            if (a.residual) v += a.residual[(long)row * a.res_pitch + col];
+            if (a.relu) v = fmaxf(v, 0.f);
           }
-        }
-        if (vec) {
-          if (col < a.Nn) PM_ST4(Cb + (long)row * a.c_pitch + col, make_float4(v[0], v[1], v[2], v[3]));
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (col + e < a.Nn) Cb[(long)row * a.c_pitch + col + e] = v[e];
+          Cb[(long)row * a.c_pitch + col] = v;
         }
       }
-  }
-  }
+    }
+  return;
 }
 
 // split-K combine: C[row][col] = epilogue( sum_z ws[z][row][col] ), fixed z order (deterministic).
