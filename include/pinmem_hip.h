@@ -210,6 +210,17 @@ int pm_mem_write_update_bwd(const float* u, const float* nomden, int m, int d, f
 /* ---- optimizer (optimizer.py:21-25: SGD momentum 0.9, wd 5e-4, no nesterov) on a flat parameter arena -------------- */
 int pm_sgd_momentum(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
                     float weight_decay, int first_step, void* stream);
+/* The same update for EVERY parameter tensor (multi-tensor apply): `entries` is a HOST array of n records; the library passes them to
+ * the device by value in the kernel arguments (32 records per launch), so nothing is copied or has to outlive the call. A fresh momentum buffer
+ * is all zeros (round(m * 0) + d == d: torch's first step). Roundings are torch.optim.SGD's: d = fma(wd, p, g); buf = round(m * buf) + d;
+ * p = fma(-lr, buf, p). Replaces torch.optim.SGD.step of optimizer.py:21-25 on the training step. */
+typedef struct pm_sgd_entry {
+  float* param;
+  const float* grad;
+  float* momentum_buffer;
+  int64_t numel;
+} pm_sgd_entry;
+int pm_sgd_momentum_multi(const pm_sgd_entry* entries, int n, float lr, float momentum, float weight_decay, void* stream);
 
 #ifdef __cplusplus
 }

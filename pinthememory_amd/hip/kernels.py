@@ -461,6 +461,14 @@ def sgd_momentum(param, grad, buf, lr, momentum, wd, first):
     check(_lib().pm_sgd_momentum(param.data_ptr(), grad.data_ptr(), buf.data_ptr(), param.numel(), lr, momentum, wd, 1 if first else 0, stream()), 'pm_sgd_momentum')
 
 
+def sgd_momentum_multi(triples, lr, momentum, wd):
+    """triples: [(param, grad, momentum_buffer)] of same-layout dense fp32 CUDA tensors; updated in place by a few launches."""
+    arr = (L.PmSgdEntry * len(triples))()
+    for i, (p, g, m) in enumerate(triples):
+        arr[i].param, arr[i].grad, arr[i].momentum_buffer, arr[i].numel = p.data_ptr(), g.data_ptr(), m.data_ptr(), p.numel()
+    check(_lib().pm_sgd_momentum_multi(arr, len(triples), lr, momentum, wd, stream()), 'pm_sgd_momentum_multi')
+
+
 def set_winograd(mode):
     """Winograd route of the wide stride-1 3x3 convs: 4 / True = prefer F(4x4,3x3) (default), 2 = F(2x2,3x3) only, 0 / False = direct."""
     mode = 4 if mode is True else (0 if mode is False else int(mode))

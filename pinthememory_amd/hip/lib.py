@@ -14,6 +14,10 @@ class PmTensor(ctypes.Structure):
     _fields_ = [('ptr', c_void_p), ('n', c_int32), ('h', c_int32), ('w', c_int32), ('c', c_int32), ('pitch', c_int64)]
 
 
+class PmSgdEntry(ctypes.Structure):
+    _fields_ = [('param', c_void_p), ('grad', c_void_p), ('momentum_buffer', c_void_p), ('numel', c_int64)]
+
+
 class PmConvParams(ctypes.Structure):
     _fields_ = [('kh', c_int32), ('kw', c_int32), ('stride', c_int32), ('pad', c_int32), ('dil', c_int32), ('prec', c_int32),
                 ('wino_v', c_void_p), ('wino_v_bytes', c_int64)]
@@ -92,6 +96,7 @@ SIGNATURES = {
     'pm_mem_write_update': (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
     'pm_mem_write_update_bwd': (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
     'pm_sgd_momentum': (_i, [_vp, _vp, _vp, _i64, _f, _f, _f, _i, _vp]),
+    'pm_sgd_momentum_multi': (_i, [_vp, _i, _f, _f, _f, _vp]),
 }
 
 _lib = None

@@ -1,0 +1,65 @@
+"""SGD with momentum and weight decay as ONE multi-tensor launch of the HIP library (pm_sgd_momentum_multi) instead of torch's three
+foreach passes -- the optimizer of /root/reference/optimizer.py:11-32 (SGD(lr, weight_decay=5e-4, momentum, nesterov=False)).
+
+A subclass of torch.optim.SGD: param_groups, `state[p]['momentum_buffer']`, state_dict() / load_state_dict() (the 'optimizer' entry of the
+reference's checkpoints, utils/misc.py:195-216) and LR schedulers are torch's own; only step() is replaced. The update is torch's formula
+    d = g + wd * p ;  buf = momentum * buf + d ;  p = p - lr * buf
+with a fresh buffer starting at zero (0 * momentum + d == d, torch's first step). CPU parameters (the gloo tests) take torch's step."""
+import torch
+
+from .hip import kernels as K
+
+
+def _dense_like(a, b):
+    return a.stride() == b.stride() and a.dtype == b.dtype == torch.float32 and a.is_cuda and b.is_cuda
+
+
+class SGD(torch.optim.SGD):
+    def __init__(self, params, lr=0.01, momentum=0.9, weight_decay=5e-4, nesterov=False, **kw):
+        super().__init__(params, lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=nesterov, **kw)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            plain = (group['momentum'] != 0 and group['dampening'] == 0 and not group['nesterov'] and not group.get('maximize', False))
+            fused, rest = [], []
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+                if not (plain and p.is_cuda and p.dtype == torch.float32 and dense and not p.grad.is_sparse):
+                    rest.append(p)       # CPU tensors (gloo tests), exotic layouts: torch's own arithmetic
+                    continue
+                g = p.grad
+                if not _dense_like(p, g):      # e.g. a reducer that hands back row-major gradients for channels-last weights
+                    g = torch.empty_like(p, memory_format=torch.preserve_format).copy_(g)
+                st = self.state[p]
+                buf = st.get('momentum_buffer')
+                if buf is None or not _dense_like(p, buf):
+                    new = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    if buf is not None:
+                        new.copy_(buf)
+                    buf = st['momentum_buffer'] = new
+                fused.append((p, g, buf))
+            if fused:
+                K.sgd_momentum_multi(fused, float(group['lr']), float(group['momentum']), float(group['weight_decay']))
+            if rest:
+                self._torch_step(group, rest)
+        return loss
+
+    def _torch_step(self, group, params):
+        for p in params:
+            d = p.grad.add(p, alpha=group['weight_decay']) if group['weight_decay'] != 0 else p.grad
+            if group['momentum'] != 0:
+                st = self.state[p]
+                buf = st.get('momentum_buffer')
+                if buf is None:
+                    buf = st['momentum_buffer'] = torch.clone(d).detach()
+                else:
+                    buf.mul_(group['momentum']).add_(d, alpha=1 - group['dampening'])
+                d = d.add(buf, alpha=group['momentum']) if group['nesterov'] else buf
+            p.add_(d, alpha=-group['lr'])

@@ -382,6 +382,34 @@ def test_sgd(K):
     assert rel(pg, pr.detach()) < 1e-6
 
 
+def test_sgd_multi_tensor_optimizer(K):
+    """pinthememory_amd.optim.SGD (one pm_sgd_momentum_multi launch for all tensors) against torch.optim.SGD on the same parameters / gradients:
+    mixed shapes (channels-last 4-D weights, odd lengths, one tensor larger than a chunk), three steps, LR changed in between, then a
+    state_dict round trip through torch's own optimizer."""
+    from pinthememory_amd.optim import SGD
+    shapes = [(64, 3, 7, 7), (19,), (256, 64, 1, 1), (5001,), (128, 128, 3, 3), (1,)]
+    ref = [rnd(*s, seed=i).requires_grad_(True) for i, s in enumerate(shapes)]
+    got = [t.detach().clone().cuda() for t in ref]
+    got = [(t.contiguous(memory_format=torch.channels_last) if t.dim() == 4 else t).requires_grad_(True) for t in got]
+    o_ref = torch.optim.SGD(ref, lr=0.01, momentum=0.9, weight_decay=5e-4)
+    o_got = SGD(got, lr=0.01, momentum=0.9, weight_decay=5e-4)
+    for it in range(3):
+        for i, (a, b) in enumerate(zip(ref, got)):
+            g = rnd(*a.shape, seed=100 + 10 * it + i)
+            a.grad = g.clone()
+            b.grad = (g.cuda().contiguous(memory_format=torch.channels_last) if g.dim() == 4 else g.cuda())
+        for o in (o_ref, o_got):
+            o.param_groups[0]['lr'] = 0.01 * (0.5 ** it)
+            o.step()
+        for a, b in zip(ref, got):
+            assert rel(b.detach(), a.detach()) < 2e-7          # same formula; CPU / GPU fma contraction may differ in the last bit
+            assert rel(o_got.state[b]['momentum_buffer'], o_ref.state[a]['momentum_buffer']) < 2e-7
+    sd = o_got.state_dict()
+    assert sorted(sd['state'].keys()) == list(range(len(shapes))) and all('momentum_buffer' in v for v in sd['state'].values())
+    o2 = torch.optim.SGD([t.detach().clone().requires_grad_(True) for t in got], lr=0.01, momentum=0.9, weight_decay=5e-4)
+    o2.load_state_dict(sd)                                  # the reference's checkpoint 'optimizer' entry: interchangeable with torch's own
+
+
 def test_bn_merge(K):
     """SyncBN moment merge kernel == the host formula used by the gloo tests == statistics of the concatenated batch."""
     from pinthememory_amd import dist as D
