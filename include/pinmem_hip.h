@@ -72,6 +72,9 @@ int pm_conv_bwd_weight(const pm_tensor* x, const pm_tensor* dy, float* dw_krsc, 
  * ~3e-6 of the output scale for F(4x4), ~4e-7 for F(2x2); the direct MFMA chain: ~5e-7).
  * mode: 0 = direct implicit GEMM everywhere, 2 = F(2x2) only, 4 = prefer F(4x4) (default). */
 int pm_set_winograd(int mode);
+/* prec = 2 weight gradients on pixel-contiguous bf16 copies of x (one per tap) and dy instead of the staged-fp32 form: 0 off (default: the
+ * copies cost more HBM time than the GEMM saves), 1 on. Process-wide like pm_set_winograd. */
+int pm_set_bf16_wgrad(int on);
 
 /* In-library HIP-event timing of the implicit-GEMM kernel (bench.py's roofline leg). While enabled every conv launch is
  * bracketed by two events on its stream; pm_profile_read sums duration and algorithmic FLOPs (2*M*N*K) of one

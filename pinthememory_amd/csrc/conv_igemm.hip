@@ -1192,6 +1192,62 @@ inline pm_conv_params dgrad_as_fwd(const pm_conv_params* p) {
 }
 inline bool dgrad_bf16_ok(const pm_conv_params* p) { return p->prec == 2 && p->stride == 1 && p->kh == p->kw && p->dil * (p->kh - 1) - p->pad >= 0; }
 
+// prec = 2 weight gradient: dw[co][(t, ci)] = sum_p dyt[co][p] * xt[t][ci][p] over the output pixels p -- with both operands transposed to
+// pixel-contiguous bf16 (pm_bf16_transpose_taps: per tap the input pixel each output pixel sees, zero outside the image) this is the same
+// k-contiguous GEMM as the forward pass (M = Cout, N = taps * Cin, K = pixels), split over K with fp32 slabs and a fixed-order reduce.
+// Off by default: the nine shifted copies of x a 3x3 layer needs cost more HBM time than the faster GEMM saves (bench.py --dtype bf16: GEMM
+// time 26.8 -> 23.0 ms/step, step 45.7 -> 48.1 ms); pm_set_bf16_wgrad(1) enables it (kernel tests, and the day the producers emit the copies).
+int g_bf16_wgrad = 0;
+struct Bf16WgradPlan {
+  bool use;
+  long P, M, Nn, Kf;
+  size_t dyt_bytes, xt_bytes;
+  Plan pl;
+};
+Bf16WgradPlan bf16_wgrad_plan(const pm_tensor* x, const pm_tensor* dy, const pm_conv_params* p) {
+  Bf16WgradPlan b{};
+  if (p->prec != 2 || !g_bf16_wgrad || x->c < 32 || dy->c < 32) return b;
+  b.P = pm_pixels(dy);
+  if (b.P % 64) return b;                                           // whole K-slabs of 64 pixels
+  const long T = (long)p->kh * p->kw;
+  b.M = dy->c, b.Nn = T * x->c, b.Kf = b.P / 2;
+  const size_t dyt = (size_t)dy->c * b.P * 2, xt = (size_t)T * x->c * b.P * 2;
+  if (dyt >= (1ull << 31) || xt >= (1ull << 31)) return b;
+  b.dyt_bytes = pm_align_up(dyt, 256), b.xt_bytes = pm_align_up(xt, 256);
+  b.pl = make_plan(MODE_FWD, b.M, b.Nn, b.Kf, true);
+  if (b.pl.bn < 64) return b;
+  b.use = true;
+  return b;
+}
+inline size_t bf16_wgrad_ws(const Bf16WgradPlan& b) { return b.dyt_bytes + b.xt_bytes + pm_align_up(b.pl.ws_bytes, 256); }
+
+int conv_wgrad_bf16(const pm_tensor* x, const pm_tensor* dy, float* dw, const pm_conv_params* p, const Bf16WgradPlan& b, void* ws, hipStream_t st) {
+  char* dyt = (char*)ws;
+  char* xt = dyt + b.dyt_bytes;
+  float* slab = (float*)(xt + b.xt_bytes);
+  // dy -> dyt[Cout][P]: the plain transpose (one "tap", stride 1, no padding, input grid = output grid)
+  if (int e = pm_bf16_transpose_taps((const float*)dy->ptr, dy->pitch, dy->c, dy->n, dy->h, dy->w, dy->h, dy->w, 1, 1, 1, 0, 1, dyt, st)) return e;
+  if (int e = pm_bf16_transpose_taps((const float*)x->ptr, x->pitch, x->c, x->n, x->h, x->w, dy->h, dy->w, p->kh, p->kw, p->stride, p->pad, p->dil, xt, st)) return e;
+  const int Pf = (int)(b.P / 2);
+  const pm_tensor av = {dyt, 1, 1, (int32_t)b.M, Pf, Pf};          // fp32-typed views: rows of P / 2 floats
+  const pm_tensor cv = {dw, 1, 1, (int32_t)b.M, (int32_t)b.Nn, b.Nn};
+  const pm_conv_params p1 = {1, 1, 1, 0, 1, 2};
+  ConvK k;
+  fill_geom(k, &av, &cv, &p1);
+  k.prec = 2;
+  k.A = (const float*)dyt, k.B = (const float*)xt;
+  k.M = (int)b.M, k.Nn = (int)b.Nn, k.K = (int)b.Kf;
+  k.a_bytes = (unsigned)((size_t)b.M * b.P * 2), k.b_bytes = (unsigned)((size_t)b.Nn * b.P * 2), k.kmode = K_FAST;
+  const double flops = 2.0 * (double)b.M * (double)b.Nn * (double)b.P;
+  if (b.pl.ksplit > 1) {
+    k.C = slab, k.c_pitch = b.Nn, k.c_split = b.M * b.Nn;
+    if (int e = launch<MODE_FWD>(k, b.pl, st, 1, flops)) return e;
+    return splitk_reduce(slab, b.pl.ksplit, b.M, b.Nn, dw, b.Nn, nullptr, nullptr, nullptr, nullptr, 0l, 0, st);
+  }
+  k.C = dw, k.c_pitch = b.Nn, k.c_split = 0;
+  return launch<MODE_FWD>(k, b.pl, st, 1, flops);
+}
+
 void gemm_dims(int which, const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p, long& M, long& Nn, long& K) {
   const long T = (long)p->kh * p->kw;
   if (which == MODE_FWD) M = pm_pixels(y), Nn = y->c, K = T * x->c;
@@ -1204,6 +1260,10 @@ void gemm_dims(int which, const pm_tensor* x, const pm_tensor* y, const pm_conv_
 extern "C" int pm_set_winograd(int mode) {
   PM_REQUIRE(mode == 0 || mode == 2 || mode == 4, PM_EINVAL, "pm_set_winograd: mode %d (0 off, 2 F(2x2,3x3), 4 prefer F(4x4,3x3))", mode);
   g_wino_mode = mode;
+  return PM_OK;
+}
+extern "C" int pm_set_bf16_wgrad(int on) {
+  g_bf16_wgrad = on != 0;
   return PM_OK;
 }
 extern "C" int pm_profile_enable(int on) {
@@ -1283,6 +1343,10 @@ extern "C" size_t pm_conv_workspace(const pm_tensor* x, const pm_tensor* y, cons
     if (wp.use) return wino_ws(wp);
   }
   const size_t bias_part = pm_align_up((size_t)pm_cdiv(pm_pixels(y), colsum_rows(pm_pixels(y), y->c)) * y->c * sizeof(float), 256);
+  if (which == MODE_WGRAD && p->prec == 2) {
+    const Bf16WgradPlan b = bf16_wgrad_plan(x, y, p);
+    if (b.use) return pm_align_up(bf16_wgrad_ws(b), 256) + bias_part;
+  }
   if (which == MODE_WGRAD) {
     const WinoPlan wp = wino_plan(x, y->c, p, true);
     if (wp.use) return pm_align_up(wino_wgrad_ws(wp, wino_wgrad_plan(wp, y->c)), 256) + bias_part;
@@ -1441,6 +1505,11 @@ extern "C" int pm_conv_bwd_weight(const pm_tensor* x, const pm_tensor* dy, float
   Plan pl = make_plan(MODE_WGRAD, M, Nn, K, p->prec != 0);
   const size_t need = pm_conv_workspace(x, dy, p, MODE_WGRAD);
   PM_REQUIRE(need <= ws_bytes && ws, PM_EWORKSPACE, "conv_bwd_weight: workspace %zu < %zu", ws_bytes, need);
+  const Bf16WgradPlan bw = bf16_wgrad_plan(x, dy, p);
+  if (bw.use) {
+    if (int e = conv_wgrad_bf16(x, dy, dw, p, bw, ws, (hipStream_t)stream)) return e;
+    pl.ws_bytes = bf16_wgrad_ws(bw);       // the bias partials follow the bf16 buffers
+  }
   const WinoPlan wp = wino_plan(x, dy->c, p, true);
   if (wp.use) {
     const WinoWgradPlan q = wino_wgrad_plan(wp, dy->c);
@@ -1454,7 +1523,7 @@ extern "C" int pm_conv_bwd_weight(const pm_tensor* x, const pm_tensor* dy, float
   k.M = (int)M, k.Nn = (int)Nn, k.K = (int)K;
   k.a_bytes = (unsigned)(pm_pixels(dy) * dy->pitch * 4), k.b_bytes = (unsigned)(pm_pixels(x) * x->pitch * 4), k.kmode = dy->w >= BK ? 1 : 2;
   hipStream_t st = (hipStream_t)stream;
-  if (wp.use) {
+  if (wp.use || bw.use) {
   } else if (pl.ksplit > 1) {
     k.C = (float*)ws, k.c_pitch = Nn, k.c_split = M * Nn;
     if (int e = launch<MODE_WGRAD>(k, pl, st)) return e;

@@ -475,6 +475,10 @@ def set_winograd(mode):
     check(_lib().pm_set_winograd(mode), 'pm_set_winograd')
 
 
+def set_bf16_wgrad(on):
+    check(_lib().pm_set_bf16_wgrad(1 if on else 0), 'pm_set_bf16_wgrad')
+
+
 def profile_enable(on):
     check(_lib().pm_profile_enable(1 if on else 0), 'pm_profile_enable')
 

@@ -439,7 +439,7 @@ BF16_CASES = [CONV_CASES[1], CONV_CASES[3], CONV_CASES[5], CONV_CASES[8], CONV_C
               (1, 512, 12, 12, 512, 3, 1, 2, 2, False)]
 
 
-@pytest.mark.parametrize('form', ['bf16', 'bf16_staged'])
+@pytest.mark.parametrize('form', ['bf16', 'bf16_staged', 'bf16+wgrad'])
 @pytest.mark.parametrize('case', BF16_CASES)
 def test_conv_bf16_operands(K, case, form):
     """BASELINE configs[2]: operands rounded to bf16 (RNE) feeding v_mfma_f32_32x32x16_bf16, fp32 accumulation -- the bf16-operand form
@@ -452,7 +452,8 @@ def test_conv_bf16_operands(K, case, form):
     xr, wr = r16(x).requires_grad_(True), r16(wt).requires_grad_(True)
     y_ref = F.conv2d(xr, wr, None, stride=s, padding=p, dilation=d)
     dy = rnd(*y_ref.shape, seed=4)
-    K.set_conv_precision(form)
+    K.set_conv_precision(form.split('+')[0])
+    K.set_bf16_wgrad(form.endswith('+wgrad'))       # weight gradient on pixel-contiguous bf16 copies (off by default)
     try:
         xg, wg = nhwc(x), wt.permute(0, 2, 3, 1).contiguous().cuda()
         y = K.conv_fwd(xg, wg, s, p, d)
@@ -463,6 +464,7 @@ def test_conv_bf16_operands(K, case, form):
         dw, _ = K.conv_bwd_weight(xg, dyg, tuple(wg.shape), s, p, d)
     finally:
         K.set_conv_precision('f32')
+        K.set_bf16_wgrad(False)
     # backward oracles: dgrad rounds (dy, w); wgrad rounds (x, dy)
     F.conv2d(x.clone().requires_grad_(True), wr, None, stride=s, padding=p, dilation=d)
     x2 = x.clone().requires_grad_(True)
