@@ -159,7 +159,11 @@ def _bn_train_bwd(dv, o, y, mean, invstd, gamma, beta, relu, group, want_dres, h
     mode = 0 if not relu else (1 if has_res else 2)
     hand_over = mode == 1 and want_dres
     sums, gm = K.bn_bwd_reduce(dv, o, y, mean, invstd, mode, gamma, beta, want_gmask=hand_over, with_count=group is not None)
+    local = sums
     if group is not None:
+        # dgamma / dbeta are THIS rank's sums (torch.nn.SyncBatchNorm returns the local grad_weight / grad_bias and lets DDP average them);
+        # only the input gradient needs the sums over all ranks
+        local = sums.clone()
         sums = D.all_reduce_sum(sums, group)       # [sum dy | sum dy * xhat | count]: the global count travels with the sums (uneven batches)
     count = float(y.shape[0] * y.shape[1] * y.shape[2]) if group is None else -1.0
     if hand_over:
@@ -167,7 +171,7 @@ def _bn_train_bwd(dv, o, y, mean, invstd, gamma, beta, relu, group, want_dres, h
         dres = gm
     else:
         dy, dres = K.bn_bwd_apply(dv, o, y, mean, invstd, gamma, sums, count, mode, want_dres, beta)
-    return dy, dres, sums[c:2 * c], sums[:c]
+    return dy, dres, local[c:2 * c], local[:c]
 
 
 class _Bottleneck(torch.autograd.Function):

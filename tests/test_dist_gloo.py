@@ -240,3 +240,86 @@ def test_one_rank_rccl_step_equals_plain_step():
         assert lines, r.stdout[-2000:] + r.stderr[-4000:]
         digests.append(lines[0].split()[1:])
     assert digests[0] == digests[1] == digests[2], digests
+
+
+# ---- GPU: two REAL ranks (gloo, sharing the one GPU of the box) against the single-process big batch ------------------------------------
+_TWO_RANK_PROBE = r'''
+import os, sys, torch
+out_path, world = sys.argv[1], int(sys.argv[2])
+rank = int(os.environ.get('RANK', '0'))
+torch.cuda.set_device(0)
+if world > 1:
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+from pinthememory_amd import dist as D, harness, synth
+from pinthememory_amd.network import deepv3plus
+crit = torch.nn.CrossEntropyLoss(reduction='mean', ignore_index=255)
+net = synth.load_det_weights(deepv3plus.DeepR50V3PlusD(synth.model_args(), 19, crit, crit)).cuda()
+net.dsn[3].p = 0.0
+if world > 1:
+    net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)          # train.py:95
+x, y = synth.make_batch(4, 128, seed=5)
+per = 4 // world
+x, y = x[rank * per:(rank + 1) * per].cuda(), y[rank * per:(rank + 1) * per].cuda()
+net.train()
+outs = net(x, gts=y, aux_gts=y, memory_writing=True, writing_detach=True)
+# a loss that is a plain SUM over images: sum over ranks == the big-batch value, so all-reduced (SUM) gradients must equal the big-batch gradients
+loss = outs[-1].square().sum() * 1e-3
+loss.backward()
+names = ['layer0.0.weight', 'layer1.0.bn3.weight', 'layer2.1.conv2.weight', 'layer3.0.downsample.0.weight', 'layer4.2.bn2.bias', 'aspp.features.2.0.weight',
+         'aspp.img_conv.1.weight', 'bot_aspp.0.weight']
+params = dict(net.named_parameters())
+grads = {}
+for n in names:
+    g = params[n].grad.detach().clone().contiguous()
+    if world > 1:
+        dist.all_reduce(g)                                            # C1: SUM (the probe's loss is a sum over images)
+    grads[n] = g.cpu()
+bufs = dict(net.named_buffers())
+res = dict(m_items=net.memory.m_items.detach().cpu(), loss=loss.detach().cpu(), grads=grads,
+           running={n: bufs[n].cpu() for n in ('layer0.1.running_mean', 'layer3.2.bn2.running_var', 'aspp.img_conv.1.running_var', 'memory.writenet.writefeat.1.running_mean')})
+if world > 1:
+    t = loss.detach().clone()
+    dist.all_reduce(t)
+    res['loss'] = t.cpu()
+if rank == 0:
+    torch.save(res, out_path)
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+print('PROBE_DONE', rank)
+'''
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_gpu_equal_single_process_big_batch(tmp_path):
+    """World size 2 for real (two processes, gloo, both on the box's one GPU; RCCL refuses two ranks on one device): rank r runs images
+    [2r, 2r + 2) through the HIP path with every BatchNorm converted to SyncBatchNorm (train.py:95) and the memory-slot all-reduce on. Against
+    ONE process running all four images: the committed memory (C3), the BatchNorm running moments incl. Memory_sup's own and the 4-sample
+    image-pooling BN (C2 forward), the summed loss to fp32 round-off, and the all-reduced gradients of eight parameters from stem to ASPP (C2 backward with the
+    all-reduced element count, C1) to the gradient gates of the parity tests."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    one, two = str(tmp_path / 'one.pt'), str(tmp_path / 'two.pt')
+    r = subprocess.run([sys.executable, '-c', _TWO_RANK_PROBE, one, '1'], cwd=root, capture_output=True, text=True, timeout=600)
+    assert 'PROBE_DONE 0' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    port = str(_free_port())
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=port, RANK=str(rank), WORLD_SIZE='2')
+        procs.append(subprocess.Popen([sys.executable, '-c', _TWO_RANK_PROBE, two, '2'], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all('PROBE_DONE' in o[0] for o in outs), ''.join(o[0][-1500:] + o[1][-3000:] for o in outs)
+    a, b = torch.load(one), torch.load(two)
+
+    def rel(u, v):
+        return ((u.double() - v.double()).norm() / (v.double().norm() + 1e-30)).item()
+    assert rel(b['m_items'], a['m_items']) < 1e-5
+    assert abs(b['loss'].item() - a['loss'].item()) < 1e-4 * abs(a['loss'].item())
+    for n in a['running']:
+        assert rel(b['running'][n], a['running'][n]) < 1e-5, n
+    errs = sorted((rel(b['grads'][n], a['grads'][n]), n) for n in a['grads'])
+    print('two-rank vs big-batch gradient errors:', [(round(e, 5), n) for e, n in errs])
+    # two fp32 evaluations of a ReLU network differ by the units that flip within round-off: the bounds of tests/test_model_parity.py
+    assert errs[-1][0] < 1e-2 and errs[0][0] < 1e-4, errs       # heads behind the last ReLU layers: round-off only; trunk: the ReLU-flip floor (~3e-3)
