@@ -331,18 +331,23 @@ int main(int argc, char** argv) {
   for (const Shape& s : shapes) {
     const double fl = 2.0 * s.M * s.N * s.K * s.batch;
     auto rep = [&](const char* v, double us) { printf("%-30s %-44s %9.1f %8.1f\n", s.name, v, us, fl / us * 1e-6); fflush(stdout); };
-    rep("128x128 nst1 (production wino)", run<128, 128, 32, 1, 0, 0, 2>(s, A, B, C, 0));
-    rep("128x128 nst1 LDS-staged row stores", run<128, 128, 32, 1, 0, 0, 2, 2>(s, A, B, C, 0));
+    rep("128x128 bk32 nst1 (Winograd GEMM tile)", run<128, 128, 32, 1, 0, 0, 2>(s, A, B, C, 0));
     printf("   max |err| vs fp64 dot: %.3g\n", check(s, A, B, C));
-    rep("128x128 nst1 TR", run<128, 128, 32, 1, 0, 0, 2, 1>(s, A, B, C, 0));
-    rep("64x64 nst1 (production 1x1)", run<64, 64, 32, 1, 0, 0, 2>(s, A, B, C, 0));
-    rep("64x64 nst1 LDS-staged row stores", run<64, 64, 32, 1, 0, 0, 2, 2>(s, A, B, C, 0));
-    printf("   max |err| vs fp64 dot: %.3g\n", check(s, A, B, C));
-    rep("64x64 nst1 TR", run<64, 64, 32, 1, 0, 0, 2, 1>(s, A, B, C, 0));
-    rep("64x128 nst1", run<64, 128, 32, 1, 0, 0, 2>(s, A, B, C, 0));
-    rep("64x128 nst1 LDS-staged row stores", run<64, 128, 32, 1, 0, 0, 2, 2>(s, A, B, C, 0));
-    rep("128x128 nst1 no-stores", run<128, 128, 32, 1, 0, 2, 2>(s, A, B, C, 0));
-    rep("64x64 nst1 no-stores", run<64, 64, 32, 1, 0, 2, 2>(s, A, B, C, 0));
+    rep("  ablation: no global loads", run<128, 128, 32, 1, 0, 1, 2>(s, A, B, C, 0));
+    rep("  ablation: no epilogue stores", run<128, 128, 32, 1, 0, 2, 2>(s, A, B, C, 0));
+    rep("  ablation: no loads, no stores (LDS + MFMA core)", run<128, 128, 32, 1, 0, 3, 2>(s, A, B, C, 0));
+    rep("  ablation: no MFMA (memory phases only)", run<128, 128, 32, 1, 0, 4, 2>(s, A, B, C, 0));
+    rep("128x128 + LDS-staged row stores", run<128, 128, 32, 1, 0, 0, 2, 2>(s, A, B, C, 0));
+    rep("128x128 + transposed tiles, 16-byte stores", run<128, 128, 32, 1, 0, 0, 2, 1>(s, A, B, C, 0));
+    rep("128x128 two LDS stages (one barrier per slab)", run<128, 128, 32, 2, 0, 0, 2>(s, A, B, C, 0));
+    rep("128x128 BK = 64", run<128, 128, 64, 1, 0, 0, 2>(s, A, B, C, 0));
+    rep("128x128 loads two slabs ahead", run<128, 128, 32, 1, 0, 0, 2, 0, 1>(s, A, B, C, 0));
+    rep("128x128 persistent blocks x2/CU, next tile prefetched", run<128, 128, 32, 1, 1, 0, 2>(s, A, B, C, 2));
+    rep("128x128 occupancy capped at 2 blocks/CU", run<128, 128, 32, 1, 0, 0, 2>(s, A, B, C, 0, 20, 20000));
+    rep("64x64 bk32 nst1 (1x1 convolution tile)", run<64, 64, 32, 1, 0, 0, 2>(s, A, B, C, 0));
+    rep("64x64 + LDS-staged row stores", run<64, 64, 32, 1, 0, 0, 2, 2>(s, A, B, C, 0));
+    rep("64x128", run<64, 128, 32, 1, 0, 0, 2>(s, A, B, C, 0));
+    rep("64x64, one wave per block (no cross-SIMD barrier)", run<64, 64, 32, 1, 0, 0, 1, 0, 0, 1>(s, A, B, C, 0));
   }
   return 0;
 }
