@@ -286,6 +286,165 @@ double run(const Shape& s, const float* A, const float* B, float* C, int per_cu,
   return ms / iters * 1e3;   // us
 }
 
+
+// ---- direct-to-LDS ring: global -> LDS by buffer_load ... lds (no VGPR round trip, no ds_write phase), STAGES buffers, counted vmcnt so
+// that the loads of the next STAGES - 1 slabs stay in flight across the one barrier per slab. LDS rows are 128 B (32 floats), unpadded;
+// bank conflicts of the b128 fragment reads are removed by an XOR swizzle applied on the SOURCE side (the DMA writes lane-linear).
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+typedef __attribute__((address_space(3))) void lds_void;
+template <int BM, int BN, int STAGES, int EPS>
+__global__ __launch_bounds__(256, 1) void gemm_glds(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K,
+                                                    long a_bs, long b_bs, long c_bs, int tiles_m, int tiles_n, int batch) {
+#if defined(__HIP_DEVICE_COMPILE__)      // the LDS-DMA builtin and the address-space casts exist on the device side only
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int STAGE_B = (BM + BN) * 128;                 // bytes per stage
+  constexpr int AI = BM / 32, BI = BN / 32;                // DMA instructions per wave and stage (8 rows each)
+  extern __shared__ __align__(16) float smem[];
+  char* sb = reinterpret_cast<char*>(smem);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+  const int ntile = tiles_m * tiles_n;
+  const int by = blockIdx.x / ntile;
+  const int lid = xcd_remap(blockIdx.x - by * ntile, ntile);
+  const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + by * a_bs), 0, M * K * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B + by * b_bs), 0, N * K * 4, 0x00020000);
+  // per-lane source offsets of this wave's DMA pieces (row R of the tile, swizzled 16-byte chunk)
+  int offA[AI], offB[BI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int R = wave * (BM / 4) + i * 8 + (lane >> 3), kc = (lane & 7) ^ ((R >> 1) & 7);
+    offA[i] = m0 + R < M ? ((m0 + R) * K) * 4 + kc * 16 : 0x7fffffff;
+  }
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int R = wave * (BN / 4) + i * 8 + (lane >> 3), kc = (lane & 7) ^ ((R >> 1) & 7);
+    offB[i] = n0 + R < N ? ((n0 + R) * K) * 4 + kc * 16 : 0x7fffffff;
+  }
+  // The DMA is issued from inline asm: hipcc does not track it, so it neither drains vmcnt before the next ds_read (it does for the builtin:
+  // every K-step waits for ALL loads in flight) nor reorders it; the counted waits below are the only ordering.
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sb;
+  const unsigned waveA = __builtin_amdgcn_readfirstlane(lds0 + wave * (BM / 4) * 128), waveB = __builtin_amdgcn_readfirstlane(lds0 + BM * 128 + wave * (BN / 4) * 128);
+  auto dma16 = [&](__amdgpu_buffer_rsrc_t r, unsigned lds_addr, int voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(r), "s"(lds_addr) : "memory");
+  };
+  auto issue = [&](int buf, int k0) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) dma16(rA, waveA + buf * STAGE_B + i * 8 * 128, offA[i] == 0x7fffffff ? 0x7fffffff : offA[i] + k0 * 4);
+#pragma unroll
+    for (int i = 0; i < BI; ++i) dma16(rB, waveB + buf * STAGE_B + i * 8 * 128, offB[i] == 0x7fffffff ? 0x7fffffff : offB[i] + k0 * 4);
+  };
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+  auto compute = [&](int buf) {
+    const char* As = sb + buf * STAGE_B;
+    const char* Bs = As + BM * 128;
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      const int kc = kg * 2 + half;
+      float4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * (BM / 2) + i * 32 + l31;
+        fa[i] = *reinterpret_cast<const float4*>(As + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int row = wn * (BN / 2) + i * 32 + l31;
+        fb[i] = *reinterpret_cast<const float4*>(Bs + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int n = 0; n < TN; ++n) {
+            const float a = j == 0 ? fa[i].x : (j == 1 ? fa[i].y : (j == 2 ? fa[i].z : fa[i].w));
+            const float b = j == 0 ? fb[n].x : (j == 1 ? fb[n].y : (j == 2 ? fb[n].z : fb[n].w));
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][n], 0, 0, 0);
+          }
+    }
+  };
+  const int nk = K / 32;
+  constexpr int PER = AI + BI;                             // DMA instructions per wave and stage
+  // prologue: STAGES - 1 slabs in flight
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) issue(s, s * 32);
+  for (int kt = 0; kt < nk; ++kt) {
+    // slab kt has landed once at most the later (STAGES - 2) slabs of this wave are outstanding
+    if (kt + STAGES - 2 < nk) wait_vm<PER*(STAGES - 2)>();
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();                          // every wave's pieces of slab kt are visible; slab kt - 1 is no longer read
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + STAGES - 1 < nk) issue((kt + STAGES - 1) % STAGES, (kt + STAGES - 1) * 32);
+    compute(kt % STAGES);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float* Cb = C + by * c_bs;
+  if (EPS) {   // staged row stores
+    constexpr int WC = BN / 2, LDC = WC + 4, LPR = WC / 4, RPI = 64 / LPR;
+    __syncthreads();
+    float* Ws = smem + wave * 32 * LDC;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Ws[((q & 3) + 8 * (q >> 2) + 4 * half) * LDC + n * 32 + l31] = acc[i][n][q];
+#pragma unroll
+      for (int r0 = 0; r0 < 32; r0 += RPI) {
+        const int rr = r0 + lane / LPR, cc = (lane % LPR) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(Ws + rr * LDC + cc);
+        const int row = m0 + wm * (BM / 2) + i * 32 + rr, col = n0 + wn * WC + cc;
+        if (row < M && col < N) *reinterpret_cast<float4*>(Cb + (long)row * N + col) = v;
+      }
+    }
+  } else {
+    const int rbase = m0 + wm * (BM / 2) + 4 * half, cbase = n0 + wn * (BN / 2) + l31;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = rbase + i * 32 + (q & 3) + 8 * (q >> 2), col = cbase + n * 32;
+          if (row < M && col < N) Cb[(long)row * N + col] = acc[i][n][q];
+        }
+  }
+#endif
+}
+
+template <int BM, int BN, int STAGES, int EPS>
+double run_glds(const Shape& s, const float* A, const float* B, float* C, int iters = 20) {
+  const int tiles_m = (s.M + BM - 1) / BM, tiles_n = (s.N + BN - 1) / BN;
+  const int total = tiles_m * tiles_n * s.batch;
+  const size_t smem = std::max<size_t>((size_t)STAGES * (BM + BN) * 128, (size_t)4 * 32 * (BN / 2 + 4) * 4);
+  auto kern = gemm_glds<BM, BN, STAGES, EPS>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i)
+    hipLaunchKernelGGL(kern, dim3(total), dim3(256), smem, 0, A, B, C, s.M, s.N, s.K, (long)s.M * s.K, (long)s.N * s.K, (long)s.M * s.N, tiles_m, tiles_n, s.batch);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < iters; ++i)
+    hipLaunchKernelGGL(kern, dim3(total), dim3(256), smem, 0, A, B, C, s.M, s.N, s.K, (long)s.M * s.K, (long)s.N * s.K, (long)s.M * s.N, tiles_m, tiles_n, s.batch);
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  CK(hipGetLastError());
+  return ms / iters * 1e3;
+}
+
 static void fill(float* d, size_t n, unsigned seed) {
   std::vector<float> h(n);
   unsigned x = seed * 2654435761u + 12345u;
@@ -348,6 +507,16 @@ int main(int argc, char** argv) {
     rep("64x64 + LDS-staged row stores", run<64, 64, 32, 1, 0, 0, 2, 2>(s, A, B, C, 0));
     rep("64x128", run<64, 128, 32, 1, 0, 0, 2>(s, A, B, C, 0));
     rep("64x64, one wave per block (no cross-SIMD barrier)", run<64, 64, 32, 1, 0, 0, 1, 0, 0, 1>(s, A, B, C, 0));
+    CK(hipMemset(C, 0, (size_t)s.M * s.N * s.batch * 4));
+    rep("DMA ring 128x128 3 stages, staged stores", run_glds<128, 128, 3, 1>(s, A, B, C));
+    printf("   max |err| vs fp64 dot: %.3g\n", check(s, A, B, C));
+    rep("DMA ring 128x128 2 stages, staged stores", run_glds<128, 128, 2, 1>(s, A, B, C));
+    rep("DMA ring 128x128 3 stages, element stores", run_glds<128, 128, 3, 0>(s, A, B, C));
+    rep("DMA ring 64x64 3 stages, staged stores", run_glds<64, 64, 3, 1>(s, A, B, C));
+    printf("   max |err| vs fp64 dot: %.3g\n", check(s, A, B, C));
+    rep("DMA ring 64x64 4 stages, staged stores", run_glds<64, 64, 4, 1>(s, A, B, C));
+    rep("DMA ring 64x128 3 stages, staged stores", run_glds<64, 128, 3, 1>(s, A, B, C));
+    rep("DMA ring 128x128 4 stages, staged stores", run_glds<128, 128, 4, 1>(s, A, B, C));
   }
   return 0;
 }
