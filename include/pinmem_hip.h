@@ -46,6 +46,11 @@ typedef struct pm_conv_epilogue { /* optional fused epilogue of pm_conv_fwd; all
   const float* residual;        /* NHWC, same n,h,w,c as y; += (Resnet.py:207) */
   int64_t residual_pitch;
   int32_t relu;                 /* max(.,0) last (Resnet.py:216) */
+  float* bn_partials;           /* optional (NULL: none): train-mode BatchNorm statistics of y produced by the epilogue itself -- per 32-row slab of the
+                                   GEMM and per channel (mean, M2), float[ceil(pixels / 32)][Cout][2], two-pass inside the slab -- so that no
+                                   separate pass re-reads y; merged by pm_bn_partials_finalize. Size from pm_conv_bn_partials_bytes
+                                   (0 = this call does not take the route: Winograd, split-K, unaligned / narrow outputs). Needs relu == 0, no residual. */
+  int64_t bn_partials_bytes;
 } pm_conv_epilogue;
 
 const char* pm_last_error(void);
@@ -56,6 +61,8 @@ int pm_version(void);
  * deepv2.py:44-51,138-151; memory.py:75,104.  y: [n,ho,wo,cout], x: [n,h,w,cin], cin % 4 == 0. */
 size_t pm_conv_workspace(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p, int which /*0 fwd,1 dgrad,2 wgrad*/);
 size_t pm_conv_winograd_v_bytes(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p);
+/* bytes of pm_conv_epilogue.bn_partials for this forward call, 0 if the call cannot emit them (then run pm_bn_stats* on y as before) */
+size_t pm_conv_bn_partials_bytes(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p);
 int pm_conv_fwd(const pm_tensor* x, const float* w_krsc, const pm_tensor* y, const pm_conv_params* p,
                 const pm_conv_epilogue* ep, void* ws, size_t ws_bytes, void* stream);
 /* dx = dgrad(dy) [+ add]: `add` (nullable, same shape as dx) fuses the sum with a second gradient path, e.g. the
@@ -120,6 +127,11 @@ int pm_bn_bwd_apply(const pm_tensor* dy, const pm_tensor* y /*relu == 1 only*/, 
                     const float* gamma, const float* beta /*relu == 2 only*/, const float* sums, float count, int relu, const pm_tensor* dx,
                     const pm_tensor* dres /*nullable*/, void* stream);
 /* eval-mode fold: scale = gamma/sqrt(running_var+eps); shift = beta - running_mean*scale + (conv_bias ? conv_bias*scale : 0) */
+/* Chan merge (double, fixed order) of the (mean, M2) slab partials a convolution epilogue emitted for its own output (pm_conv_epilogue.bn_partials,
+ * `pixels` rows in slabs of 32). moments == NULL: finalise like pm_bn_stats_finalize (mean, invstd, running moments); moments != NULL: write
+ * mean[C] | M2[C] | count[C] for the SyncBatchNorm exchange instead (mean / invstd / running_* are ignored). */
+int pm_bn_partials_finalize(const float* partials, int64_t pixels, int c, float eps, float* mean, float* invstd, float* running_mean /*nullable*/,
+                            float* running_var /*nullable*/, float momentum, float* moments /*nullable*/, void* stream);
 int pm_bn_fold(const float* gamma, const float* beta, const float* running_mean, const float* running_var, const float* conv_bias,
                int c, float eps, float* scale, float* shift, void* stream);
 /* the same fold for n BatchNorm layers in one launch (eval-mode forward of a whole network): table = n x {gamma, beta, running_mean,

@@ -112,6 +112,48 @@ __global__ void bn_finalize_kernel(const float* __restrict__ moments, int C, flo
   if (running_var && n > 1.f) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (m2 / (n - 1.f));
 }
 
+
+// Merge of the (mean, M2) slab partials a convolution epilogue emitted for its own output (conv_igemm.hip, staged epilogue): rows in slabs
+// of 32, part[slab][c][2]. Block = 4 channels x 64 lanes; lane l accumulates, in double, A = sum n_b mean_b and B = sum (M2_b + n_b mean_b^2)
+// over slabs l, l + 64, ... (two FMAs per slab, no division); the 64 lane pairs are added in lane order (fixed -> deterministic);
+// mean = A / N, M2 = B - N mean^2 (the within-slab part is exact two-pass fp32; the between-slab part is a sum of squares in double:
+// relative error 1e-16 (mean^2 / var), harmless below 1e8). MOM: write mean | M2 | count for the SyncBatchNorm exchange instead of finalising.
+template <bool MOM>
+__global__ __launch_bounds__(256) void bn_partials_final(const float* __restrict__ part, long rows, int C, float eps, float* __restrict__ mean,
+                                                         float* __restrict__ invstd, float* running_mean, float* running_var, float momentum,
+                                                         float* __restrict__ moments) {
+  __shared__ double red[FL][FC][2];
+  const int ci = threadIdx.x & (FC - 1), lane = threadIdx.x / FC;
+  const int c = blockIdx.x * FC + ci;
+  const long nslab = (rows + 31) / 32;
+  double A = 0.0, B = 0.0;
+  if (c < C)
+#pragma unroll 8
+    for (long sidx = lane; sidx < nslab; sidx += FL) {
+      const float2 v = *reinterpret_cast<const float2*>(part + (sidx * C + c) * 2);
+      const double nb = (double)min(32l, rows - sidx * 32), mb = (double)v.x;
+      A = fma(nb, mb, A);
+      B += fma(nb * mb, mb, (double)v.y);
+    }
+  red[lane][ci][0] = A, red[lane][ci][1] = B;
+  __syncthreads();
+  if (lane != 0 || c >= C) return;
+  A = B = 0.0;
+#pragma unroll 1
+  for (int i = 0; i < FL; ++i) A += red[i][ci][0], B += red[i][ci][1];
+  const double n = (double)rows, gm = A / n;
+  const float m = (float)gm, m2 = (float)fmax(B - n * gm * gm, 0.0), nf = (float)n;
+  if constexpr (MOM) {
+    moments[c] = m, moments[C + c] = m2, moments[2 * C + c] = nf;
+  } else {
+    const float var = m2 / nf;
+    mean[c] = m;
+    invstd[c] = 1.f / sqrtf(var + eps);
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+    if (running_var && nf > 1.f) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (m2 / (nf - 1.f));
+  }
+}
+
 // backward reductions: partial[blk][c][2] = sum(dyz), sum(dyz * xhat), dyz = dy masked by the ReLU of the forward pass.
 // RELU 0: no activation. 1: mask = y > 0 read from the forward output (needed when a residual was added before the ReLU).
 // 2: mask rebuilt from x (y = relu(bn(x)), no residual) -- one tensor less to read. GOUT: also store dyz (the gradient of the
@@ -286,6 +328,20 @@ extern "C" int pm_bn_merge_finalize(const float* parts, int world, int c, float 
   hipLaunchKernelGGL(bn_merge_kernel<true>, dim3(pm_cdiv(c, 64)), dim3(64), 0, (hipStream_t)stream, parts, world, c, (float*)nullptr, eps, mean, invstd,
                      running_mean, running_var, momentum);
   return pm_check_launch("bn_merge_finalize");
+}
+
+extern "C" int pm_bn_partials_finalize(const float* partials, int64_t pixels, int c, float eps, float* mean, float* invstd, float* running_mean,
+                                       float* running_var, float momentum, float* moments, void* stream) {
+  PM_REQUIRE(partials && pixels > 0 && c > 0 && (moments || (mean && invstd)), PM_EINVAL, "bn_partials_finalize: bad args");
+  PM_REQUIRE(moments || pixels > 1, PM_EINVAL, "bn_partials_finalize: expected more than 1 value per channel when training, got %ld", (long)pixels);
+  hipStream_t st = (hipStream_t)stream;
+  if (moments)
+    hipLaunchKernelGGL(bn_partials_final<true>, dim3(pm_cdiv(c, FC)), dim3(256), 0, st, partials, (long)pixels, c, eps, (float*)nullptr, (float*)nullptr,
+                       (float*)nullptr, (float*)nullptr, 0.f, moments);
+  else
+    hipLaunchKernelGGL(bn_partials_final<false>, dim3(pm_cdiv(c, FC)), dim3(256), 0, st, partials, (long)pixels, c, eps, mean, invstd, running_mean, running_var,
+                       momentum, (float*)nullptr);
+  return pm_check_launch("bn_partials_finalize");
 }
 
 extern "C" int pm_bn_fold(const float* gamma, const float* beta, const float* rm, const float* rv, const float* conv_bias, int c, float eps, float* scale,

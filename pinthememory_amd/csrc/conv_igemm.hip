@@ -53,6 +53,7 @@ struct ConvK {
   const float* residual;
   long res_pitch;
   int relu;
+  float* stats;               // train-mode BN statistics of the output: (mean, M2) per 32-row slab and channel, or null
   int stage_ep;               // 1: epilogue staged through LDS (16-byte row stores); 0: per-element stores (PM_STAGE_EP=0, A/B)
 };
 
@@ -567,6 +568,49 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
           PM_ST4(Cb + row * a.c_pitch + col, v);
         }
       }
+      if (a.stats) {   // wave-uniform. BatchNorm statistics of this 32-row slab (train mode: the epilogue is the convolution plus at most a
+                       // bias), two passes over the slab still parked in LDS: per column the mean over the valid rows, then M2 around it;
+                       // the RPI lanes sharing a column quad are combined by lane exchanges (fixed order). The slab is re-read rather than
+                       // kept in registers so that the kernel's register budget (and occupancy) is the one without statistics.
+        const long slab_row0 = m0 + wm * (BM / WM) + i * 32;
+        const float cnt = (float)max(0l, min(32l, (long)a.M - slab_row0));
+        auto slab_row = [&](int r0, bool& rok) {
+          float4 v = *reinterpret_cast<const float4*>(Ws + (r0 + rr0) * LDC + cc);
+          v.x = (v.x + bi[0]) * sc[0] + sh[0], v.y = (v.y + bi[1]) * sc[1] + sh[1], v.z = (v.z + bi[2]) * sc[2] + sh[2], v.w = (v.w + bi[3]) * sc[3] + sh[3];
+          rok = slab_row0 + r0 + rr0 < a.M;
+          return v;
+        };
+        float s1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r0 = 0; r0 < 32; r0 += RPI) {
+          bool rok;
+          const float4 v = slab_row(r0, rok);
+          s1[0] += rok ? v.x : 0.f, s1[1] += rok ? v.y : 0.f, s1[2] += rok ? v.z : 0.f, s1[3] += rok ? v.w : 0.f;
+        }
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s1[e] += __shfl_xor(s1[e], o, 64);
+        float mu[4], m2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mu[e] = cnt > 0.f ? s1[e] / cnt : 0.f;
+#pragma unroll
+        for (int r0 = 0; r0 < 32; r0 += RPI) {
+          bool rok;
+          const float4 v = slab_row(r0, rok);
+          const float d0 = v.x - mu[0], d1 = v.y - mu[1], d2 = v.z - mu[2], d3 = v.w - mu[3];
+          m2[0] += rok ? d0 * d0 : 0.f, m2[1] += rok ? d1 * d1 : 0.f, m2[2] += rok ? d2 * d2 : 0.f, m2[3] += rok ? d3 * d3 : 0.f;
+        }
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) m2[e] += __shfl_xor(m2[e], o, 64);
+        if (rr0 == 0 && cok && cnt > 0.f) {
+          float* dst = a.stats + ((slab_row0 >> 5) * (long)a.Nn + col) * 2;
+          PM_ST4(dst, make_float4(mu[0], m2[0], mu[1], m2[1]));
+          PM_ST4(dst + 4, make_float4(mu[2], m2[2], mu[3], m2[3]));
+        }
+      }
     }
     return;
   }
@@ -1003,7 +1047,7 @@ void fill_geom(ConvK& k, const pm_tensor* x, const pm_tensor* y, const pm_conv_p
   k.T_eff = p->kh * p->kw, k.tk_w = p->kw, k.ky0 = k.kx0 = 0, k.ksy = k.ksx = 1;
   k.sub = k.sub_cy = k.sub_cx = 0, k.Hc = x->h, k.Wc = x->w;
   k.bias = k.scale = k.shift = k.residual = nullptr;
-  k.res_pitch = 0, k.relu = 0;
+  k.res_pitch = 0, k.relu = 0, k.stats = nullptr;
   static const int stage_ep = getenv("PM_STAGE_EP") ? atoi(getenv("PM_STAGE_EP")) : 1;
   k.stage_ep = stage_ep;
   k.a_bs = k.b_bs = k.c_bs = 0;
@@ -1183,6 +1227,7 @@ int conv_bf16(const pm_tensor* xin, const float* w, int w_cout, int w_cin, bool 
   }
   k.C = (float*)yout->ptr, k.c_pitch = yout->pitch, k.c_split = 0;
   k.bias = e0.bias, k.scale = e0.scale, k.shift = e0.shift, k.residual = e0.residual, k.res_pitch = e0.residual_pitch, k.relu = e0.relu;
+  k.stats = e0.bn_partials;
   return launch<MODE_FWD>(k, b.pl, st, 1, flops);
 }
 inline pm_conv_params dgrad_as_fwd(const pm_conv_params* p) {
@@ -1319,6 +1364,29 @@ extern "C" size_t pm_conv_winograd_v_bytes(const pm_tensor* x, const pm_tensor* 
   return (f.use && g.use && f.g.m == g.g.m) ? f.v_bytes : 0;
 }
 
+// Can this forward call hand the BatchNorm statistics of its output out of its own epilogue? Only the unbatched direct GEMM with one K
+// split and a 16-byte-aligned output takes the staged epilogue; everything else (Winograd route, split-K, the 19-class heads) answers 0.
+static bool bn_partials_route(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p) {
+  if (!x || !y || !p || check_common(x, y, p) != PM_OK) return false;
+  if ((y->c & 3) || (y->pitch & 3) || !pm_aligned16(y->ptr)) return false;
+  static const int on = getenv("PM_BN_EPILOGUE") ? atoi(getenv("PM_BN_EPILOGUE")) : 1;
+  static const int stage_ep = getenv("PM_STAGE_EP") ? atoi(getenv("PM_STAGE_EP")) : 1;
+  if (!on || !stage_ep) return false;
+  if (p->prec == 2) {
+    const Bf16Plan b = bf16_plan(x, y, p);
+    if (b.use) return b.pl.ksplit == 1;
+  }
+  if (wino_plan(x, y->c, p).use) return false;
+  long M, Nn, K;
+  gemm_dims(MODE_FWD, x, y, p, M, Nn, K);
+  const Plan pl = make_plan(MODE_FWD, M, Nn, K, p->prec != 0);
+  return pl.ksplit == 1 && pl.bn >= 64;
+}
+extern "C" size_t pm_conv_bn_partials_bytes(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p) {
+  if (!bn_partials_route(x, y, p)) return 0;
+  return pm_align_up((size_t)pm_cdiv(pm_pixels(y), 32) * y->c * 2 * sizeof(float), 256);
+}
+
 extern "C" size_t pm_conv_workspace(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p, int which) {
   if (which == MODE_DGRAD && p->stride == 2) {   // four parity classes: compact results + the largest split-K slab set
     size_t slab = 0, tmp = 0;
@@ -1361,6 +1429,11 @@ extern "C" size_t pm_conv_workspace(const pm_tensor* x, const pm_tensor* y, cons
 extern "C" int pm_conv_fwd(const pm_tensor* x, const float* w, const pm_tensor* y, const pm_conv_params* p,
                            const pm_conv_epilogue* ep, void* ws, size_t ws_bytes, void* stream) {
   if (int e = check_common(x, y, p)) return e;
+  if (ep && ep->bn_partials) {
+    PM_REQUIRE(!ep->relu && !ep->residual, PM_EINVAL, "conv_fwd: bn_partials are the statistics of the convolution output (no residual / ReLU)");
+    const size_t need = pm_conv_bn_partials_bytes(x, y, p);
+    PM_REQUIRE(need != 0 && (size_t)ep->bn_partials_bytes >= need, PM_EINVAL, "conv_fwd: this call cannot emit bn_partials (ask pm_conv_bn_partials_bytes): %zu needed", need);
+  }
   PM_REQUIRE(w && pm_aligned16(w), PM_EINVAL, "conv_fwd: weight null or unaligned");
   {
     pm_conv_epilogue e1 = {nullptr, nullptr, nullptr, nullptr, 0, 0};
@@ -1404,6 +1477,7 @@ extern "C" int pm_conv_fwd(const pm_tensor* x, const float* w, const pm_tensor* 
   }
   k.C = (float*)y->ptr, k.c_pitch = y->pitch, k.c_split = 0;
   k.bias = e0.bias, k.scale = e0.scale, k.shift = e0.shift, k.residual = e0.residual, k.res_pitch = e0.residual_pitch, k.relu = e0.relu;
+  k.stats = e0.bn_partials;
   return launch<MODE_FWD>(k, pl, st);
 }
 

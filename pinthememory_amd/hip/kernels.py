@@ -50,9 +50,17 @@ def krsc(w):
 KEEP_WINOGRAD_V = os.environ.get('PM_KEEP_V', '1') == '1'   # forward keeps the Winograd-transformed input for the weight gradient
 
 
-def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, residual=None, relu=False, out=None, keep_v=None):
+# BatchNorm statistics handed out by the producing convolution's epilogue: implemented, kernel-tested, and measured neutral --
+# the statistics passes it removes (-1.0 ms/step) are paid back by the longer epilogues (+0.35 ms) and the slab merge (same-box A/B 67.4-67.6 ms
+# either way, tools/gpu_env_ab2.sh PM_BN_EPILOGUE) -- so the separate pass stays the default. PM_BN_EPILOGUE=1 turns it on.
+BN_EPILOGUE = os.environ.get('PM_BN_EPILOGUE', '0') == '1'
+
+
+def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, residual=None, relu=False, out=None, keep_v=None, bn_partials=None):
     """keep_v: a list; if this convolution and its weight gradient both take the Winograd route, the transformed input V is written
-    to a fresh tensor that is appended to the list (else None is appended) -- pass it to conv_bwd_weight(wino_v=...)."""
+    to a fresh tensor that is appended to the list (else None is appended) -- pass it to conv_bwd_weight(wino_v=...).
+    bn_partials: a list; if this call can hand the train-mode BatchNorm statistics of its output out of its own epilogue ((mean, M2) per
+    32-row slab and channel), the partials tensor is appended (else None) -- merge it with bn_partials_finalize(...) instead of bn_stats(y)."""
     cout, kh, kw, cin = w_krsc.shape
     n, h, w_, c = x.shape
     assert c == cin, 'conv: Cin mismatch %d vs %d' % (c, cin)
@@ -69,10 +77,16 @@ def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, res
             p.wino_v, p.wino_v_bytes = v.data_ptr(), nbv
     nb = lib.pm_conv_workspace(byref(xd), byref(yd), byref(p), 0)
     ws = workspace(nb, x.device) if nb else None
+    part = None
+    if bn_partials is not None:
+        npb = lib.pm_conv_bn_partials_bytes(byref(xd), byref(yd), byref(p)) if (BN_EPILOGUE and residual is None and not relu) else 0
+        part = torch.empty(npb // 4, dtype=torch.float32, device=x.device) if npb else None
+        bn_partials.append(part)
     ep = None
-    if bias is not None or scale is not None or residual is not None or relu:
+    if bias is not None or scale is not None or residual is not None or relu or part is not None:
         rd = tdesc(residual) if residual is not None else None
-        ep = PmConvEpilogue(ptr(bias), ptr(scale), ptr(shift), rd.ptr if rd else None, rd.pitch if rd else 0, 1 if relu else 0)
+        ep = PmConvEpilogue(ptr(bias), ptr(scale), ptr(shift), rd.ptr if rd else None, rd.pitch if rd else 0, 1 if relu else 0, ptr(part),
+                            part.numel() * 4 if part is not None else 0)
     check(lib.pm_conv_fwd(byref(xd), w_krsc.data_ptr(), byref(yd), byref(p), byref(ep) if ep else None, ptr(ws), nb, stream()), 'pm_conv_fwd')
     return y
 
@@ -130,6 +144,22 @@ def bn_stats_finalize(x, eps, running_mean=None, running_var=None, momentum=0.1)
     check(lib.pm_bn_stats_finalize(byref(xd), eps, mean.data_ptr(), invstd.data_ptr(), ptr(running_mean), ptr(running_var), momentum, ptr(ws), nb, stream()),
           'pm_bn_stats_finalize')
     return mean, invstd
+
+
+def bn_partials_finalize(part, pixels, c, eps, running_mean=None, running_var=None, momentum=0.1):
+    """(mean, M2) slab partials emitted by a convolution epilogue -> (mean, invstd); running moments updated in place."""
+    mean = torch.empty(c, dtype=torch.float32, device=part.device)
+    invstd = torch.empty_like(mean)
+    check(_lib().pm_bn_partials_finalize(part.data_ptr(), pixels, c, eps, mean.data_ptr(), invstd.data_ptr(), ptr(running_mean), ptr(running_var), momentum, None,
+                                         stream()), 'pm_bn_partials_finalize')
+    return mean, invstd
+
+
+def bn_partials_moments(part, pixels, c):
+    """the same partials -> moments float[3C] = mean | M2 | count (the SyncBatchNorm exchange format of bn_stats)."""
+    mom = torch.empty(3 * c, dtype=torch.float32, device=part.device)
+    check(_lib().pm_bn_partials_finalize(part.data_ptr(), pixels, c, 0.0, None, None, None, None, 0.0, mom.data_ptr(), stream()), 'pm_bn_partials_finalize')
+    return mom
 
 
 def bn_merge(parts, world, c):

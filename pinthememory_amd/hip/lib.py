@@ -25,7 +25,7 @@ class PmConvParams(ctypes.Structure):
 
 class PmConvEpilogue(ctypes.Structure):
     _fields_ = [('bias', c_void_p), ('scale', c_void_p), ('shift', c_void_p), ('residual', c_void_p),
-                ('residual_pitch', c_int64), ('relu', c_int32)]
+                ('residual_pitch', c_int64), ('relu', c_int32), ('bn_partials', c_void_p), ('bn_partials_bytes', c_int64)]
 
 
 class PinmemError(RuntimeError):
@@ -97,6 +97,8 @@ SIGNATURES = {
     'pm_mem_write_update_bwd': (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp]),
     'pm_sgd_momentum': (_i, [_vp, _vp, _vp, _i64, _f, _f, _f, _i, _vp]),
     'pm_set_bf16_wgrad': (_i, [_i]),
+    'pm_conv_bn_partials_bytes': (_sz, [_T, _T, POINTER(PmConvParams)]),
+    'pm_bn_partials_finalize': (_i, [_vp, _i64, _i, _f, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
     'pm_sgd_momentum_multi': (_i, [_vp, _i, _f, _f, _f, _vp]),
 }
 

@@ -135,16 +135,23 @@ def _wgrad(x, dy, wshape, geom, want_bias=False, deferred=False, wino_v=None):
 BN_FUSED_FINALIZE = _os.environ.get('PM_BN_FUSED', '1') == '1'      # A/B knob: 0 = separate bn_stats / bn_finalize launches
 
 
-def _bn_train_fwd(y, gamma, beta, bn, residual, relu, out=None):
-    """Batch statistics (merged across ranks for SyncBN) -> normalise + residual + ReLU. Returns (o, mean, invstd)."""
+def _bn_train_fwd(y, gamma, beta, bn, residual, relu, out=None, partials=None):
+    """Batch statistics (merged across ranks for SyncBN) -> normalise + residual + ReLU. Returns (o, mean, invstd).
+    partials: the (mean, M2) slab partials the producing convolution's epilogue emitted for y (K.conv_fwd(bn_partials=...)), or None:
+    with them no kernel re-reads y for its statistics."""
     c = y.shape[3]
+    pixels = y.shape[0] * y.shape[1] * y.shape[2]
     if bn.group is None and BN_FUSED_FINALIZE:
-        mean, invstd = K.bn_stats_finalize(y, bn.eps, bn.running_mean, bn.running_var, bn.momentum)
+        if partials is not None:
+            mean, invstd = K.bn_partials_finalize(partials, pixels, c, bn.eps, bn.running_mean, bn.running_var, bn.momentum)
+        else:
+            mean, invstd = K.bn_stats_finalize(y, bn.eps, bn.running_mean, bn.running_var, bn.momentum)
     elif bn.group is not None and D.is_dist() and BN_FUSED_FINALIZE:
-        flat, world = D.gather_moments(K.bn_stats(y), bn.group)        # SyncBN: stats, all-gather, merge + finalise, apply
+        mom = K.bn_partials_moments(partials, pixels, c) if partials is not None else K.bn_stats(y)
+        flat, world = D.gather_moments(mom, bn.group)                  # SyncBN: stats, all-gather, merge + finalise, apply
         mean, invstd = K.bn_merge_finalize(flat, world, c, bn.eps, bn.running_mean, bn.running_var, bn.momentum)
     else:
-        mom = K.bn_stats(y)
+        mom = K.bn_partials_moments(partials, pixels, c) if partials is not None else K.bn_stats(y)
         if bn.group is not None:
             mom = D.merge_moments(mom, c, bn.group)
         mean, invstd = K.bn_finalize(mom, c, bn.eps, bn.running_mean, bn.running_var, bn.momentum)
@@ -183,20 +190,21 @@ class _Bottleneck(torch.autograd.Function):
     def forward(ctx, x, w1, g1, b1, w2, g2, b2, w3, g3, b3, wd, gd, bd, geoms, bns, deferred):
         xv = nhwc(x)
         k1, k2, k3 = K.krsc(w1), K.krsc(w2), K.krsc(w3)
-        y1 = K.conv_fwd(xv, k1, *geoms[0])
-        o1, m1, i1 = _bn_train_fwd(y1, g1, b1, bns[0], None, True)
+        ps = []                                            # BatchNorm statistics handed out by the convolution epilogues (None: separate pass)
+        y1 = K.conv_fwd(xv, k1, *geoms[0], bn_partials=ps)
+        o1, m1, i1 = _bn_train_fwd(y1, g1, b1, bns[0], None, True, partials=ps[0])
         kv = []
-        y2 = K.conv_fwd(o1, k2, *geoms[1], keep_v=kv)      # Winograd layers keep the transformed input for the weight gradient
-        o2, m2, i2 = _bn_train_fwd(y2, g2, b2, bns[1], None, True)
-        y3 = K.conv_fwd(o2, k3, *geoms[2])
+        y2 = K.conv_fwd(o1, k2, *geoms[1], keep_v=kv, bn_partials=ps)      # Winograd layers keep the transformed input for the weight gradient
+        o2, m2, i2 = _bn_train_fwd(y2, g2, b2, bns[1], None, True, partials=ps[1])
+        y3 = K.conv_fwd(o2, k3, *geoms[2], bn_partials=ps)
         if wd is not None:
             kd = K.krsc(wd)
-            yd = K.conv_fwd(xv, kd, *geoms[3])
-            res, md, idd = _bn_train_fwd(yd, gd, bd, bns[3], None, False)
+            yd = K.conv_fwd(xv, kd, *geoms[3], bn_partials=ps)
+            res, md, idd = _bn_train_fwd(yd, gd, bd, bns[3], None, False, partials=ps[3])
         else:
             kd = yd = md = idd = None
             res = xv
-        out, m3, i3 = _bn_train_fwd(y3, g3, b3, bns[2], res, True)
+        out, m3, i3 = _bn_train_fwd(y3, g3, b3, bns[2], res, True, partials=ps[2])
         ctx.geoms, ctx.groups, ctx.has_ds, ctx.deferred = geoms, [b.group for b in bns], wd is not None, deferred
         ctx.save_for_backward(xv, k1, k2, k3, kd, y1, o1, y2, o2, y3, yd, out, m1, i1, m2, i2, m3, i3, md, idd, g1, g2, g3, gd, b1, b2, b3, kv[0])
         return nchw(out)
@@ -294,10 +302,10 @@ class _ConvBnAct(torch.autograd.Function):
             scale, shift = hit if hit is not None else K.bn_fold(gamma, beta, bn.running_mean, bn.running_var, bn.eps, bias)
             o = K.conv_fwd(xv, wk, stride, pad, dil, scale=scale, shift=shift, residual=rv, relu=relu, out=ov)
             return nchw(o)
-        kv = []
-        y = K.conv_fwd(xv, wk, stride, pad, dil, bias=bias, keep_v=kv if ctx.needs_input_grad[1] else None)
+        kv, ps = [], []
+        y = K.conv_fwd(xv, wk, stride, pad, dil, bias=bias, keep_v=kv if ctx.needs_input_grad[1] else None, bn_partials=ps if bn.training else None)
         if bn.training:
-            o, mean, invstd = _bn_train_fwd(y, gamma, beta, bn, rv, relu, ov)
+            o, mean, invstd = _bn_train_fwd(y, gamma, beta, bn, rv, relu, ov, partials=ps[0])
         else:                                      # frozen statistics with a graph: normalise by the running moments, keep y for backward
             mean, invstd = bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
             o = K.bn_apply(y, mean, invstd, gamma, beta, residual=rv, relu=relu, out=ov)

@@ -148,6 +148,47 @@ def test_conv_winograd(K, case):
     assert taken == [wino for wino in (4, 2) if wino_route(h, w, d, wino)] and 4 in taken, (case, taken)
 
 
+@pytest.mark.parametrize('case', [(2, 64, 24, 20, 256, 1, 1, 0, 1), (3, 64, 45, 37, 64, 3, 1, 1, 1), (2, 256, 47, 33, 64, 1, 1, 0, 1), (1, 32, 40, 36, 128, 3, 2, 1, 1)])
+def test_conv_epilogue_bn_statistics(K, case):
+    """Train-mode BatchNorm statistics handed out by the convolution epilogue itself ((mean, M2) per 32-row slab, merged by
+    pm_bn_partials_finalize) against the statistics pass over y (pm_bn_stats_finalize) and against torch on the same output: mean /
+    invstd / running moments, incl. ragged last slabs (pixel counts that are no multiple of 32 or of the block tile) and the SyncBN
+    moment format."""
+    n, cin, h, w, cout, k, s, p, d = case
+    x, wt = rnd(n, cin, h, w, seed=1), rnd(cout, cin, k, k, seed=2, scale=(2.0 / (cin * k * k)) ** 0.5)
+    b = rnd(cout, seed=3)
+    xg, wg = nhwc(x), wt.permute(0, 2, 3, 1).contiguous().cuda()
+    ps = []
+    K.BN_EPILOGUE = True                 # opt-in route (default off: measured neutral on the step)
+    try:
+        y = K.conv_fwd(xg, wg, s, p, d, bias=b.cuda(), bn_partials=ps)
+    finally:
+        K.BN_EPILOGUE = False
+    assert ps[0] is not None, 'this shape must take the epilogue-statistics route'
+    pixels = y.shape[0] * y.shape[1] * y.shape[2]
+    rm1, rv1 = torch.zeros(cout, device='cuda'), torch.ones(cout, device='cuda')
+    rm2, rv2 = rm1.clone(), rv1.clone()
+    mean1, inv1 = K.bn_partials_finalize(ps[0], pixels, cout, 1e-5, rm1, rv1, 0.1)
+    mean2, inv2 = K.bn_stats_finalize(y, 1e-5, rm2, rv2, 0.1)
+    yr = nchw(y).double()
+    assert rel(mean1, yr.mean((0, 2, 3))) < 1e-6 and rel(inv1, 1.0 / torch.sqrt(yr.var((0, 2, 3), unbiased=False) + 1e-5)) < 1e-6
+    assert rel(mean1, mean2) < 1e-6 and rel(inv1, inv2) < 1e-6 and rel(rm1, rm2) < 1e-6 and rel(rv1, rv2) < 1e-6
+    mom = K.bn_partials_moments(ps[0], pixels, cout)
+    assert rel(mom[:cout], yr.mean((0, 2, 3))) < 1e-6 and rel(mom[cout:2 * cout], ((yr - yr.mean((0, 2, 3), keepdim=True)) ** 2).sum((0, 2, 3))) < 1e-5
+    assert torch.all(mom[2 * cout:] == pixels)
+    # the same convolution without the request writes the same y
+    assert torch.equal(K.conv_fwd(xg, wg, s, p, d, bias=b.cuda()), y)
+    # routes that cannot emit the partials say so: Winograd (wide 3x3) and the 19-class head
+    ps2 = []
+    K.BN_EPILOGUE = True
+    try:
+        K.conv_fwd(nhwc(rnd(1, 128, 16, 16, seed=5)), rnd(128, 3, 3, 128, seed=6).cuda() * 0.05, 1, 1, 1, bn_partials=ps2)
+        K.conv_fwd(nhwc(rnd(1, 64, 8, 8, seed=5)), rnd(19, 1, 1, 64, seed=6).cuda() * 0.05, 1, 0, 1, bn_partials=ps2)
+    finally:
+        K.BN_EPILOGUE = False
+    assert ps2 == [None, None]
+
+
 def test_conv_epilogue_and_slices(K):
     """eval-mode fold (scale/shift), residual, relu, and writing into a channel slice of a wider concat buffer."""
     x, wt = rnd(2, 64, 12, 12, seed=1), rnd(32, 64, 3, 3, seed=2, scale=0.05)
