@@ -89,7 +89,9 @@ enum { K_FAST = 0, K_MID = 1, K_SMALL = 2 };
 // BASELINE configs[2]. Gathers, LDS layout and epilogue are shared; storage stays fp32.
 // NST: LDS stages. 1 = single buffer for reductions of <= 64 K-steps (K <= 2048: every 1x1 convolution and Winograd GEMM of the
 // flagship), 2 = double-buffered beyond that. A single stage halves the LDS footprint so that three blocks share a CU and cover each other's load / store phases.
-template <int MODE, int BM, int BN, int WM, int WN, int KM, int PREC, int NST>
+// STATS: the staged epilogue also emits the BatchNorm statistics of the tile (a separate instantiation, so that the register budget and the
+// occupancy of the kernel without statistics are untouched: 72 vs 74 VGPRs on the 64 x 64 forward tile = 7 vs 6 waves per SIMD).
+template <int MODE, int BM, int BN, int WM, int WN, int KM, int PREC, int NST, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   constexpr bool A_KC = (MODE != MODE_WGRAD);  // A tile stored [BM][LDK] (k contiguous) else [BK][BM]
   constexpr bool B_KC = (MODE == MODE_FWD);    // B tile stored [BN][LDK] else [BK][BN]
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
           PM_ST4(Cb + row * a.c_pitch + col, v);
         }
       }
-      if (a.stats) {   // wave-uniform. BatchNorm statistics of this 32-row slab (train mode: the epilogue is the convolution plus at most a
+      if constexpr (STATS) {   // BatchNorm statistics of this 32-row slab (train mode: the epilogue is the convolution plus at most a
                        // bias), two passes over the slab still parked in LDS: per column the mean over the valid rows, then M2 around it;
                        // the RPI lanes sharing a column quad are combined by lane exchanges (fixed order). The slab is re-read rather than
                        // kept in registers so that the kernel's register budget (and occupancy) is the one without statistics.
@@ -943,6 +945,18 @@ void launch_nst(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
   }();
   (void)attr_set;
   const size_t ep_bytes = (size_t)4 * 32 * (BN / WN + 4) * sizeof(float);      // staged epilogue: four wave slabs
+  if constexpr (MODE == MODE_FWD && PREC != 1 && BN >= 64) {
+    if (k.stats) {
+      static const bool attr_set2 = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<MODE, BM, BN, WM, WN, KM, PREC, NST, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return true;
+      }();
+      (void)attr_set2;
+      hipLaunchKernelGGL((conv_igemm_kernel<MODE, BM, BN, WM, WN, KM, PREC, NST, true>), grid, dim3(256), std::max(smem / (NST == 1 ? 2 : 1), ep_bytes), st, k);
+      return;
+    }
+  }
   hipLaunchKernelGGL((conv_igemm_kernel<MODE, BM, BN, WM, WN, KM, PREC, NST>), grid, dim3(256), std::max(smem / (NST == 1 ? 2 : 1), ep_bytes), st, k);
 }
 // longest reduction (in K-steps per block) that takes the single-stage variant; PM_NST1_STEPS overrides it for tuning runs
@@ -1377,9 +1391,10 @@ static bool bn_partials_route(const pm_tensor* x, const pm_tensor* y, const pm_c
     if (b.use) return b.pl.ksplit == 1;
   }
   if (wino_plan(x, y->c, p).use) return false;
+  if (p->prec != 0) return false;                 // staged-fp32 bf16 form: no statistics instantiation
   long M, Nn, K;
   gemm_dims(MODE_FWD, x, y, p, M, Nn, K);
-  const Plan pl = make_plan(MODE_FWD, M, Nn, K, p->prec != 0);
+  const Plan pl = make_plan(MODE_FWD, M, Nn, K, false);
   return pl.ksplit == 1 && pl.bn >= 64;
 }
 extern "C" size_t pm_conv_bn_partials_bytes(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p) {
