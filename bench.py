@@ -41,6 +41,9 @@ def parse():
                     help='f32 = BASELINE configs[1] (the metric; default). bf16 = configs[2]: every convolution converts its operands to bf16 in HBM, bf16 LDS tiles '
                          '(64 k per row), bf16 MFMA with fp32 accumulation; activations between layers stay fp32. bf16_staged = the first form of that tier '
                          '(fp32 tiles in LDS rounded per fragment), kept for A/B')
+    ap.add_argument('--input-edge', action='store_true',
+                    help='side measurement (not the metric): every step takes a fresh uint8 [B, D, H, W, 3] batch from pinned host memory, copied and '
+                         'converted on a side stream while the previous step computes (pinthememory_amd/input_edge.py)')
     ap.add_argument('--workload', choices=['train', 'config5'], default='train',
                     help="train = the metric (default). config5 = side measurement of BASELINE configs[4]: ResNet-101 DeepLabV2 sliding-window "
                          "evaluation of 1024x2048 images (crop 1024, overlap 1/3 -> 3 tiles x 2 flips, eval.py:148-274), single GPU")
@@ -252,7 +255,27 @@ def main():
     x, y = synth.make_batch(a.batch, a.size, seed=304 + rank)          # rank r: its own 8 images (config 4)
     x, y = x.to(dev), y.to(dev)
 
+    edge = None
+    if a.input_edge:
+        from pinthememory_amd import input_edge
+        domains = 2 if a.batch % 2 == 0 else 1                                 # e.g. gtav + synthia (datasets/multi_loader.py:81-102)
+        src = input_edge.SyntheticDomainSource(a.batch // domains, domains, a.size, n_buffers=3, seed=304 + rank, static=True)
+        pf = input_edge.DevicePrefetcher(src, depth=1, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            pf.next()
+        torch.cuda.synchronize()
+        h2d_ms = (time.perf_counter() - t0) / 5 * 1e3
+        edge = {'source': 'synthetic uint8 [%d, %d, %d, %d, 3] + uint8 labels, pinned host ring of 3, side-stream H2D + u8->NHWC4/int64 kernels, depth 1' % (
+                    a.batch // domains, domains, a.size, a.size),
+                'h2d_bytes_per_step': src.bytes_per_batch(), 'edge_alone_ms': round(h2d_ms, 3), 'pcie_GBps_alone': round(src.bytes_per_batch() / h2d_ms / 1e6, 2),
+                'fp32_int64_bytes_the_reference_ships': src.bytes_per_batch() // 4 * (12 + 8)}
+
     def step():
+        if edge is not None:
+            xb, yb = pf.next()
+            return harness.agg_train_step(net, opt, xb, yb, sched=sched, buckets=buckets, truncate_second_forward=a.truncate_second_forward)
         return harness.agg_train_step(net, opt, x, y, sched=sched, buckets=buckets, truncate_second_forward=a.truncate_second_forward)
 
     for _ in range(a.warmup):
@@ -352,6 +375,9 @@ def main():
                           'step_mfma_frac': round(gf_img * a.batch * world * a.steps / 1e3 / dt / (peak * world), 4),
                           'final_loss': round(float(losses['total']), 5)},
                'roofline': roof}
+        if edge is not None:
+            out['config']['input_edge'] = edge
+            out['data'] = 'synthetic, fresh uint8 batch from pinned host memory every step (PCIe-inclusive side measurement)'
         if roof is not None:
             try:
                 roof['memory_read'] = memory_path_roofline(a.batch, a.size)

@@ -166,6 +166,9 @@ int pm_resize_bilinear_bwd_separable(const pm_tensor* dy, const pm_tensor* dx, i
  * MeanFusion: buffer += (softmax(logits) - buffer) / counter in float64 (buffer NHWC double); argmax over channels. */
 int pm_resize_bilinear_hp_fwd(const pm_tensor* x, const pm_tensor* y, int flip_w, void* stream);
 int pm_softmax_mean_update(const pm_tensor* logits, double* buffer, int counter, void* stream);
+/* Sliding-window stitching (eval.py:210-274,340-405): logits [ntiles, th, tw, C] of the tiles (x1,y1,x2,y2)[ntiles] (HOST array) -> float64 sum over
+ * the covering tiles (tile order) / tile count, written to acc[C][H][W] at the un-flipped column (flip_w); accumulate != 0 adds to acc. */
+int pm_sliding_stitch(const pm_tensor* logits, const int32_t* tiles_xyxy, int ntiles, int H, int W, int flip_w, double* acc, int accumulate, void* stream);
 int pm_argmax_f64(const double* buffer, int n, int h, int w, int c, int64_t* out_cls, double* out_prob /*nullable*/, void* stream);
 
 /* ---- input edge: ToTensor + Normalize(ImageNet) (datasets/gtav.py:284-289) and MaskToTensor

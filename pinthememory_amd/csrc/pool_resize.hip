@@ -478,6 +478,52 @@ extern "C" int pm_softmax_mean_update(const pm_tensor* logits, double* buffer, i
                      logits->c, buffer, 1.0 / (double)counter);
   return pm_check_launch("softmax_mean_update");
 }
+namespace {
+// Sliding-window stitching (eval.py:210-274: add the tiles' logits, divide by the per-pixel tile count, un-flip; the reference does it per
+// class in numpy threads on the host). One thread per output pixel: float64 sum over the covering tiles in tile order, / count, written to
+// the class-major float64 accumulator at the (un-flipped) column; `accumulate` adds to what an earlier flip / scale left there.
+constexpr int STITCH_MAX_TILES = 64;
+struct StitchTiles {
+  int n;
+  int x1[STITCH_MAX_TILES], y1[STITCH_MAX_TILES], x2[STITCH_MAX_TILES], y2[STITCH_MAX_TILES];
+};
+__global__ __launch_bounds__(256) void sliding_stitch_kernel(const float* __restrict__ lg, long pitch, int th, int tw, int C, const StitchTiles tiles, int H, int W,
+                                                             int flip, double* __restrict__ acc, int accumulate) {
+  const long total = (long)H * W;
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < total; p += (long)gridDim.x * 256) {
+    const int y = (int)(p / W), x = (int)(p - (long)y * W);
+    const int xo = flip ? W - 1 - x : x;
+    double cnt = 0.0;
+    for (int t = 0; t < tiles.n; ++t)
+      if (x >= tiles.x1[t] && x < tiles.x2[t] && y >= tiles.y1[t] && y < tiles.y2[t]) cnt += 1.0;
+    for (int c = 0; c < C; ++c) {
+      double s = 0.0;
+      for (int t = 0; t < tiles.n; ++t)
+        if (x >= tiles.x1[t] && x < tiles.x2[t] && y >= tiles.y1[t] && y < tiles.y2[t])
+          s += (double)lg[(((long)t * th + (y - tiles.y1[t])) * tw + (x - tiles.x1[t])) * pitch + c];
+      const double v = s / cnt;          // uncovered pixels: 0 / 0 = NaN, as the host formulation gives
+      double* dst = acc + ((long)c * H + y) * W + xo;
+      *dst = accumulate ? *dst + v : v;
+    }
+  }
+}
+
+}  // namespace
+extern "C" int pm_sliding_stitch(const pm_tensor* logits, const int32_t* tiles_xyxy, int ntiles, int H, int W, int flip_w, double* acc, int accumulate,
+                                 void* stream) {
+  PM_REQUIRE(logits && logits->ptr && tiles_xyxy && acc && ntiles >= 1 && ntiles <= STITCH_MAX_TILES && logits->n == ntiles, PM_EINVAL,
+             "sliding_stitch: bad args (1..%d tiles, logits->n == ntiles)", STITCH_MAX_TILES);
+  StitchTiles t;
+  t.n = ntiles;
+  for (int i = 0; i < ntiles; ++i) {
+    t.x1[i] = tiles_xyxy[4 * i], t.y1[i] = tiles_xyxy[4 * i + 1], t.x2[i] = tiles_xyxy[4 * i + 2], t.y2[i] = tiles_xyxy[4 * i + 3];
+    PM_REQUIRE(t.x2[i] - t.x1[i] == logits->w && t.y2[i] - t.y1[i] == logits->h && t.x1[i] >= 0 && t.y1[i] >= 0 && t.x2[i] <= W && t.y2[i] <= H, PM_EINVAL,
+               "sliding_stitch: tile %d does not match the logits' %dx%d", i, logits->h, logits->w);
+  }
+  hipLaunchKernelGGL(sliding_stitch_kernel, dim3(grid_for((long)H * W)), dim3(256), 0, (hipStream_t)stream, (const float*)logits->ptr, (long)logits->pitch, logits->h,
+                     logits->w, logits->c, t, H, W, flip_w, acc, accumulate);
+  return pm_check_launch("sliding_stitch");
+}
 extern "C" int pm_argmax_f64(const double* buffer, int n, int h, int w, int c, int64_t* out_cls, double* out_prob, void* stream) {
   PM_REQUIRE(buffer && out_cls && c >= 1, PM_EINVAL, "argmax_f64: bad args");
   const long pixels = (long)n * h * w;

@@ -127,15 +127,8 @@ def sliding_logits(net, img, crop, overlap=1.0 / 3, flips=(False, True), batch_t
             src = torch.flip(img, dims=[2]) if flip else img
             crops = torch.stack([src[:, y1:y2, x1:x2] for (x1, y1, x2, y2) in tiles])
             outs = net(crops)[0] if batch_tiles else torch.cat([net(cr[None])[0] for cr in crops])   # eval.py:379-390 (--faster batches)
-            full = torch.zeros(outs.shape[1], h, w, dtype=torch.float64, device=img.device)
-            cnt = torch.zeros(1, h, w, dtype=torch.float64, device=img.device)
-            for i, (x1, y1, x2, y2) in enumerate(tiles):
-                full[:, y1:y2, x1:x2] += outs[i].double()
-                cnt[:, y1:y2, x1:x2] += 1
-            full = full / cnt
-            if flip:
-                full = torch.flip(full, dims=[2])
-            acc = full if acc is None else acc + full
+            # one kernel per flip: float64 sum of the covering tiles (tile order) / count, written un-flipped into the accumulator
+            acc = K.sliding_stitch(ops.nhwc(outs), tiles, h, w, flip, acc)
     return acc / len(flips)
 
 

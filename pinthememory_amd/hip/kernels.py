@@ -343,6 +343,16 @@ def softmax_mean_update(logits, buffer, counter):
     check(_lib().pm_softmax_mean_update(byref(tdesc(logits)), buffer.data_ptr(), counter, stream()), 'pm_softmax_mean_update')
 
 
+def sliding_stitch(logits, tiles, H, W, flip_w, acc=None):
+    """logits NHWC [T, th, tw, C] of the tiles [(x1, y1, x2, y2)] -> float64 [C, H, W]: sum over covering tiles / count, un-flipped; added to `acc` if given."""
+    import ctypes
+    T, th, tw, c = logits.shape
+    arr = (ctypes.c_int32 * (4 * T))(*[int(v) for t in tiles for v in t])
+    out = acc if acc is not None else torch.empty((c, H, W), dtype=torch.float64, device=logits.device)
+    check(L.load().pm_sliding_stitch(byref(tdesc(logits)), arr, T, H, W, 1 if flip_w else 0, out.data_ptr(), 1 if acc is not None else 0, stream()), 'pm_sliding_stitch')
+    return out
+
+
 def argmax_f64(buffer):
     n, h, w, c = buffer.shape
     cls = torch.empty((n, h, w), dtype=torch.int64, device=buffer.device)

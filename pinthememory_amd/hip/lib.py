@@ -75,6 +75,7 @@ SIGNATURES = {
     'pm_resize_bilinear_bwd_separable': (_i, [_T, _T, _i, _vp, _sz, _vp]),
     'pm_resize_bilinear_hp_fwd': (_i, [_T, _T, _i, _vp]),
     'pm_softmax_mean_update': (_i, [_T, _vp, _i, _vp]),
+    'pm_sliding_stitch': (_i, [_T, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     'pm_argmax_f64': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'pm_image_u8_to_nhwc4': (_i, [_vp, _i64, POINTER(c_float), POINTER(c_float), _vp, _vp]),
     'pm_labels_u8_to_i64': (_i, [_vp, _i64, _vp, _vp]),

@@ -54,3 +54,20 @@ def test_unsupported_configurations_are_rejected():
         deepv3plus.DeepR50V3PlusD(synth.model_args(wt_layer=[0, 0, 1, 0, 0, 0, 0]), 19, CRIT, CRIT)     # whitening: out of scope
     with pytest.raises(ValueError):
         deepv3plus.DeepV3Plus(19, trunk='resnet-101', criterion=CRIT, criterion_aux=CRIT, variant='D16', args=synth.model_args())
+
+
+def test_synthetic_domain_source_is_deterministic():
+    """The loader stand-in of the input edge: [B, D, H, W, 3] uint8 + [B, D, H, W] uint8 train ids, the same bytes for the
+    same (seed, batch index) whatever the host ring size; `static` replays the ring."""
+    from pinthememory_amd import input_edge
+    a = input_edge.SyntheticDomainSource(2, 3, (32, 48), n_buffers=2, seed=1)
+    b = input_edge.SyntheticDomainSource(2, 3, (32, 48), n_buffers=1, seed=1)
+    for i in range(4):
+        ia, la = next(a)
+        ib, lb = next(b)
+        assert ia.shape == (2, 3, 32, 48, 3) and la.shape == (2, 3, 32, 48) and ia.dtype == la.dtype == torch.uint8
+        assert torch.equal(ia, ib) and torch.equal(la, lb)
+        assert set(la.unique().tolist()) <= set(range(19)) | {255}
+    s = input_edge.SyntheticDomainSource(1, 2, 32, n_buffers=2, seed=2, static=True)
+    first = [next(s)[0].clone() for _ in range(4)]
+    assert torch.equal(first[0], first[2]) and torch.equal(first[1], first[3]) and not torch.equal(first[0], first[1])

@@ -301,6 +301,30 @@ def test_pool_and_resize(K):
         assert rel(nchw(dx_g), xr.grad) < 1e-5 and rel(dx, dx_g) < 2e-6, (shape, size)
 
 
+@pytest.mark.parametrize('h,w,crop,overlap', [(160, 288, 128, 1.0 / 3), (96, 200, 64, 0.5), (128, 128, 128, 1.0 / 3)])
+def test_sliding_stitch(K, h, w, crop, overlap):
+    """pm_sliding_stitch against the host formulation of eval.py:210-274 (float64 sum in tile order / count, un-flip, add the flips):
+    same additions in the same order, so the same bits."""
+    from pinthememory_amd import harness
+    tiles = harness.sliding_tiles(h, w, crop, overlap)
+    acc, ref = None, None
+    for flip in (False, True):
+        lg = rnd(len(tiles), 19, crop, crop, seed=5 + flip)
+        full = torch.zeros(19, h, w, dtype=torch.float64)
+        cnt = torch.zeros(1, h, w, dtype=torch.float64)
+        for i, (x1, y1, x2, y2) in enumerate(tiles):
+            full[:, y1:y2, x1:x2] += lg[i].double()
+            cnt[:, y1:y2, x1:x2] += 1
+        full = full / cnt
+        if flip:
+            full = torch.flip(full, dims=[2])
+        ref = full if ref is None else ref + full
+        acc = K.sliding_stitch(nhwc(lg), tiles, h, w, flip, acc)
+    assert torch.equal(acc.cpu(), ref)
+    with pytest.raises(RuntimeError):
+        K.sliding_stitch(nhwc(lg), [(0, 0, crop + 1, crop)] * len(tiles), h, w, False)
+
+
 def test_layout_and_labels(K):
     x = rnd(2, 3, 37, 41, seed=1).cuda()
     y = K.nchw_to_nhwc(x, c_pad=4)
