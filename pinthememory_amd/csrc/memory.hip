@@ -299,59 +299,85 @@ __global__ __launch_bounds__(256) void mem_write_update_bwd_kernel(const float* 
   if (dmem_in) dmem_in[j * D + c] = den != 0.f ? du * mu : du;
 }
 
-// Memory read on the matrix cores: one wave (= one 64-thread block) owns 32 query rows, and x is fetched from HBM exactly once.
-//   * the 32 rows are loaded as 32 fully coalesced 1 KB wave instructions into LDS (Xs, 33 KB), next to the m slots (Ms, 20 KB): 53 KB
-//     per block, three blocks per CU -- the 576 blocks of the flagship (18 432 rows) are resident at once;
+// Memory read on the matrix cores: a 256-thread block (4 waves) owns 32 query rows, and x is fetched from HBM exactly once.
+//   * the 32 rows are loaded as 32 fully coalesced 1 KB wave instructions (8 per wave, all in flight at once) into LDS (Xs, 33 KB);
+//   * wave w owns the channels [64 w, 64 w + 64): it forms the PARTIAL score tile over its quarter of the reduction (32 MFMAs instead
+//     of the 128 a lone wave would chain -- the single-wave version of this kernel was bound by exactly that latency: 208 dependent
+//     MFMAs = 5.5 us per tile with 2.25 waves per CU), parks it in LDS, and after one barrier every wave adds the four partials in the
+//     same fixed order, so all of them hold bit-identical scores;
 //   * both products run TRANSPOSED (operands swapped): S^T = M X^T and agg^T = M^T P^T, so the MFMA result layout hands lane
 //     (row = lane & 31, half = lane >> 5) 16 of its OWN row's 32 (padded) slots / four consecutive output channels per register quad:
-//     the softmax over the slots is 16 in-lane values + one exchange with the partner half-lane (no LDS transpose, no barrier), P is
-//     already the B operand of the second product, and [agg] leaves as 16-byte stores;
-//   * qhat = x / ||x|| is produced from the LDS copy (the previous version re-read x from L2: 1.25 x the algorithmic traffic).
-// The single wave never synchronises with anyone: LDS accesses of one wave are ordered by the hardware.
+//     the softmax over the slots is 16 in-lane values + one exchange with the partner half-lane, P is already the B operand of the
+//     second product (each wave produces its own 64 channels of it);
+//   * the 19 x 256 memory is read straight from L1 / L2 in fragment layout (19 KB, hot in every CU) and prefetched ahead of the x rows;
+//   * qhat = x / ||x|| is produced from the LDS copy, 8 rows per wave; [agg] is transposed through the same LDS rows and leaves as
+//     whole 1 KB rows as well.
+// 50 KB of LDS per block: three blocks (12 waves) per CU, the 576 blocks of the flagship (18 432 rows) are resident at once.
 typedef float mr_f32x16 __attribute__((ext_vector_type(16)));
 constexpr int MR_LDK = D + 4;     // 1040-byte rows: conflict-free ds_read_b128 fragments (bank step 4 per row)
+constexpr int MR_SP = 17 * 64;    // per wave: 16 partial-score registers + the partial squared norm, one float per lane each
 template <int M_>
-__global__ __launch_bounds__(64) void mem_read_fwd_mfma_kernel(const float* __restrict__ x, long xp, long rows, const float* __restrict__ mem, int m_rt,
-                                                               const float* __restrict__ noise, float* __restrict__ qr, long qp,
-                                                               float* __restrict__ score, float* __restrict__ pm) {
+__global__ __launch_bounds__(256, 3) void mem_read_fwd_mfma_kernel(const float* __restrict__ x, long xp, long rows, const float* __restrict__ mem, int m_rt,
+                                                                const float* __restrict__ noise, float* __restrict__ qr, long qp,
+                                                                float* __restrict__ score, float* __restrict__ pm) {
   constexpr int LDK = MR_LDK;
   constexpr int MM = M_ > 0 ? M_ : MAXM;
   const int M = M_ > 0 ? M_ : m_rt;
   extern __shared__ __align__(16) float mr_smem[];
   float* Xs = mr_smem;                  // [32][LDK]
-  float* Ms = mr_smem + 32 * LDK;       // [M][LDK]
-  const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
-  for (int r = 0; r < M; ++r) *reinterpret_cast<float4*>(Ms + r * LDK + lane * 4) = PM_LD4(mem + (long)r * D + lane * 4);
-  for (long row0 = (long)blockIdx.x * 32; row0 < rows; row0 += (long)gridDim.x * 32) {
+  float* Sp = mr_smem + 32 * LDK;       // [4][17][64]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+  const int mslot = min(l31, M - 1);                       // lanes beyond the slots read a valid row and multiply by zero below
+  const float mz = l31 < M ? 1.f : 0.f;
+  // this wave's fragments of the memory: S^T operand (slot = lane & 31, 4 consecutive channels per 8-channel group of its 64) ...
+  float4 mf[8];
 #pragma unroll
-    for (int it0 = 0; it0 < 32; it0 += 8) {   // 8 independent 1 KB row loads in flight
+  for (int g = 0; g < 8; ++g) {
+    mf[g] = PM_LD4(mem + (long)mslot * D + 64 * w + 8 * g + 4 * half);
+    mf[g].x *= mz, mf[g].y *= mz, mf[g].z *= mz, mf[g].w *= mz;
+  }
+  // ... and agg^T operand (channel = 64 w + 32 n + (lane & 31); step q multiplies slot (q&3) + 8 (q>>2) [+ 4 in the upper half-wave])
+  float ma[2][16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    if ((q & 3) + 8 * (q >> 2) >= MM) continue;             // both slots of this step are padding
+    const float* bp = mem + (long)min((q & 3) + 8 * (q >> 2) + 4 * half, M - 1) * D + 64 * w + l31;
+    ma[0][q] = bp[0], ma[1][q] = bp[32];
+  }
+  for (long row0 = (long)blockIdx.x * 32; row0 < rows; row0 += (long)gridDim.x * 32) {
+    if (row0 != (long)blockIdx.x * 32) __syncthreads();    // the previous tile's qhat pass is done with Xs
+    {
       float4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = PM_LD4(x + min(row0 + it0 + u, rows - 1) * xp + lane * 4);   // rows past the end: a copy of the last row, never stored
+      for (int u = 0; u < 8; ++u) v[u] = PM_LD4(x + min(row0 + 8 * w + u, rows - 1) * xp + lane * 4);   // rows past the end: a copy of the last row, never stored
 #pragma unroll
-      for (int u = 0; u < 8; ++u) *reinterpret_cast<float4*>(Xs + (it0 + u) * LDK + lane * 4) = v[u];
+      for (int u = 0; u < 8; ++u) *reinterpret_cast<float4*>(Xs + (8 * w + u) * LDK + lane * 4) = v[u];
     }
+    __syncthreads();
     const long myrow = min(row0 + l31, rows - 1);
     const bool live = row0 + l31 < rows;
-    const int mslot = min(l31, M - 1);                     // lanes beyond the slots read a valid row and multiply by zero below
-    const float mz = l31 < M ? 1.f : 0.f;
     mr_f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
     float n2 = 0.f;
-#pragma unroll 8
-    for (int g = 0; g < D / 8; ++g) {
-      const float4 a = *reinterpret_cast<const float4*>(Xs + l31 * LDK + 8 * g + 4 * half);      // lane & 31 = query row
-      float4 b = *reinterpret_cast<const float4*>(Ms + mslot * LDK + 8 * g + 4 * half);           // lane & 31 = slot
-      b.x *= mz, b.y *= mz, b.z *= mz, b.w *= mz;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const float4 a = *reinterpret_cast<const float4*>(Xs + l31 * LDK + 64 * w + 8 * g + 4 * half);      // lane & 31 = query row
       n2 += dot4(a, a);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a.x, acc, 0, 0, 0);                          // S^T[slot][row]: operands swapped
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a.w, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(mf[g].x, a.x, acc, 0, 0, 0);                              // S^T[slot][row]: operands swapped
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(mf[g].y, a.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(mf[g].z, a.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(mf[g].w, a.w, acc, 0, 0, 0);
     }
     n2 += __shfl_xor(n2, 32, 64);
-    const float nrm = fmaxf(sqrtf(n2), EPS);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Sp[w * MR_SP + q * 64 + lane] = acc[q];
+    Sp[w * MR_SP + 16 * 64 + lane] = n2;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = ((Sp[q * 64 + lane] + Sp[MR_SP + q * 64 + lane]) + Sp[2 * MR_SP + q * 64 + lane]) + Sp[3 * MR_SP + q * 64 + lane];
+    n2 = ((Sp[16 * 64 + lane] + Sp[MR_SP + 16 * 64 + lane]) + Sp[2 * MR_SP + 16 * 64 + lane]) + Sp[3 * MR_SP + 16 * 64 + lane];
+    const float rnrm = 1.f / fmaxf(sqrtf(n2), EPS);      // one division per row; qhat and the scores multiply by it (<= 1 ulp from x / ||x||)
     // acc[q] = <x_row, m_slot> for slot s = (q & 3) + 8 (q >> 2) + 4 half of this lane's own row
     float pr[16];
     float mx = -INFINITY;
@@ -359,8 +385,8 @@ __global__ __launch_bounds__(64) void mem_read_fwd_mfma_kernel(const float* __re
     for (int q = 0; q < 16; ++q) {
       const int sl = (q & 3) + 8 * (q >> 2) + 4 * half;
       if ((q & 3) + 8 * (q >> 2) < MM && sl < M) {          // first test: compile-time pruning of register quads beyond the slots
-        float sv = acc[q] / nrm;
-        if (live) score[myrow * M + sl] = sv;
+        float sv = acc[q] * rnrm;
+        if (live && w == 0) score[myrow * M + sl] = sv;
         if (noise) sv += noise[myrow * M + sl];
         pr[q] = sv;
         mx = fmaxf(mx, sv);
@@ -373,43 +399,49 @@ __global__ __launch_bounds__(64) void mem_read_fwd_mfma_kernel(const float* __re
 #pragma unroll
     for (int q = 0; q < 16; ++q) pr[q] = pr[q] == -INFINITY ? 0.f : expf(pr[q] - mx), se += pr[q];
     se += __shfl_xor(se, 32, 64);
+    const float rse = 1.f / se;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int sl = (q & 3) + 8 * (q >> 2) + 4 * half;
-      pr[q] = pr[q] / se;
-      if ((q & 3) + 8 * (q >> 2) < MM && sl < M && live) pm[myrow * M + sl] = pr[q];
+      pr[q] = pr[q] * rse;
+      if ((q & 3) + 8 * (q >> 2) < MM && sl < M && live && w == 1) pm[myrow * M + sl] = pr[q];
     }
-    // agg^T = M^T P^T, 128 channels per pass: step q multiplies slot (q&3) + 8 (q>>2) [+ 4 in the upper half-wave]; padding slots carry P = 0
+    // qhat = x / ||x|| from the LDS copy, one row (1 KB) per wave instruction; the row's norm lives in lane (row & 31)
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      mr_f32x16 ag[4];
+    for (int u = 0; u < 8; ++u) {
+      const long r = row0 + 8 * w + u;
+      const float nr = __shfl(rnrm, 8 * w + u, 64);
+      const float4 v = *reinterpret_cast<const float4*>(Xs + (8 * w + u) * LDK + lane * 4);
+      if (r < rows) PM_ST4(qr + r * qp + lane * 4, make_float4(v.x * nr, v.y * nr, v.z * nr, v.w * nr));
+    }
+    __syncthreads();                                       // every wave is done with the x rows: Xs becomes the [32][256] staging tile of agg
+    // agg^T = M^T P^T for this wave's 64 channels; padding slots carry P = 0. The register quads (4 consecutive channels of the lane's own
+    // row) are parked in LDS and leave as whole 1 KB rows, 8 rows per wave: full-line stores instead of 32-byte pieces of 32 rows.
+    {
+      mr_f32x16 ag[2];
 #pragma unroll
-      for (int n = 0; n < 4; ++n)
+      for (int n = 0; n < 2; ++n)
 #pragma unroll
         for (int q = 0; q < 16; ++q) ag[n][q] = 0.f;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        if ((q & 3) + 8 * (q >> 2) >= MM) continue;        // both slots of this step are padding
-        const float* bp = Ms + min((q & 3) + 8 * (q >> 2) + 4 * half, M - 1) * LDK + pass * 128 + l31;   // lane & 31 = channel here
+        if ((q & 3) + 8 * (q >> 2) >= MM) continue;
 #pragma unroll
-        for (int n = 0; n < 4; ++n) ag[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bp[n * 32], pr[q], ag[n], 0, 0, 0);
+        for (int n = 0; n < 2; ++n) ag[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ma[n][q], pr[q], ag[n], 0, 0, 0);
       }
-      if (live) {
-        float* dst = qr + myrow * qp + D + pass * 128 + 4 * half;
+      float* dst = Xs + l31 * LDK + 64 * w + 4 * half;
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+      for (int n = 0; n < 2; ++n)
 #pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4)
-            PM_ST4(dst + n * 32 + 8 * g4, make_float4(ag[n][4 * g4], ag[n][4 * g4 + 1], ag[n][4 * g4 + 2], ag[n][4 * g4 + 3]));
-      }
+        for (int g4 = 0; g4 < 4; ++g4)
+          *reinterpret_cast<float4*>(dst + n * 32 + 8 * g4) = make_float4(ag[n][4 * g4], ag[n][4 * g4 + 1], ag[n][4 * g4 + 2], ag[n][4 * g4 + 3]);
     }
-    // qhat = x / ||x|| from the LDS copy, one row (1 KB) per wave instruction; the row's norm lives in lane (row & 31)
-#pragma unroll 8
-    for (int u = 0; u < 32; ++u) {
-      const long r = row0 + u;
-      const float nr = __shfl(nrm, u, 64);
-      const float4 v = *reinterpret_cast<const float4*>(Xs + u * LDK + lane * 4);
-      if (r < rows) PM_ST4(qr + r * qp + lane * 4, make_float4(v.x / nr, v.y / nr, v.z / nr, v.w / nr));
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long r = row0 + 8 * w + u;
+      const float4 v = *reinterpret_cast<const float4*>(Xs + (8 * w + u) * LDK + lane * 4);
+      if (r < rows) PM_ST4(qr + r * qp + D + lane * 4, v);
     }
   }
 }
@@ -427,12 +459,12 @@ extern "C" int pm_mem_read_fwd(const pm_tensor* x, const float* mem, int m, cons
   const long rows = pm_pixels(x);
   hipStream_t st = (hipStream_t)stream;
   const int nb = (int)std::min<long>((rows + 31) / 32, 256 * 3 * 4);
-  const size_t lds = (size_t)(32 + m) * MR_LDK * sizeof(float);
+  const size_t lds = (size_t)(32 * MR_LDK + 4 * MR_SP) * sizeof(float);
   if (m == 19)
-    hipLaunchKernelGGL(mem_read_fwd_mfma_kernel<19>, dim3(nb), dim3(64), lds, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, noise, (float*)qr->ptr,
+    hipLaunchKernelGGL(mem_read_fwd_mfma_kernel<19>, dim3(nb), dim3(256), lds, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, noise, (float*)qr->ptr,
                        (long)qr->pitch, score, p_mem);
   else
-    hipLaunchKernelGGL(mem_read_fwd_mfma_kernel<0>, dim3(nb), dim3(64), lds, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, noise, (float*)qr->ptr,
+    hipLaunchKernelGGL(mem_read_fwd_mfma_kernel<0>, dim3(nb), dim3(256), lds, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, noise, (float*)qr->ptr,
                        (long)qr->pitch, score, p_mem);
   return pm_check_launch("mem_read_fwd");
 }

@@ -29,6 +29,9 @@ def rec(name, nbytes, fn, iters=20):
     t = bench(fn, iters); out[name] = dict(ms=t, algorithmic_MB=nbytes / 1e6, GBps=nbytes / t / 1e6)
     print('%-22s %8.3f ms  %8.1f MB algorithmic  %8.1f GB/s' % (name, t, nbytes / 1e6, nbytes / t / 1e6), flush=True)
 rec('copy_calibration', 2 * cal_a.numel() * 4, lambda: K.copy(cal_a, cal_b))
+cal_c = torch.randn(N * 3 * d // 2, device='cuda'); cal_d = torch.empty_like(cal_c)                      # 28.3 MB each way = the read's 56.6 MB
+rec('copy_small_calibration', 2 * cal_c.numel() * 4, lambda: K.copy(cal_c.view(1, 1, -1, d), cal_d.view(1, 1, -1, d)))
+rec('fill_calibration', cal_b.numel() * 4, lambda: cal_b.zero_())
 rec('mem_read_fwd', N * d * 4 + m * d * 4 + N * 2 * d * 4 + 2 * N * m * 4, lambda: K.mem_read_fwd(x, mem))            # 59.4 MB
 rec('mem_read_bwd', N * 2 * d * 4 + N * d * 4 + N * d * 4 + 2 * N * m * 4, lambda: K.mem_read_bwd(x, mem, pmem, dqr, dsx))   # 75.5 MB + scores
 rec('mem_colsoftmax', 2 * N * m * 4, lambda: K.mem_colsoftmax(score))
