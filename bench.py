@@ -186,18 +186,22 @@ def memory_path_roofline(batch, size):
     except (OSError, KeyError, ValueError, IndexError):
         src = None
     rows = []
+    fill_a = torch.empty(B, H // 4, H // 4, d, device=x.device)      # 302 MB at the flagship size: ~0.12 ms per copy
+    fill_b = torch.empty_like(fill_a)
+    reps = 20
     for name, ref, nbytes, fn in cases:
         for _ in range(3):
             fn()
-        reps = 10
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
-        for a, b in evs:
-            a.record()
+        for _ in range(12):              # ~1.4 ms of queued copies: the host runs ahead, so the timed launches execute back to back
+            K.copy(fill_a, fill_b)
+        s.record()
+        for _ in range(reps):
             fn()
-            b.record()
+        e.record()
         torch.cuda.synchronize()
-        ms = sorted(a.elapsed_time(b) for a, b in evs)[reps // 2]          # median launch
+        ms = s.elapsed_time(e) / reps
         rows.append({'op': name, 'replaces': ref, 'algorithmic_MB': round(nbytes / 1e6, 2), 'launch_us': round(ms * 1e3, 1),
                      'achieved': round(nbytes / ms / 1e6, 1), 'frac': round(nbytes / ms / 1e6 / PEAK_HBM_GBPS, 4)})
     head = dict(rows[0])
@@ -205,8 +209,9 @@ def memory_path_roofline(batch, size):
            'achieved': head['achieved'], 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': head['frac'], 'launch_us': head['launch_us'],
            'algorithmic_MB': head['algorithmic_MB'],
            'traffic': next((round(v['hbm_MB_per_launch'] * 1e6) for k, v in counters.items() if k.startswith('mem_read_fwd')), None), 'traffic_source': src,
-           'measured': 'median of 10 launches, each bracketed by its own HIP event pair on the launch stream, after the timed region; one launch may include the '
-                       'second-stage kernels of the op (fixed-order reductions)',
+           'measured': 'after the timed region: %d back-to-back launches between one pair of HIP events on the launch stream, queued behind ~1.4 ms of copies so '
+                       'that the host is ahead of the GPU (an event pair per launch adds ~5 us of launch latency to a 20 us kernel); average per launch incl. '
+                       'the gaps between kernels; one launch may include the second-stage kernels of the op (fixed-order reductions)' % reps,
            'all_memory_path_ops': rows}
     return out
 

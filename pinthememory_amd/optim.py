@@ -11,7 +11,10 @@ from .hip import kernels as K
 
 
 def _dense_like(a, b):
-    return a.stride() == b.stride() and a.dtype == b.dtype == torch.float32 and a.is_cuda and b.is_cuda
+    """Same element order in memory: strides agree on every dimension that has more than one element (a [Cout, Cin, 1, 1] weight gradient
+    that arrives as a channels-last view has other strides on its unit dimensions and the same bytes)."""
+    same = a.shape == b.shape and all(sa == sb for n, sa, sb in zip(a.shape, a.stride(), b.stride()) if n > 1)
+    return same and a.dtype == b.dtype == torch.float32 and a.is_cuda and b.is_cuda
 
 
 class SGD(torch.optim.SGD):
