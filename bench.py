@@ -349,7 +349,7 @@ def main():
                 import glob
                 pj = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_1gpu_hbm_counters.json')))[-1]      # the latest committed PMC passes
                 for kr in json.load(open(pj))['kernels']:
-                    if kr['kernel'].replace('void ', '').strip() == sym:
+                    if kr['kernel'].replace('void ', '').replace(', false>', '>').strip() == sym:      # the symbol's trailing STATS=false template argument
                         traffic = round((kr['read_MB_per_launch'] + kr['write_MB_per_launch']) * 1e6)
                         traffic_src = ('profiles/' + os.path.basename(pj) + ': rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of '
                                        'bench.py --steps 1 --warmup 1; read = 2 x FETCH_SIZE (gfx950), average over all launches of the symbol')

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Aggregate a pm_profile_dump CSV (PM_PROFILE_DUMP=path python bench.py) by launch shape: time, TFLOP/s and the time that a
-135 TFLOP/s kernel would save. Usage: conv_shapes.py dump.csv [steps]"""
+135 TFLOP/s kernel would save. Usage: conv_shapes.py dump.csv [steps [rows]]"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0
@@ -18,5 +18,5 @@ for k, (n, ms, gf) in agg.items():
     out.append((lost / steps, ms / steps, n / steps, tf, k))
 out.sort(reverse=True)
 print('%8s %8s %6s %7s  mode bm  bn km nst      M     N      K  batch ksplit' % ('lost/st', 'ms/st', 'n/st', 'TF'))
-for lost, ms, n, tf, k in out[:45]:
+for lost, ms, n, tf, k in out[:int(sys.argv[3]) if len(sys.argv) > 3 else 45]:
     print('%8.3f %8.3f %6.1f %7.1f  %4d %3d %3d %2d %3d %7d %5d %6d %5d %5d' % ((lost, ms, n, tf) + k))
