@@ -642,3 +642,34 @@ def test_side_stream_prefetcher_equals_direct_edge(env):
         return float(losses['total']), net.memory.m_items.clone(), net.final2[-1].weight.detach().clone()
     a, b = run(True), run(False)
     assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+
+@pytest.mark.parametrize('arch', ['DeepR50V3PlusD_OS8', 'DeepR50V2D'])
+def test_sibling_archs_eval_and_step_vs_oracle(env, arch):
+    """The cheap siblings SURVEY 8(b) keeps in scope: output stride 8 (layer3 dilation 2, layer4 dilation 4, ASPP rates 12 / 24 / 36:
+    deepv3plus.py:343-345,58-59) and the ResNet-50 DeepLabV2 'D' variant (deepv2.py:342-349). Eval logits and the memory read against the CPU
+    oracle at 192^2 (24 x 24 maps: every dilation <= 24 has in-range taps), then one agg step: five losses, committed memory, every parameter."""
+    synth, h, o_h = env['synth'], env['harness'], env['o_harness']
+    mod, omod = (env['deepv2'], env['o_deeplab']) if arch.endswith('V2D') else (env['deepv3plus'], env['o_deeplab'])
+    ref = synth.load_det_weights(getattr(omod, arch)(synth.model_args(), 19, CRIT, CRIT)).eval()
+    net = synth.load_det_weights(getattr(mod, arch)(synth.model_args(), 19, CRIT, CRIT)).cuda().eval()
+    x, y = synth.make_batch(2, 192, seed=21)
+    with torch.no_grad():
+        want, got = ref(x), net(x.cuda())
+    lg = got[0].cpu()
+    assert lg.shape == want[0].shape and (lg - want[0]).abs().max().item() < LOGIT_TOL
+    ok, frac, safe = argmax_gate(lg, want[0])
+    assert ok and frac > 0.9995, (frac, safe)
+    assert (got[1][1].cpu() - want[1][1]).abs().max().item() < 1e-4
+    for n_ in (ref, net):
+        n_.dsn[3].p = 0.0
+    o_opt, _ = o_h.make_optimizer(ref)
+    opt, _ = h.make_optimizer(net)
+    w_l = o_h.agg_train_step(ref, o_opt, x, y)
+    g_l = h.agg_train_step(net, opt, x.cuda(), y.cuda())
+    for k in w_l:
+        assert abs(float(g_l[k]) - float(w_l[k])) <= 2e-4 * max(1.0, abs(float(w_l[k]))), (k, float(g_l[k]), float(w_l[k]))
+    assert (net.memory.m_items.cpu() - ref.memory.m_items).abs().max().item() < 1e-4
+    worst = max(((v.detach().cpu() - ref.state_dict()[k]).abs().max().item() / (ref.state_dict()[k].abs().max().item() + 1e-12), k)
+                for k, v in net.state_dict().items() if v.dtype.is_floating_point)
+    assert worst[0] < 2e-4, worst
