@@ -1,8 +1,9 @@
 // K7/K8: the categorical memory of "Pin the Memory" (/root/reference/network/memory.py) -- HBM-bound row kernels.
 //   read   (memory.py:317-336 + get_score :167-189): qhat = x/max(|x|,1e-12); S = qhat.M^T; P = softmax_slots(S [+gumbel]);
-//          R = P.M; writes [qhat | R] (the 2d-channel input of memory.output), S and P. Forward: one wave per 32 query rows, both
-//          products as MFMA tiles against the 19x256 memory held in LDS (mem_read_fwd_mfma_kernel below); backward: one wave per row
-//          (d = 256 = 64 lanes x float4), per-slot dot products reduced with wave shuffles.
+//          R = P.M; writes [qhat | R] (the 2d-channel input of memory.output), S and P. Forward and the dx-only backward: four waves per
+//          32 query rows, both products as MFMA tiles (mem_read_fwd_mfma_kernel / mem_read_bwd_mfma_kernel below); backward with dmem
+//          (meta-test read through a written memory): one wave per row (d = 256 = 64 lanes x float4), per-slot dot products reduced
+//          with wave shuffles.
 //   write  (memory.py:206-239): 4-tap bilinear(align_corners) soft labels straight from the int64 mask (never the
 //          755 MB one-hot), class-masked accumulation of nominator[20][256] / denominator[20] in per-wave LDS slabs,
 //          fixed-order two-stage reduce; momentum update + renormalise with a device-side `den != 0` predicate
@@ -446,6 +447,136 @@ __global__ __launch_bounds__(256, 3) void mem_read_fwd_mfma_kernel(const float* 
   }
 }
 
+// Memory read backward on the matrix cores (dx only; the dmem variant keeps the row kernel above). Same decomposition as the forward kernel:
+// a 256-thread block owns 32 query rows, wave w the channels [64 w, 64 w + 64). Lane (row = lane & 31, half = lane >> 5) holds, for
+// g = 0..7, the four channels 64 w + 8 g + 4 half + (0..3) of ITS row of x, dq and dr -- which is both the B-operand layout of
+// dP^T = M dR^T (reduction split over the four waves, partials added in fixed order after one barrier) and the result layout of
+// add^T = M^T dS^T, so everything between the two products (softmax backward over the slots, the extra score gradient) and after them
+// (dq + add, the projection off q of the normalisation backward, whose row dot needs one more cross-wave sum) stays in registers.
+// dx leaves as whole 1 KB rows through an LDS tile. 220 VGPRs (three row fragments of 32 floats + the memory fragment): two blocks per CU; capping
+// the registers for three spills and is slower (30.5 vs 24.1 us). 78.3 MB in 24 us = 3.25 TB/s (49 us for the row kernel).
+template <int M_>
+__global__ __launch_bounds__(256, 2) void mem_read_bwd_mfma_kernel(const float* __restrict__ x, long xp, long rows, const float* __restrict__ mem, int m_rt,
+                                                                   const float* __restrict__ pm, const float* __restrict__ dqr, long dqp,
+                                                                   const float* __restrict__ dsx, float* __restrict__ dx, long dxp) {
+  constexpr int LDK = MR_LDK;
+  constexpr int MM = M_ > 0 ? M_ : MAXM;
+  const int M = M_ > 0 ? M_ : m_rt;
+  extern __shared__ __align__(16) float mr_smem[];
+  float* Os = mr_smem;                  // [32][LDK]: dx tile
+  float* Sp = mr_smem + 32 * LDK;       // [4][17][64]: partial dP quads + partial squared norm / partial row dot
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+  const int mslot = min(l31, M - 1);
+  const float mz = l31 < M ? 1.f : 0.f;
+  float4 mf[8];
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    mf[g] = PM_LD4(mem + (long)mslot * D + 64 * w + 8 * g + 4 * half);
+    mf[g].x *= mz, mf[g].y *= mz, mf[g].z *= mz, mf[g].w *= mz;
+  }
+  for (long row0 = (long)blockIdx.x * 32; row0 < rows; row0 += (long)gridDim.x * 32) {
+    if (row0 != (long)blockIdx.x * 32) __syncthreads();    // the previous tile's row stores are done with Os / Sp
+    const long myrow = min(row0 + l31, rows - 1);
+    const bool live = row0 + l31 < rows;
+    float4 xv[8], dq[8], dr[8];
+    {
+      const float* xr = x + myrow * xp + 64 * w + 4 * half;
+      const float* qr = dqr + myrow * dqp + 64 * w + 4 * half;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) dr[g] = PM_LD4(qr + D + 8 * g);
+#pragma unroll
+      for (int g = 0; g < 8; ++g) xv[g] = PM_LD4(xr + 8 * g);
+#pragma unroll
+      for (int g = 0; g < 8; ++g) dq[g] = PM_LD4(qr + 8 * g);
+    }
+    mr_f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(mf[g].x, dr[g].x, acc, 0, 0, 0);       // dP^T[slot][row]
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(mf[g].y, dr[g].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(mf[g].z, dr[g].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(mf[g].w, dr[g].w, acc, 0, 0, 0);
+    }
+    float n2 = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) n2 += dot4(xv[g], xv[g]);
+    n2 += __shfl_xor(n2, 32, 64);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Sp[w * MR_SP + q * 64 + lane] = acc[q];
+    Sp[w * MR_SP + 16 * 64 + lane] = n2;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = ((Sp[q * 64 + lane] + Sp[MR_SP + q * 64 + lane]) + Sp[2 * MR_SP + q * 64 + lane]) + Sp[3 * MR_SP + q * 64 + lane];
+    n2 = ((Sp[16 * 64 + lane] + Sp[MR_SP + 16 * 64 + lane]) + Sp[2 * MR_SP + 16 * 64 + lane]) + Sp[3 * MR_SP + 16 * 64 + lane];
+    const float n0 = sqrtf(n2);
+    const float rn = 1.f / fmaxf(n0, EPS);
+    // softmax backward over the slots of the lane's own row: ds = p (dp - sum_j p_j dp_j) + dsx
+    float ds[16], pv[16];
+    float pdp = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int sl = (q & 3) + 8 * (q >> 2) + 4 * half;
+      pv[q] = 0.f;
+      if ((q & 3) + 8 * (q >> 2) < MM && sl < M) {
+        pv[q] = pm[myrow * M + sl];
+        pdp += pv[q] * acc[q];
+      }
+    }
+    pdp += __shfl_xor(pdp, 32, 64);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int sl = (q & 3) + 8 * (q >> 2) + 4 * half;
+      ds[q] = 0.f;
+      if ((q & 3) + 8 * (q >> 2) < MM && sl < M) ds[q] = pv[q] * (acc[q] - pdp) + (dsx ? dsx[myrow * M + sl] : 0.f);
+    }
+    __syncthreads();                                       // every wave has read the partials: Sp is free for the row dots
+    // dq += dS M for this wave's 64 channels
+    float qd = 0.f;
+    {
+      mr_f32x16 ag[2];
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) ag[n][q] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        if ((q & 3) + 8 * (q >> 2) >= MM) continue;
+        const float* bp = mem + (long)min((q & 3) + 8 * (q >> 2) + 4 * half, M - 1) * D + 64 * w + l31;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) ag[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bp[32 * n], ds[q], ag[n], 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        dq[g].x += ag[g >> 2][4 * (g & 3)], dq[g].y += ag[g >> 2][4 * (g & 3) + 1], dq[g].z += ag[g >> 2][4 * (g & 3) + 2], dq[g].w += ag[g >> 2][4 * (g & 3) + 3];
+        qd += dot4(xv[g], dq[g]);
+      }
+    }
+    qd *= rn;                                              // q . dq with q = x / ||x||
+    qd += __shfl_xor(qd, 32, 64);
+    Sp[w * 64 + lane] = qd;
+    __syncthreads();
+    qd = ((Sp[lane] + Sp[64 + lane]) + Sp[128 + lane]) + Sp[192 + lane];
+    // through qhat = x / max(|x|, eps): o = (dq - q (q . dq)) / ||x||  (the clamp is inactive for every row with a norm >= eps)
+    {
+      const float c = n0 >= EPS ? qd * rn : 0.f;
+      float* dst = Os + l31 * LDK + 64 * w + 4 * half;
+#pragma unroll
+      for (int g = 0; g < 8; ++g)
+        *reinterpret_cast<float4*>(dst + 8 * g) = make_float4((dq[g].x - xv[g].x * c) * rn, (dq[g].y - xv[g].y * c) * rn, (dq[g].z - xv[g].z * c) * rn, (dq[g].w - xv[g].w * c) * rn);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long r = row0 + 8 * w + u;
+      const float4 v = *reinterpret_cast<const float4*>(Os + (8 * w + u) * LDK + lane * 4);
+      if (r < rows) PM_ST4(dx + r * dxp + lane * 4, v);
+    }
+    (void)live;
+  }
+}
+
 inline int row_blocks(long rows) { return (int)std::min<long>((rows + 3) / 4, 256 * 8); }
 inline int accum_blocks(long rows) { return (int)std::min<long>((rows + 15) / 16, 256); }   // one block (4 wave slabs in LDS) per CU
 
@@ -499,6 +630,15 @@ extern "C" int pm_mem_read_bwd(const pm_tensor* x, const float* mem, int m, cons
                          (const float*)dqr->ptr, (long)dqr->pitch, dsx, (float*)dx->ptr, (long)dx->pitch, (float*)ws);
     const long n = (long)m * D;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(pm_cdiv(n, 16)), dim3(256), 0, st, (const float*)ws, nb, n, dmem);
+  } else if (getenv("PM_MEM_BWD_ROWS") == nullptr) {
+    const int nt = (int)std::min<long>((rows + 31) / 32, 256 * 3 * 4);
+    const size_t lds = (size_t)(32 * MR_LDK + 4 * MR_SP) * sizeof(float);
+    if (m == 19)
+      hipLaunchKernelGGL(mem_read_bwd_mfma_kernel<19>, dim3(nt), dim3(256), lds, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, p_mem,
+                         (const float*)dqr->ptr, (long)dqr->pitch, dsx, (float*)dx->ptr, (long)dx->pitch);
+    else
+      hipLaunchKernelGGL(mem_read_bwd_mfma_kernel<0>, dim3(nt), dim3(256), lds, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, p_mem,
+                         (const float*)dqr->ptr, (long)dqr->pitch, dsx, (float*)dx->ptr, (long)dx->pitch);
   } else {
     if (m == 19)
       hipLaunchKernelGGL((mem_read_bwd_kernel<19, false>), dim3(nb), dim3(256), 0, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, p_mem,

@@ -394,6 +394,18 @@ def test_memory_read(K):
     dx, dmem = K.mem_read_bwd(xg, memg, pmem, dqr.view(n, h, w, 2 * d).cuda(), dsx.cuda(), want_dmem=True)
     assert rel(nchw(dx)[:, :, 1:], xr.grad[:, :, 1:]) < 2e-5
     assert rel(dmem, mr.grad) < 2e-5
+    # dx alone (m_items detached: the training step's case) takes the MFMA kernel; the row kernel above is the dmem variant
+    dx2, none = K.mem_read_bwd(xg, memg, pmem, dqr.view(n, h, w, 2 * d).cuda(), dsx.cuda())
+    assert none is None and rel(nchw(dx2)[:, :, 1:], xr.grad[:, :, 1:]) < 2e-5
+    assert rel(dx2, dx) < 1e-5                           # incl. the all-zero row (gradient scaled by 1 / eps in both)
+    dx3, _ = K.mem_read_bwd(xg, memg, pmem, dqr.view(n, h, w, 2 * d).cuda(), None)
+    dx4, _ = K.mem_read_bwd(xg, memg, pmem, dqr.view(n, h, w, 2 * d).cuda(), None, want_dmem=True)
+    assert rel(dx3[:, 1:], dx4[:, 1:]) < 1e-5
+    m7 = F.normalize(rnd(7, d, seed=6), dim=1).cuda()    # a slot count without a specialised instantiation
+    _, _, p7 = K.mem_read_fwd(xg, m7)
+    a7, _ = K.mem_read_bwd(xg, m7, p7, dqr.view(n, h, w, 2 * d).cuda(), dsx[:, :7].contiguous().cuda())
+    b7, _ = K.mem_read_bwd(xg, m7, p7, dqr.view(n, h, w, 2 * d).cuda(), dsx[:, :7].contiguous().cuda(), want_dmem=True)
+    assert rel(a7[:, 1:], b7[:, 1:]) < 1e-5
     # gumbel path with injected noise (memory.py:181-184): softmax((S + g) / 1)
     noise = -torch.empty(n * h * w, m).exponential_(generator=torch.Generator().manual_seed(5)).log()
     _, _, pg = K.mem_read_fwd(xg, memg, noise.cuda())

@@ -170,6 +170,14 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void gemm_lab(const float* __rest
       }
   };
 
+  // PF2 >= 2: raw s_barrier instead of __syncthreads(): the compiler's workgroup barrier carries s_waitcnt vmcnt(0), which drains the loads that
+  // were issued two slabs ahead at EVERY barrier (so the deeper prefetch of PF2 == 1 never spans one); here only LDS traffic is waited for
+  auto bar_reads_done = [&]() {
+    if (PF2 >= 2) { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } else __syncthreads();
+  };
+  auto bar_writes_visible = [&]() {
+    if (PF2 >= 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } else __syncthreads();
+  };
   const int nk = K / BKK;
   if (!PERSIST) {
     int m0, n0, by;
@@ -178,28 +186,28 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void gemm_lab(const float* __rest
     issue(m0, n0, by, 0);
     stash(0);
     __syncthreads();
-    if (NST == 1 && PF2) {      // loads run two slabs ahead of the MFMAs (two register sets, loop unrolled by two)
+    if (NST == 1 && (PF2 == 1 || PF2 == 2)) {      // loads run two slabs ahead of the MFMAs (two register sets, loop unrolled by two)
       if (nk > 1) issue_into(ra2, rb2, m0, n0, by, BKK);
       int kt = 0;
       for (; kt + 2 < nk; kt += 2) {
         issue_into(ra, rb, m0, n0, by, (kt + 2) * BKK);
         __builtin_amdgcn_sched_barrier(0);
         compute(0);
-        __syncthreads();
+        bar_reads_done();
         stash_from(ra2, rb2, 0);
-        __syncthreads();
+        bar_writes_visible();
         if (kt + 3 < nk) issue_into(ra2, rb2, m0, n0, by, (kt + 3) * BKK);
         __builtin_amdgcn_sched_barrier(0);
         compute(0);
-        __syncthreads();
+        bar_reads_done();
         stash_from(ra, rb, 0);
-        __syncthreads();
+        bar_writes_visible();
       }
       if (kt + 1 < nk) {       // nk even: slab nk-1 is still in ra2
         compute(0);
-        __syncthreads();
+        bar_reads_done();
         stash_from(ra2, rb2, 0);
-        __syncthreads();
+        bar_writes_visible();
       }
       compute(0);
     } else if (NST == 1) {
@@ -207,9 +215,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void gemm_lab(const float* __rest
         issue(m0, n0, by, (kt + 1) * BKK);
         __builtin_amdgcn_sched_barrier(0);
         compute(0);
-        __syncthreads();
+        bar_reads_done();
         stash(0);
-        __syncthreads();
+        bar_writes_visible();
       }
       compute(0);
     } else {
@@ -490,6 +498,39 @@ int main(int argc, char** argv) {
   for (const Shape& s : shapes) {
     const double fl = 2.0 * s.M * s.N * s.K * s.batch;
     auto rep = [&](const char* v, double us) { printf("%-30s %-44s %9.1f %8.1f\n", s.name, v, us, fl / us * 1e-6); fflush(stdout); };
+    if (argc > 1 && std::string(argv[1]) == "diag") {     // counter passes (rocprofv3 --pmc): the 1x1 256->1024 @48 class of the dominant kernel only
+      if (std::string(s.name) != "1x1 512->2048 @48") continue;
+      const Shape d = {"1x1 256->1024 @48", 18432, 1024, 256, 1};
+      const double fd = 2.0 * d.M * d.N * d.K;
+      auto rd = [&](const char* v, double us) { printf("%-30s %-44s %9.1f %8.1f\n", d.name, v, us, fd / us * 1e-6); fflush(stdout); };
+      rd("64x64 staged stores (production)", run<64, 64, 32, 1, 0, 0, 2, 2>(d, A, B, C, 0, 5));
+      rd("64x64 staged, no loads", run<64, 64, 32, 1, 0, 1, 2, 2>(d, A, B, C, 0, 5));
+      rd("64x64 staged, no stores", run<64, 64, 32, 1, 0, 2, 2, 2>(d, A, B, C, 0, 5));
+      rd("64x64 staged, core only", run<64, 64, 32, 1, 0, 3, 2, 2>(d, A, B, C, 0, 5));
+      rd("64x64 staged, no MFMA", run<64, 64, 32, 1, 0, 4, 2, 2>(d, A, B, C, 0, 5));
+      rd("128x128 staged stores", run<128, 128, 32, 1, 0, 0, 2, 2>(d, A, B, C, 0, 5));
+      continue;
+    }
+    if (argc > 1 && std::string(argv[1]) == "rawbar") {
+      rep("128x128 nst1", run<128, 128, 32, 1, 0, 0, 2>(s, A, B, C, 0));
+      rep("128x128 nst1 raw barriers", run<128, 128, 32, 1, 0, 0, 2, 0, 3>(s, A, B, C, 0));
+      printf("   max |err| vs fp64 dot: %.3g\n", check(s, A, B, C));
+      rep("128x128 loads two slabs ahead", run<128, 128, 32, 1, 0, 0, 2, 0, 1>(s, A, B, C, 0));
+      rep("128x128 loads two slabs ahead, raw barriers", run<128, 128, 32, 1, 0, 0, 2, 0, 2>(s, A, B, C, 0));
+      printf("   max |err| vs fp64 dot: %.3g\n", check(s, A, B, C));
+      rep("128x128 staged stores", run<128, 128, 32, 1, 0, 0, 2, 2>(s, A, B, C, 0));
+      rep("128x128 staged stores, two ahead, raw barriers", run<128, 128, 32, 1, 0, 0, 2, 2, 2>(s, A, B, C, 0));
+      rep("64x64 nst1", run<64, 64, 32, 1, 0, 0, 2>(s, A, B, C, 0));
+      rep("64x64 nst1 raw barriers", run<64, 64, 32, 1, 0, 0, 2, 0, 3>(s, A, B, C, 0));
+      rep("64x64 loads two slabs ahead", run<64, 64, 32, 1, 0, 0, 2, 0, 1>(s, A, B, C, 0));
+      rep("64x64 loads two slabs ahead, raw barriers", run<64, 64, 32, 1, 0, 0, 2, 0, 2>(s, A, B, C, 0));
+      printf("   max |err| vs fp64 dot: %.3g\n", check(s, A, B, C));
+      rep("64x64 staged stores", run<64, 64, 32, 1, 0, 0, 2, 2>(s, A, B, C, 0));
+      rep("64x64 staged stores, two ahead, raw barriers", run<64, 64, 32, 1, 0, 0, 2, 2, 2>(s, A, B, C, 0));
+      rep("64x128 staged stores", run<64, 128, 32, 1, 0, 0, 2, 2>(s, A, B, C, 0));
+      rep("64x128 staged stores, two ahead, raw barriers", run<64, 128, 32, 1, 0, 0, 2, 2, 2>(s, A, B, C, 0));
+      continue;
+    }
     rep("128x128 bk32 nst1 (Winograd GEMM tile)", run<128, 128, 32, 1, 0, 0, 2>(s, A, B, C, 0));
     printf("   max |err| vs fp64 dot: %.3g\n", check(s, A, B, C));
     rep("  ablation: no global loads", run<128, 128, 32, 1, 0, 1, 2>(s, A, B, C, 0));
