@@ -396,6 +396,8 @@ def main():
     if multi:
         from pinthememory_amd import rccl
         torch.cuda.synchronize()
+        dist.barrier()          # rank 0 is still producing its side measurements: nobody tears a communicator down under it
+        torch.cuda.synchronize()
         rccl.shutdown()
         dist.destroy_process_group()
 
