@@ -1133,13 +1133,14 @@ WinoPlan wino_plan(const pm_tensor* xin, int cout, const pm_conv_params* p, bool
 inline size_t wino_ws(const WinoPlan& wp) { return wp.v_bytes + wp.m_bytes + wp.u_bytes; }
 
 int wino_conv(const pm_tensor* xin, const float* w, int w_cout, int w_cin, bool dgrad, const pm_tensor* yout, const WinoPlan& wp,
-              const pm_conv_epilogue& ep, void* ws, hipStream_t st, float* v_keep = nullptr) {
+              const pm_conv_epilogue& ep, void* ws, hipStream_t st, float* v_keep = nullptr, float* u_ext = nullptr, bool u_valid = false) {
   float* V = v_keep ? v_keep : (float*)ws;   // forward of a training step: the transformed input is kept for the weight gradient
   float* Mo = (float*)((char*)ws + wp.v_bytes);
-  float* U = (float*)((char*)ws + wp.v_bytes + wp.m_bytes);
+  float* U = u_ext ? u_ext : (float*)((char*)ws + wp.v_bytes + wp.m_bytes);   // caller-owned: survives the call (filter-transform cache)
   const int cout = yout->c;
   if (int e = pm_wino_input_xf((const float*)xin->ptr, xin->pitch, xin->c, wp.Kp, wp.g, V, st)) return e;
-  if (int e = pm_wino_filter_xf(w, w_cout, w_cin, wp.Kp, dgrad, wp.g.m, U, st)) return e;
+  if (!(u_ext && u_valid))
+    if (int e = pm_wino_filter_xf(w, w_cout, w_cin, wp.Kp, dgrad, wp.g.m, U, st)) return e;
   const pm_tensor xv = {V, 1, 1, (int32_t)wp.g.tiles, wp.Kp, wp.Kp};
   const pm_tensor yv = {Mo, 1, 1, (int32_t)wp.g.tiles, cout, cout};
   const pm_conv_params p1 = {1, 1, 1, 0, 1, 0};
@@ -1389,6 +1390,12 @@ extern "C" size_t pm_conv_winograd_v_bytes(const pm_tensor* x, const pm_tensor* 
   return (f.use && g.use && f.g.m == g.g.m) ? f.v_bytes : 0;
 }
 
+extern "C" size_t pm_conv_winograd_u_bytes(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p) {
+  if (!x || !y || !p) return 0;
+  const WinoPlan f = wino_plan(x, y->c, p);
+  return f.use ? f.u_bytes : 0;
+}
+
 // Can this forward call hand the BatchNorm statistics of its output out of its own epilogue? Only the unbatched direct GEMM with one K
 // split and a 16-byte-aligned output takes the staged epilogue; everything else (Winograd route, split-K, the 19-class heads) answers 0.
 static bool bn_partials_route(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p) {
@@ -1469,7 +1476,8 @@ extern "C" int pm_conv_fwd(const pm_tensor* x, const float* w, const pm_tensor* 
     if (wp.use) {
       PM_REQUIRE(ws && ws_bytes >= wino_ws(wp), PM_EWORKSPACE, "conv_fwd(winograd): workspace %zu < %zu", ws_bytes, wino_ws(wp));
       float* keep = (p->wino_v && (size_t)p->wino_v_bytes >= wp.v_bytes) ? (float*)p->wino_v : nullptr;
-      return wino_conv(x, w, y->c, x->c, false, y, wp, e1, ws, (hipStream_t)stream, keep);
+      float* uext = (p->wino_u && (size_t)p->wino_u_bytes >= wp.u_bytes) ? (float*)p->wino_u : nullptr;
+      return wino_conv(x, w, y->c, x->c, false, y, wp, e1, ws, (hipStream_t)stream, keep, uext, p->wino_u_valid != 0);
     }
   }
   if (p->prec == 2) {

@@ -56,6 +56,33 @@ KEEP_WINOGRAD_V = os.environ.get('PM_KEEP_V', '1') == '1'   # forward keeps the 
 BN_EPILOGUE = os.environ.get('PM_BN_EPILOGUE', '0') == '1'
 
 
+# Winograd-transformed filters U = G w G^T kept between calls: the eval-mode forward of step t and the training forward of step t + 1 read the
+# same weights. Keyed by the weight's storage address, shape and U size; an entry holds a reference to the weight tensor (so its address cannot be
+# handed to another tensor while the entry lives) and the tensor version its U was computed from -- every in-place update through torch bumps the
+# version, and optim.SGD bumps it for the fused update. Functional weights (train_memory_mldg's theta) are new tensors every step: they never hit
+# and are evicted in turn. PM_KEEP_U=0 disables the cache.
+KEEP_WINOGRAD_U = os.environ.get('PM_KEEP_U', '1') == '1'
+_U_CACHE = {}
+_U_CACHE_MAX = 96
+
+
+def _wino_u(lib, xd, yd, p, w_krsc):
+    nbu = lib.pm_conv_winograd_u_bytes(byref(xd), byref(yd), byref(p))
+    if not nbu:
+        return None
+    key = (w_krsc.data_ptr(), tuple(w_krsc.shape), nbu, w_krsc.device.index)
+    ent = _U_CACHE.pop(key, None)
+    if ent is None:
+        if len(_U_CACHE) >= _U_CACHE_MAX:
+            _U_CACHE.pop(next(iter(_U_CACHE)))             # oldest entry (dicts keep insertion order; hits are re-inserted)
+        ent = [w_krsc, -1, torch.empty(nbu // 4, dtype=torch.float32, device=w_krsc.device)]
+    valid = ent[1] == w_krsc._version
+    ent[1] = w_krsc._version
+    _U_CACHE[key] = ent
+    p.wino_u, p.wino_u_bytes, p.wino_u_valid = ent[2].data_ptr(), nbu, 1 if valid else 0
+    return ent[2]
+
+
 def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, residual=None, relu=False, out=None, keep_v=None, bn_partials=None):
     """keep_v: a list; if this convolution and its weight gradient both take the Winograd route, the transformed input V is written
     to a fresh tensor that is appended to the list (else None is appended) -- pass it to conv_bwd_weight(wino_v=...).
@@ -75,6 +102,8 @@ def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, res
         keep_v.append(v)
         if v is not None:
             p.wino_v, p.wino_v_bytes = v.data_ptr(), nbv
+    if KEEP_WINOGRAD_U and kh == 3 and CONV_PREC == 0:
+        _wino_u(lib, xd, yd, p, w_krsc)
     nb = lib.pm_conv_workspace(byref(xd), byref(yd), byref(p), 0)
     ws = workspace(nb, x.device) if nb else None
     part = None

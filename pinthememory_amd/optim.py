@@ -50,6 +50,8 @@ class SGD(torch.optim.SGD):
                 fused.append((p, g, buf))
             if fused:
                 K.sgd_momentum_multi(fused, float(group['lr']), float(group['momentum']), float(group['weight_decay']))
+                # the kernel writes through raw pointers: tell autograd (saved-tensor checks) and the Winograd filter cache (hip/kernels.py)
+                torch.autograd.graph.increment_version([t for p, _, buf in fused for t in (p, buf)])
             if rest:
                 self._torch_step(group, rest)
         return loss

@@ -325,6 +325,39 @@ def test_sliding_stitch(K, h, w, crop, overlap):
         K.sliding_stitch(nhwc(lg), [(0, 0, crop + 1, crop)] * len(tiles), h, w, False)
 
 
+def test_winograd_filter_cache(K):
+    """The transformed filter U is kept between forward calls on the same weight storage and recomputed when the tensor version moves:
+    torch's in-place ops bump it, the fused SGD bumps it explicitly (optim.SGD) -- a stale U would show as the old weights' output."""
+    from pinthememory_amd import optim
+    x = nhwc(rnd(2, 128, 24, 24, seed=1))
+    w = torch.nn.Parameter(rnd(128, 128, 3, 3, seed=2).mul(0.05).cuda().contiguous(memory_format=torch.channels_last))
+    wk = w.detach().permute(0, 2, 3, 1)                       # KRSC view of the parameter's own memory
+    assert wk.data_ptr() == w.data_ptr() and wk.is_contiguous()
+    ref = lambda: F.conv2d(nchw(x), w.detach().cpu(), padding=1)
+    K._U_CACHE.clear()
+    y1 = K.conv_fwd(x, wk, 1, 1, 1)
+    assert len(K._U_CACHE) == 1 and rel(nchw(y1), ref()) < 2e-5
+    ent = next(iter(K._U_CACHE.values()))
+    u_before = ent[2].clone()
+    y2 = K.conv_fwd(x, wk, 1, 1, 1)                           # hit: same bits, U untouched
+    assert torch.equal(y1, y2) and torch.equal(ent[2], u_before) and len(K._U_CACHE) == 1
+    with torch.no_grad():
+        w.mul_(0.5)                                           # torch in-place op: version bump -> recomputed
+    y3 = K.conv_fwd(x, wk, 1, 1, 1)
+    assert rel(nchw(y3), ref()) < 2e-5 and not torch.equal(ent[2], u_before)
+    w.grad = torch.ones_like(w)                               # one fused SGD step (raw-pointer update inside the library)
+    opt = optim.SGD([w], lr=0.1, momentum=0.9, weight_decay=0.0)
+    opt.step()
+    y4 = K.conv_fwd(x, wk, 1, 1, 1)
+    assert rel(nchw(y4), ref()) < 2e-5 and rel(y4, y3) > 1e-3
+    keep = K.KEEP_WINOGRAD_U
+    K.KEEP_WINOGRAD_U = False
+    try:
+        assert torch.equal(K.conv_fwd(x, wk, 1, 1, 1), y4)
+    finally:
+        K.KEEP_WINOGRAD_U = keep
+
+
 def test_layout_and_labels(K):
     x = rnd(2, 3, 37, 41, seed=1).cuda()
     y = K.nchw_to_nhwc(x, c_pad=4)

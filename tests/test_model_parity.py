@@ -673,3 +673,43 @@ def test_sibling_archs_eval_and_step_vs_oracle(env, arch):
     worst = max(((v.detach().cpu() - ref.state_dict()[k]).abs().max().item() / (ref.state_dict()[k].abs().max().item() + 1e-12), k)
                 for k, v in net.state_dict().items() if v.dtype.is_floating_point)
     assert worst[0] < 2e-4, worst
+
+
+def test_three_agg_steps_vs_oracle(env):
+    """Three consecutive agg steps on one batch: what a single step cannot show -- state carried from step to step (SGD momentum, BatchNorm running
+    moments, the committed memory, and the Winograd filter transforms the library keeps between calls, which must follow every weight update).
+    (1) Against the CPU oracle: two fp32 implementations of a train-mode BatchNorm network drift apart as the steps go (5e-4 on the third loss here),
+    so the bound is 5e-3 -- it catches lost state, not round-off. (2) Sharp: the same three steps with the filter cache off must give the same BITS
+    (every kernel is deterministic; a transform kept across a weight update would not)."""
+    synth, h, o_h = env['synth'], env['harness'], env['o_harness']
+    from pinthememory_amd.hip import kernels as K
+    x, y = synth.make_batch(2, 128, seed=31)
+
+    def run_hip(keep_u):
+        prev = K.KEEP_WINOGRAD_U
+        K.KEEP_WINOGRAD_U = keep_u
+        K._U_CACHE.clear()
+        try:
+            net = synth.load_det_weights(env['deepv3plus'].DeepR50V3PlusD(synth.model_args(), 19, CRIT, CRIT)).cuda()
+            net.dsn[3].p = 0.0
+            opt, _ = h.make_optimizer(net)
+            losses = [h.agg_train_step(net, opt, x.cuda(), y.cuda()) for _ in range(3)]
+            torch.cuda.synchronize()
+            return net, losses
+        finally:
+            K.KEEP_WINOGRAD_U = prev
+    net, g_all = run_hip(True)
+    assert len(K._U_CACHE) > 0                                  # the route and the cache were in use
+    net0, g0 = run_hip(False)
+    for a_, b_ in zip(g_all, g0):
+        assert all(torch.equal(a_[k], b_[k]) for k in a_)
+    assert torch.equal(net.memory.m_items, net0.memory.m_items)
+    assert all(torch.equal(v, net0.state_dict()[k]) for k, v in net.state_dict().items())
+    ref = synth.load_det_weights(env['o_deeplab'].DeepR50V3PlusD(synth.model_args(), 19, CRIT, CRIT))
+    ref.dsn[3].p = 0.0
+    o_opt, _ = o_h.make_optimizer(ref)
+    for step in range(3):
+        w_l = o_h.agg_train_step(ref, o_opt, x, y)
+        for k in w_l:
+            assert abs(float(g_all[step][k]) - float(w_l[k])) <= 5e-3 * max(1.0, abs(float(w_l[k]))), (step, k, float(g_all[step][k]), float(w_l[k]))
+    assert (net.memory.m_items.cpu() - ref.memory.m_items).abs().max().item() < 2e-3
