@@ -453,6 +453,190 @@ double run_glds(const Shape& s, const float* A, const float* B, float* C, int it
   return ms / iters * 1e3;
 }
 
+
+// ---- wave-specialised variant: 4 consumer waves (LDS fragment reads + MFMA + epilogue only) and 4 producer waves (global loads, LDS writes
+// only) per block, a ring of STAGES K-slabs in LDS, hand-off through two LDS counters per stage (full / empty, one ds_add per wave and use),
+// persistent blocks: the producers run ahead into the next tile while the consumers store the finished one. Every poll loop is bounded and
+// reports through *err instead of hanging the GPU.
+__device__ __forceinline__ bool ws_wait(volatile unsigned* flag, unsigned target, int* err) {
+  for (int spin = 0; spin < (1 << 22); ++spin) {
+    if ((int)(*flag - target) >= 0) return true;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  *err = 1;
+  return false;
+}
+template <int BM, int BN, int STAGES, int EPS, int MINB>
+__global__ __launch_bounds__(512, MINB) void gemm_ws(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K, long a_bs,
+                                                  long b_bs, long c_bs, int tiles_m, int tiles_n, int batch, int* err) {
+  constexpr int BKK = 32, LDK = BKK + 4, KG = BKK / 4;
+  constexpr int RP = 256 / KG;                       // producer threads: rows per pass
+  constexpr int A_N = BM / RP, B_N = BN / RP;
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int A_FLOATS = BM * LDK, B_FLOATS = BN * LDK, STAGE = A_FLOATS + B_FLOATS;
+  extern __shared__ __align__(16) float smem[];
+  unsigned* flags = reinterpret_cast<unsigned*>(smem + STAGES * STAGE);      // full[STAGES], empty[STAGES]
+  float* stage_c = smem + STAGES * STAGE + 16;                                // EPS: per consumer wave 32 x (BN/2 + 4) floats (flags: 16 words)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t < 2 * STAGES) flags[t] = 0;
+  __syncthreads();
+  volatile unsigned* full = flags;
+  volatile unsigned* empty = flags + STAGES;
+  const int ntile = tiles_m * tiles_n, total = ntile * batch;
+  const int nk = K / BKK;
+  unsigned it = 0;                                   // K-slabs handled so far by this block (ring position), same sequence in every wave
+  if (wave >= 4) {
+    // ---------------- producers ----------------
+    const int pt = t - 256, g = pt % KG, r = pt / KG;
+    float4 cur[A_N + B_N], nxt[A_N + B_N];
+    auto issue = [&](float4 (&dst)[A_N + B_N], int w, int kt) {
+      const int by = w / ntile, lid = w - by * ntile;
+      const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
+      const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + by * a_bs), 0, M * K * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B + by * b_bs), 0, N * K * 4, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < A_N; ++i) {
+        const int m = m0 + r + RP * i;
+        dst[i] = bload(rA, m < M ? (m * K + kt * BKK + g * 4) * 4 : 0x7fffffff);
+      }
+#pragma unroll
+      for (int i = 0; i < B_N; ++i) {
+        const int n = n0 + r + RP * i;
+        dst[A_N + i] = bload(rB, n < N ? (n * K + kt * BKK + g * 4) * 4 : 0x7fffffff);
+      }
+    };
+    int w = blockIdx.x, kt = 0;
+    if (w < total) issue(cur, w, 0);
+    while (w < total) {
+      // the slab after this one (possibly the first of the next tile) is requested before this one is parked
+      int w2 = w, kt2 = kt + 1;
+      if (kt2 == nk) kt2 = 0, w2 = w + gridDim.x;
+      if (w2 < total) issue(nxt, w2, kt2);
+      const int st = it % STAGES;
+      const unsigned use = it / STAGES;
+      if (!ws_wait(&empty[st], 4 * use, err)) return;
+      float* As = smem + st * STAGE;
+      float* Bs = As + A_FLOATS;
+#pragma unroll
+      for (int i = 0; i < A_N; ++i) *reinterpret_cast<float4*>(As + (r + RP * i) * LDK + g * 4) = cur[i];
+#pragma unroll
+      for (int i = 0; i < B_N; ++i) *reinterpret_cast<float4*>(Bs + (r + RP * i) * LDK + g * 4) = cur[A_N + i];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) atomicAdd(const_cast<unsigned*>(&full[st]), 1u);
+#pragma unroll
+      for (int i = 0; i < A_N + B_N; ++i) cur[i] = nxt[i];
+      ++it, w = w2, kt = kt2;
+    }
+    return;
+  }
+  // ---------------- consumers ----------------
+  const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+  unsigned seen = 0;
+  for (int w = blockIdx.x; w < total; w += gridDim.x) {
+    const int by = w / ntile, lid = w - by * ntile;
+    const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    for (int kt = 0; kt < nk; ++kt, ++it) {
+      const int st = it % STAGES;
+      const unsigned use = it / STAGES;
+      if ((int)(seen - 4 * (use + 1)) < 0)            // `seen`: this stage's counter as read under the previous slab's MFMAs
+        if (!ws_wait(&full[st], 4 * (use + 1), err)) return;
+      seen = full[(it + 1) % STAGES];                 // next stage's counter, in flight during this slab
+      const float* As = smem + st * STAGE;
+      const float* Bs = As + A_FLOATS;
+#pragma unroll
+      for (int kg = 0; kg < BKK / 8; ++kg) {
+        const int kk = kg * 8 + half * 4;
+        float4 fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const float4*>(As + (wm * (BM / 2) + i * 32 + l31) * LDK + kk);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) fb[i] = *reinterpret_cast<const float4*>(Bs + (wn * (BN / 2) + i * 32 + l31) * LDK + kk);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int n = 0; n < TN; ++n) {
+              const float a = j == 0 ? fa[i].x : (j == 1 ? fa[i].y : (j == 2 ? fa[i].z : fa[i].w));
+              const float b = j == 0 ? fb[n].x : (j == 1 ? fb[n].y : (j == 2 ? fb[n].z : fb[n].w));
+              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][n], 0, 0, 0);
+            }
+      }
+      // the fragment reads of this slab have returned (their values fed the MFMAs above): hand the stage back
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) atomicAdd(const_cast<unsigned*>(&empty[st]), 1u);
+    }
+    float* Cb = C + by * c_bs;
+    if (EPS) {
+      constexpr int WC = BN / 2, LDC = WC + 4, LPR = WC / 4, RPI = 64 / LPR;
+      float* Ws = stage_c + wave * 32 * LDC;          // wave-private staging rows (outside the ring)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) Ws[((q & 3) + 8 * (q >> 2) + 4 * half) * LDC + n * 32 + l31] = acc[i][n][q];
+#pragma unroll
+        for (int r0 = 0; r0 < 32; r0 += RPI) {
+          const int rr = r0 + lane / LPR, cc = (lane % LPR) * 4;
+          const float4 v = *reinterpret_cast<const float4*>(Ws + rr * LDC + cc);
+          const int row = m0 + wm * (BM / 2) + i * 32 + rr, col = n0 + wn * WC + cc;
+          if (row < M && col < N) *reinterpret_cast<float4*>(Cb + (long)row * N + col) = v;
+        }
+      }
+    } else {
+      const int rbase = m0 + wm * (BM / 2) + 4 * half, cbase = n0 + wn * (BN / 2) + l31;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+          const int col = cbase + n * 32;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int row = rbase + i * 32 + (q & 3) + 8 * (q >> 2);
+            if (row < M && col < N) Cb[(long)row * N + col] = acc[i][n][q];
+          }
+        }
+    }
+  }
+}
+template <int BM, int BN, int STAGES, int EPS, int MINB = 1>
+double run_ws(const Shape& s, const float* A, const float* B, float* C, int per_cu, int iters = 20) {
+  const int tiles_m = (s.M + BM - 1) / BM, tiles_n = (s.N + BN - 1) / BN;
+  const int total = tiles_m * tiles_n * s.batch;
+  static_assert(2 * STAGES <= 16, "flag words");
+  const size_t smem = ((size_t)STAGES * (BM + BN) * 36 + 16 + (EPS ? 4 * 32 * (BN / 2 + 4) : 0)) * sizeof(float);
+  auto kern = gemm_ws<BM, BN, STAGES, EPS, MINB>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  static int* err = nullptr;
+  if (!err) { CK(hipMalloc(&err, 4)); }
+  CK(hipMemset(err, 0, 4));
+  const int grid = std::min(total, 256 * per_cu);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, 0, A, B, C, s.M, s.N, s.K, (long)s.M * s.K, (long)s.N * s.K, (long)s.M * s.N, tiles_m, tiles_n, s.batch, err);
+  CK(hipDeviceSynchronize());
+  int herr = 0;
+  CK(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));
+  if (herr) { printf("   !! gemm_ws: a hand-off wait ran out (protocol bug), skipping\n"); return 1e9; }
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < iters; ++i)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, 0, A, B, C, s.M, s.N, s.K, (long)s.M * s.K, (long)s.N * s.K, (long)s.M * s.N, tiles_m, tiles_n, s.batch, err);
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  CK(hipGetLastError());
+  return ms / iters * 1e3;
+}
+
 static void fill(float* d, size_t n, unsigned seed) {
   std::vector<float> h(n);
   unsigned x = seed * 2654435761u + 12345u;
@@ -509,6 +693,21 @@ int main(int argc, char** argv) {
       rd("64x64 staged, core only", run<64, 64, 32, 1, 0, 3, 2, 2>(d, A, B, C, 0, 5));
       rd("64x64 staged, no MFMA", run<64, 64, 32, 1, 0, 4, 2, 2>(d, A, B, C, 0, 5));
       rd("128x128 staged stores", run<128, 128, 32, 1, 0, 0, 2, 2>(d, A, B, C, 0, 5));
+      continue;
+    }
+    if (argc > 1 && std::string(argv[1]) == "ws") {
+      rep("128x128 nst1 element stores (baseline)", run<128, 128, 32, 1, 0, 0, 2>(s, A, B, C, 0));
+      rep("128x128 nst1 staged stores (baseline)", run<128, 128, 32, 1, 0, 0, 2, 2>(s, A, B, C, 0));
+      rep("64x64 nst1 staged stores (baseline)", run<64, 64, 32, 1, 0, 0, 2, 2>(s, A, B, C, 0));
+      CK(hipMemset(C, 0, (size_t)s.M * s.N * s.batch * 4));
+      rep("wave-specialised 128x128, 3 stages, 1 block/CU", run_ws<128, 128, 3, 0>(s, A, B, C, 1));
+      printf("   max |err| vs fp64 dot: %.3g\n", check(s, A, B, C));
+      rep("wave-specialised 128x128, 3 stages, staged stores", run_ws<128, 128, 3, 1>(s, A, B, C, 1));
+      printf("   max |err| vs fp64 dot: %.3g\n", check(s, A, B, C));
+      rep("wave-specialised 128x128, 2 stages, staged, 2 blocks/CU", run_ws<128, 128, 2, 1, 2>(s, A, B, C, 2));
+      rep("wave-specialised 128x128, 2 stages, element, 2 blocks/CU", run_ws<128, 128, 2, 0, 2>(s, A, B, C, 2));
+      rep("wave-specialised 128x128, 4 stages, element, 1 block/CU", run_ws<128, 128, 4, 0, 1>(s, A, B, C, 1));
+      rep("wave-specialised 64x64, 3 stages, staged, 2 blocks/CU", run_ws<64, 64, 3, 1, 2>(s, A, B, C, 2));
       continue;
     }
     if (argc > 1 && std::string(argv[1]) == "rawbar") {
