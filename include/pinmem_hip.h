@@ -37,12 +37,13 @@ typedef struct pm_conv_params { /* nn.Conv2d geometry (square kernels/strides as
                                    pm_conv_fwd writes it there instead of its workspace; pm_conv_bwd_weight then reads it instead of
                                    transforming x again. Size from pm_conv_winograd_v_bytes (0 = the layer does not take the route). */
   int64_t wino_v_bytes;
-  void* wino_u;                 /* optional caller-owned buffer for the Winograd-transformed FILTER of pm_conv_fwd (NULL: none), size from
-                                   pm_conv_winograd_u_bytes. wino_u_valid == 0: the call writes U = G w G^T there instead of its workspace;
-                                   != 0: the call trusts its content and skips the transform -- for a caller that knows the weights are
-                                   unchanged since the call that filled it (eval-mode forward of step t and training forward of step t + 1). */
-  int64_t wino_u_bytes;
-  int32_t wino_u_valid;
+  void* wxf;                    /* optional caller-owned buffer for the TRANSFORMED FILTER pm_conv_fwd derives from w (NULL: none), size from
+                                   pm_conv_wxf_bytes: the Winograd U = G w G^T of a layer on that route, or the bf16 copy of the weights with
+                                   prec == 2. wxf_valid == 0: the call writes it there instead of its workspace; != 0: the call trusts the
+                                   content and skips the transform -- for a caller that knows the weights are unchanged since the call that
+                                   filled it (eval-mode forward of step t and training forward of step t + 1). */
+  int64_t wxf_bytes;
+  int32_t wxf_valid;
 } pm_conv_params;
 
 typedef struct pm_conv_epilogue { /* optional fused epilogue of pm_conv_fwd; all pointers may be NULL */
@@ -67,7 +68,7 @@ int pm_version(void);
  * deepv2.py:44-51,138-151; memory.py:75,104.  y: [n,ho,wo,cout], x: [n,h,w,cin], cin % 4 == 0. */
 size_t pm_conv_workspace(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p, int which /*0 fwd,1 dgrad,2 wgrad*/);
 size_t pm_conv_winograd_v_bytes(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p);
-size_t pm_conv_winograd_u_bytes(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p);   /* 0: pm_conv_fwd does not take the route */
+size_t pm_conv_wxf_bytes(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p);   /* 0: pm_conv_fwd keeps no transformed filter for this call */
 /* bytes of pm_conv_epilogue.bn_partials for this forward call, 0 if the call cannot emit them (then run pm_bn_stats* on y as before) */
 size_t pm_conv_bn_partials_bytes(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p);
 int pm_conv_fwd(const pm_tensor* x, const float* w_krsc, const pm_tensor* y, const pm_conv_params* p,

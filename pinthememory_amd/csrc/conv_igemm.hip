@@ -1230,13 +1230,14 @@ inline size_t bf16_ws(const Bf16Plan& b) { return b.xb_bytes + b.wb_bytes + pm_a
 // transposed filter; pe: geometry of the convolution actually run (the data gradient of a stride-1 convolution is a stride-1
 // convolution of dy with pad' = dil (k - 1) - pad).
 int conv_bf16(const pm_tensor* xin, const float* w, int w_cout, int w_cin, bool rotate, const pm_tensor* yout, const pm_conv_params* pe, const Bf16Plan& b,
-              const pm_conv_epilogue& e0, void* ws, hipStream_t st) {
+              const pm_conv_epilogue& e0, void* ws, hipStream_t st, char* wb_ext = nullptr, bool wb_valid = false) {
   char* xb = (char*)ws;
-  char* wb = xb + b.xb_bytes;
-  float* slab = (float*)(wb + b.wb_bytes);
+  char* wb = wb_ext ? wb_ext : xb + b.xb_bytes;          // caller-owned: survives the call (weight-cast cache)
+  float* slab = (float*)(xb + b.xb_bytes + b.wb_bytes);
   const int T = pe->kh * pe->kw;
   if (int e = pm_bf16_cast_rows((const float*)xin->ptr, xin->pitch, xin->c, b.Cp, pm_pixels(xin), xb, st)) return e;
-  if (int e = pm_bf16_cast_weights(w, w_cout, T, w_cin, b.Cp, rotate, wb, st)) return e;
+  if (!(wb_ext && wb_valid))
+    if (int e = pm_bf16_cast_weights(w, w_cout, T, w_cin, b.Cp, rotate, wb, st)) return e;
   const pm_tensor xv = {xb, xin->n, xin->h, xin->w, b.Cp / 2, b.Cp / 2};     // fp32-typed view: one float = two bf16 channels
   ConvK k;
   fill_geom(k, &xv, yout, pe);
@@ -1390,10 +1391,15 @@ extern "C" size_t pm_conv_winograd_v_bytes(const pm_tensor* x, const pm_tensor* 
   return (f.use && g.use && f.g.m == g.g.m) ? f.v_bytes : 0;
 }
 
-extern "C" size_t pm_conv_winograd_u_bytes(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p) {
+extern "C" size_t pm_conv_wxf_bytes(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p) {
   if (!x || !y || !p) return 0;
   const WinoPlan f = wino_plan(x, y->c, p);
-  return f.use ? f.u_bytes : 0;
+  if (f.use) return f.u_bytes;
+  if (p->prec == 2) {
+    const Bf16Plan b = bf16_plan(x, y, p);
+    if (b.use) return b.wb_bytes;
+  }
+  return 0;
 }
 
 // Can this forward call hand the BatchNorm statistics of its output out of its own epilogue? Only the unbatched direct GEMM with one K
@@ -1476,8 +1482,8 @@ extern "C" int pm_conv_fwd(const pm_tensor* x, const float* w, const pm_tensor* 
     if (wp.use) {
       PM_REQUIRE(ws && ws_bytes >= wino_ws(wp), PM_EWORKSPACE, "conv_fwd(winograd): workspace %zu < %zu", ws_bytes, wino_ws(wp));
       float* keep = (p->wino_v && (size_t)p->wino_v_bytes >= wp.v_bytes) ? (float*)p->wino_v : nullptr;
-      float* uext = (p->wino_u && (size_t)p->wino_u_bytes >= wp.u_bytes) ? (float*)p->wino_u : nullptr;
-      return wino_conv(x, w, y->c, x->c, false, y, wp, e1, ws, (hipStream_t)stream, keep, uext, p->wino_u_valid != 0);
+      float* uext = (p->wxf && (size_t)p->wxf_bytes >= wp.u_bytes) ? (float*)p->wxf : nullptr;
+      return wino_conv(x, w, y->c, x->c, false, y, wp, e1, ws, (hipStream_t)stream, keep, uext, p->wxf_valid != 0);
     }
   }
   if (p->prec == 2) {
@@ -1487,7 +1493,8 @@ extern "C" int pm_conv_fwd(const pm_tensor* x, const float* w, const pm_tensor* 
       if (ep) e2 = *ep;
       PM_REQUIRE((e2.scale == nullptr) == (e2.shift == nullptr), PM_EINVAL, "conv_fwd: scale and shift go together");
       PM_REQUIRE(ws && ws_bytes >= bf16_ws(b), PM_EWORKSPACE, "conv_fwd(bf16): workspace %zu < %zu", ws_bytes, bf16_ws(b));
-      return conv_bf16(x, w, y->c, x->c, false, y, p, b, e2, ws, (hipStream_t)stream);
+      char* wext = (p->wxf && (size_t)p->wxf_bytes >= b.wb_bytes) ? (char*)p->wxf : nullptr;
+      return conv_bf16(x, w, y->c, x->c, false, y, p, b, e2, ws, (hipStream_t)stream, wext, p->wxf_valid != 0);
     }
   }
   long M, Nn, K;

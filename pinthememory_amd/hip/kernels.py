@@ -56,21 +56,21 @@ KEEP_WINOGRAD_V = os.environ.get('PM_KEEP_V', '1') == '1'   # forward keeps the 
 BN_EPILOGUE = os.environ.get('PM_BN_EPILOGUE', '0') == '1'
 
 
-# Winograd-transformed filters U = G w G^T kept between calls: the eval-mode forward of step t and the training forward of step t + 1 read the
+# Transformed filters -- the Winograd U = G w G^T, or the bf16 copy of the weights in the bf16 tier -- kept between calls: the eval-mode forward of step t and the training forward of step t + 1 read the
 # same weights. Keyed by the weight's storage address, shape and U size; an entry holds a reference to the weight tensor (so its address cannot be
 # handed to another tensor while the entry lives) and the tensor version its U was computed from -- every in-place update through torch bumps the
 # version, and optim.SGD bumps it for the fused update. Functional weights (train_memory_mldg's theta) are new tensors every step: they never hit
 # and are evicted in turn. PM_KEEP_U=0 disables the cache.
 KEEP_WINOGRAD_U = os.environ.get('PM_KEEP_U', '1') == '1'
 _U_CACHE = {}
-_U_CACHE_MAX = 96
+_U_CACHE_MAX = 256
 
 
 def _wino_u(lib, xd, yd, p, w_krsc):
-    nbu = lib.pm_conv_winograd_u_bytes(byref(xd), byref(yd), byref(p))
+    nbu = lib.pm_conv_wxf_bytes(byref(xd), byref(yd), byref(p))
     if not nbu:
         return None
-    key = (w_krsc.data_ptr(), tuple(w_krsc.shape), nbu, w_krsc.device.index)
+    key = (w_krsc.data_ptr(), tuple(w_krsc.shape), nbu, w_krsc.device.index, p.prec)
     ent = _U_CACHE.pop(key, None)
     if ent is None:
         if len(_U_CACHE) >= _U_CACHE_MAX:
@@ -79,7 +79,7 @@ def _wino_u(lib, xd, yd, p, w_krsc):
     valid = ent[1] == w_krsc._version
     ent[1] = w_krsc._version
     _U_CACHE[key] = ent
-    p.wino_u, p.wino_u_bytes, p.wino_u_valid = ent[2].data_ptr(), nbu, 1 if valid else 0
+    p.wxf, p.wxf_bytes, p.wxf_valid = ent[2].data_ptr(), nbu, 1 if valid else 0
     return ent[2]
 
 
@@ -102,7 +102,7 @@ def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, res
         keep_v.append(v)
         if v is not None:
             p.wino_v, p.wino_v_bytes = v.data_ptr(), nbv
-    if KEEP_WINOGRAD_U and kh == 3 and CONV_PREC == 0:
+    if KEEP_WINOGRAD_U and ((kh == 3 and CONV_PREC == 0) or CONV_PREC == 2):
         _wino_u(lib, xd, yd, p, w_krsc)
     nb = lib.pm_conv_workspace(byref(xd), byref(yd), byref(p), 0)
     ws = workspace(nb, x.device) if nb else None

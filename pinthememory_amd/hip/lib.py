@@ -21,7 +21,7 @@ class PmSgdEntry(ctypes.Structure):
 class PmConvParams(ctypes.Structure):
     _fields_ = [('kh', c_int32), ('kw', c_int32), ('stride', c_int32), ('pad', c_int32), ('dil', c_int32), ('prec', c_int32),
                 ('wino_v', c_void_p), ('wino_v_bytes', c_int64),
-                ('wino_u', c_void_p), ('wino_u_bytes', c_int64), ('wino_u_valid', c_int32)]
+                ('wxf', c_void_p), ('wxf_bytes', c_int64), ('wxf_valid', c_int32)]
 
 
 class PmConvEpilogue(ctypes.Structure):
@@ -41,7 +41,7 @@ SIGNATURES = {
     'pm_last_error': (c_char_p, []),
     'pm_version': (c_int, []),
     'pm_conv_winograd_v_bytes': (_sz, [_T, _T, _P]),
-    'pm_conv_winograd_u_bytes': (_sz, [_T, _T, _P]),
+    'pm_conv_wxf_bytes': (_sz, [_T, _T, _P]),
     'pm_conv_workspace': (_sz, [_T, _T, _P, _i]),
     'pm_conv_fwd': (_i, [_T, _vp, _T, _P, _E, _vp, _sz, _vp]),
     'pm_conv_bwd_data': (_i, [_T, _vp, _T, _P, _T, _vp, _sz, _vp]),
