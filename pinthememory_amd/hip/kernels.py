@@ -64,6 +64,7 @@ BN_EPILOGUE = os.environ.get('PM_BN_EPILOGUE', '0') == '1'
 KEEP_WINOGRAD_U = os.environ.get('PM_KEEP_U', '1') == '1'
 _U_CACHE = {}
 _U_CACHE_MAX = 256
+_U_CACHE_BYTES = int(os.environ.get('PM_KEEP_U_MB', '2048')) << 20     # one ResNet-50 DeepLabV3+ keeps 0.43 GB, a ResNet-101 DeepLabV2 0.65 GB
 
 
 def _wino_u(lib, xd, yd, p, w_krsc):
@@ -73,8 +74,9 @@ def _wino_u(lib, xd, yd, p, w_krsc):
     key = (w_krsc.data_ptr(), tuple(w_krsc.shape), nbu, w_krsc.device.index, p.prec)
     ent = _U_CACHE.pop(key, None)
     if ent is None:
-        if len(_U_CACHE) >= _U_CACHE_MAX:
-            _U_CACHE.pop(next(iter(_U_CACHE)))             # oldest entry (dicts keep insertion order; hits are re-inserted)
+        # oldest entries go first (dicts keep insertion order; hits are re-inserted): models that are gone release their buffers here
+        while _U_CACHE and (len(_U_CACHE) >= _U_CACHE_MAX or sum(e[2].numel() * 4 for e in _U_CACHE.values()) + nbu > _U_CACHE_BYTES):
+            _U_CACHE.pop(next(iter(_U_CACHE)))
         ent = [w_krsc, -1, torch.empty(nbu // 4, dtype=torch.float32, device=w_krsc.device)]
     valid = ent[1] == w_krsc._version
     ent[1] = w_krsc._version
