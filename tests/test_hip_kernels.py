@@ -446,6 +446,27 @@ def test_memory_read(K):
     assert rel(K.mem_colsoftmax(score, noise.cuda()), F.softmax(s.detach() + noise, 0)) < 2e-6
 
 
+def test_memory_read_more_rows_than_resident_tiles(K):
+    """> 98 304 rows: the 32-row tiles outnumber the launched blocks (3072), so every block walks several tiles (grid-stride path of the
+    MFMA read kernels, with a ragged last tile); forward and the dx-only backward against torch."""
+    n, h, w, d, m = 1, 317, 311, 256, 19                      # 98 587 rows = 3080 tiles + 27 rows
+    x = torch.relu(rnd(n, d, h, w, seed=11))
+    mem = F.normalize(rnd(m, d, seed=12), dim=1)
+    xr = x.clone().requires_grad_(True)
+    q = F.normalize(xr, dim=1).permute(0, 2, 3, 1).contiguous()
+    s = torch.matmul(q, mem.t()).view(-1, m)
+    pm = F.softmax(s, 1)
+    qr_ref = torch.cat((q.view(-1, d), torch.matmul(pm, mem)), 1)
+    dqr, dsx = rnd(n * h * w, 2 * d, seed=13), rnd(n * h * w, m, seed=14) * 0.1
+    ((qr_ref * dqr).sum() + (s * dsx).sum()).backward()
+    xg, memg = nhwc(x), mem.cuda()
+    qr, score, pmem = K.mem_read_fwd(xg, memg)
+    assert rel(qr.view(-1, 2 * d), qr_ref.detach()) < 2e-6 and rel(score, s.detach()) < 2e-6 and rel(pmem, pm.detach()) < 2e-6
+    dx, _ = K.mem_read_bwd(xg, memg, pmem, dqr.view(n, h, w, 2 * d).cuda(), dsx.cuda())
+    live = (x.abs().sum(1, keepdim=True) > 0).expand_as(x)   # rows that are all zero after the ReLU take the eps branch (torch: different sub-gradient)
+    assert rel(nchw(dx)[live], xr.grad[live]) < 2e-5
+
+
 def test_memory_write(K):
     n, h, w, d, m, H, W = 2, 6, 5, 256, 19, 48, 40
     z = torch.relu(rnd(n, d, h, w, seed=1))
