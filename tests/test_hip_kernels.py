@@ -159,11 +159,12 @@ def test_conv_epilogue_bn_statistics(K, case):
     b = rnd(cout, seed=3)
     xg, wg = nhwc(x), wt.permute(0, 2, 3, 1).contiguous().cuda()
     ps = []
-    K.BN_EPILOGUE = True                 # opt-in route (default off: measured neutral on the step)
+    prev = K.BN_EPILOGUE
+    K.BN_EPILOGUE = True                 # opt-in route (PM_BN_EPILOGUE=1): -0.2 ms/step in the same-box A/B, kept off for the gradient gates
     try:
         y = K.conv_fwd(xg, wg, s, p, d, bias=b.cuda(), bn_partials=ps)
     finally:
-        K.BN_EPILOGUE = False
+        K.BN_EPILOGUE = prev
     assert ps[0] is not None, 'this shape must take the epilogue-statistics route'
     pixels = y.shape[0] * y.shape[1] * y.shape[2]
     rm1, rv1 = torch.zeros(cout, device='cuda'), torch.ones(cout, device='cuda')
@@ -184,9 +185,11 @@ def test_conv_epilogue_bn_statistics(K, case):
     try:
         K.conv_fwd(nhwc(rnd(1, 128, 16, 16, seed=5)), rnd(128, 3, 3, 128, seed=6).cuda() * 0.05, 1, 1, 1, bn_partials=ps2)
         K.conv_fwd(nhwc(rnd(1, 64, 8, 8, seed=5)), rnd(19, 1, 1, 64, seed=6).cuda() * 0.05, 1, 0, 1, bn_partials=ps2)
-    finally:
         K.BN_EPILOGUE = False
-    assert ps2 == [None, None]
+        K.conv_fwd(xg, wg, s, p, d, bias=b.cuda(), bn_partials=ps2)          # switched off: the caller falls back to the statistics pass
+    finally:
+        K.BN_EPILOGUE = prev
+    assert ps2 == [None, None, None]
 
 
 def test_conv_epilogue_and_slices(K):

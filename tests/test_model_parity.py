@@ -229,6 +229,8 @@ def test_mldg_train_step_vs_oracle(env):
     for k, t in truth['losses'].items():
         assert abs(hip['losses'][k].item() - o32['losses'][k].item()) < 5e-4 * max(1, abs(t.item())), k
         assert abs(hip['losses'][k].item() - t.item()) <= 3 * abs(o32['losses'][k].item() - t.item()) + 1e-4 * max(1, abs(t.item())), k
+    st = _grad_stats(hip, truth, 'grads')
+    assert st[0][0] < GRAD_TOL_MAX and st[len(st) // 2][0] < GRAD_TOL_MEDIAN, st[:6]          # the agg step's fixed bounds
     bad = _as_good_as_fp32(hip, o32, truth, 'grads', floor=1e-4)
     assert not bad, bad[:8]
     # gradient that reaches the write path ONLY through the written memory read at meta-test time (plus the inner step's own)
