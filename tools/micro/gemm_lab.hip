@@ -695,6 +695,19 @@ int main(int argc, char** argv) {
       rd("128x128 staged stores", run<128, 128, 32, 1, 0, 0, 2, 2>(d, A, B, C, 0, 5));
       continue;
     }
+    if (argc > 1 && std::string(argv[1]) == "wide") {      // 256-wide block tiles: 4 waves of 128x64 / 64x128 / 128x128 register tiles
+      rep("128x128 staged", run<128, 128, 32, 1, 0, 0, 2, 2>(s, A, B, C, 0));
+      rep("128x128 element", run<128, 128, 32, 1, 0, 0, 2>(s, A, B, C, 0));
+      rep("256x128 staged", run<256, 128, 32, 1, 0, 0, 1, 2>(s, A, B, C, 0));
+      printf("   max |err| vs fp64 dot: %.3g\n", check(s, A, B, C));
+      rep("256x128 element", run<256, 128, 32, 1, 0, 0, 1>(s, A, B, C, 0));
+      rep("128x256 staged", run<128, 256, 32, 1, 0, 0, 1, 2>(s, A, B, C, 0));
+      rep("128x256 element", run<128, 256, 32, 1, 0, 0, 1>(s, A, B, C, 0));
+      rep("256x256 element", run<256, 256, 32, 1, 0, 0, 1>(s, A, B, C, 0));
+      rep("256x128 two LDS stages, element", run<256, 128, 32, 2, 0, 0, 1>(s, A, B, C, 0));
+      rep("256x128 core only (no loads, no stores)", run<256, 128, 32, 1, 0, 3, 1>(s, A, B, C, 0));
+      continue;
+    }
     if (argc > 1 && std::string(argv[1]) == "ws") {
       rep("128x128 nst1 element stores (baseline)", run<128, 128, 32, 1, 0, 0, 2>(s, A, B, C, 0));
       rep("128x128 nst1 staged stores (baseline)", run<128, 128, 32, 1, 0, 0, 2, 2>(s, A, B, C, 0));
