@@ -706,6 +706,11 @@ int main(int argc, char** argv) {
       rep("256x256 element", run<256, 256, 32, 1, 0, 0, 1>(s, A, B, C, 0));
       rep("256x128 two LDS stages, element", run<256, 128, 32, 2, 0, 0, 1>(s, A, B, C, 0));
       rep("256x128 core only (no loads, no stores)", run<256, 128, 32, 1, 0, 3, 1>(s, A, B, C, 0));
+      rep("256x64 staged (the vendor's tile for the K = 2048 GEMM)", run<256, 64, 32, 1, 0, 0, 2, 2>(s, A, B, C, 0));
+      rep("256x64 element", run<256, 64, 32, 1, 0, 0, 2>(s, A, B, C, 0));
+      rep("64x64 staged", run<64, 64, 32, 1, 0, 0, 2, 2>(s, A, B, C, 0));
+      rep("128x64 staged", run<128, 64, 32, 1, 0, 0, 2, 2>(s, A, B, C, 0));
+      rep("64x64 BK = 64 staged", run<64, 64, 64, 1, 0, 0, 2, 2>(s, A, B, C, 0));
       continue;
     }
     if (argc > 1 && std::string(argv[1]) == "ws") {
