@@ -17,6 +17,7 @@ def make_optimizer(net, lr=0.01, momentum=0.9, poly_exp=9):
     """optimizer.py:11-32: SGD over all named parameters, weight decay hard-coded 5e-4, lr * exp(-poly_exp*it/120000).
     The optimizer is torch.optim.SGD (same state_dict) whose step() is one multi-tensor launch of the HIP library (optim.py)."""
     from .optim import SGD
+    K.keep_transformed_filters(True)         # optim.SGD bumps the tensor versions the filter cache is keyed by (hip/kernels.py)
     opt = SGD([p for _, p in net.named_parameters()], lr=lr, weight_decay=5e-4, momentum=momentum, nesterov=False)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda it: math.exp(-1 * poly_exp * it / 120000))
     return opt, sched

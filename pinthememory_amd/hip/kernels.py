@@ -60,12 +60,24 @@ KEEP_WINOGRAD_V = os.environ.get('PM_KEEP_V', '1') == '1'   # forward keeps the 
 BN_EPILOGUE = os.environ.get('PM_BN_EPILOGUE', '0') == '1'
 
 
-# Transformed filters -- the Winograd U = G w G^T, or the bf16 copy of the weights in the bf16 tier -- kept between calls: the eval-mode forward of step t and the training forward of step t + 1 read the
-# same weights. Keyed by the weight's storage address, shape and U size; an entry holds a reference to the weight tensor (so its address cannot be
-# handed to another tensor while the entry lives) and the tensor version its U was computed from -- every in-place update through torch bumps the
-# version, and optim.SGD bumps it for the fused update. Functional weights (train_memory_mldg's theta) are new tensors every step: they never hit
-# and are evicted in turn. PM_KEEP_U=0 disables the cache.
-KEEP_WINOGRAD_U = os.environ.get('PM_KEEP_U', '1') == '1'
+# Transformed filters -- the Winograd U = G w G^T, or the bf16 copy of the weights in the bf16 tier -- kept between calls: the eval-mode forward of
+# step t and the training forward of step t + 1 read the same weights. Keyed by the weight's storage address, shape and size of the transformed
+# filter; an entry holds a reference to the weight tensor (so its address cannot be handed to another tensor while the entry lives) and the tensor
+# VERSION its content was computed from: every in-place update through torch's ops bumps the version, and optim.SGD bumps it for its fused update.
+# What does NOT bump it is a write through `w.data` (legacy optimizers, manual EMA) or through raw pointers -- a stale filter would be silently wrong,
+# so the cache is OFF unless the caller vouches for its optimizer: harness.make_optimizer() (optim.SGD) switches it on, PM_KEEP_U=1 / 0 forces it.
+# Functional weights (train_memory_mldg's theta) are new tensors every step: they never hit and are evicted in turn.
+KEEP_WINOGRAD_U = os.environ.get('PM_KEEP_U', '0') == '1'
+
+
+def keep_transformed_filters(on=True):
+    """Called by code that updates weights only through version-bumping ops (harness.make_optimizer); PM_KEEP_U in the environment wins."""
+    global KEEP_WINOGRAD_U
+    KEEP_WINOGRAD_U = (os.environ['PM_KEEP_U'] == '1') if 'PM_KEEP_U' in os.environ else bool(on)
+    if not KEEP_WINOGRAD_U:
+        _U_CACHE.clear()
+
+
 _U_CACHE = {}
 _U_CACHE_MAX = 256
 _U_CACHE_BYTES = int(os.environ.get('PM_KEEP_U_MB', '2048')) << 20     # one ResNet-50 DeepLabV3+ keeps 0.43 GB, a ResNet-101 DeepLabV2 0.65 GB

@@ -338,6 +338,8 @@ def test_winograd_filter_cache(K):
     assert wk.data_ptr() == w.data_ptr() and wk.is_contiguous()
     ref = lambda: F.conv2d(nchw(x), w.detach().cpu(), padding=1)
     K._U_CACHE.clear()
+    was = K.KEEP_WINOGRAD_U
+    K.KEEP_WINOGRAD_U = True                                  # off by default; harness.make_optimizer() switches it on
     y1 = K.conv_fwd(x, wk, 1, 1, 1)
     assert len(K._U_CACHE) == 1 and rel(nchw(y1), ref()) < 2e-5
     ent = next(iter(K._U_CACHE.values()))
@@ -353,12 +355,14 @@ def test_winograd_filter_cache(K):
     opt.step()
     y4 = K.conv_fwd(x, wk, 1, 1, 1)
     assert rel(nchw(y4), ref()) < 2e-5 and rel(y4, y3) > 1e-3
-    keep = K.KEEP_WINOGRAD_U
     K.KEEP_WINOGRAD_U = False
     try:
         assert torch.equal(K.conv_fwd(x, wk, 1, 1, 1), y4)
+        with torch.no_grad():
+            w.data.mul_(2.0)                                  # a write through .data does NOT move the version: why the cache is opt-in
+        assert rel(nchw(K.conv_fwd(x, wk, 1, 1, 1)), ref()) < 2e-5
     finally:
-        K.KEEP_WINOGRAD_U = keep
+        K.KEEP_WINOGRAD_U = was
 
 
 def test_layout_and_labels(K):

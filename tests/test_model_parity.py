@@ -689,12 +689,12 @@ def test_three_agg_steps_vs_oracle(env):
 
     def run_hip(keep_u):
         prev = K.KEEP_WINOGRAD_U
-        K.KEEP_WINOGRAD_U = keep_u
         K._U_CACHE.clear()
         try:
             net = synth.load_det_weights(env['deepv3plus'].DeepR50V3PlusD(synth.model_args(), 19, CRIT, CRIT)).cuda()
             net.dsn[3].p = 0.0
-            opt, _ = h.make_optimizer(net)
+            opt, _ = h.make_optimizer(net)                     # switches the cache on (its SGD bumps the versions) ...
+            K.KEEP_WINOGRAD_U = keep_u                         # ... this run decides for itself
             losses = [h.agg_train_step(net, opt, x.cuda(), y.cuda()) for _ in range(3)]
             torch.cuda.synchronize()
             return net, losses
