@@ -55,6 +55,18 @@ def all_reduce_sum(t, group=None):
     return t
 
 
+def all_reduce_sum_copy(t, group=None):
+    """-> (sum over ranks, t untouched). Out of place on the direct communicator (no copy); a clone + in-place all-reduce otherwise."""
+    if not is_dist():
+        return t
+    comm = _direct(t, group)
+    if comm is not None:
+        return comm.all_reduce_sum_into(torch.empty_like(t), t)
+    out = t.clone()
+    dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+    return out
+
+
 def merge_moments_list(parts, c):
     """Chan et al. parallel merge of per-rank (mean[c] | M2[c] | count[c]) -> same layout, exact in real arithmetic."""
     stack = torch.stack(parts)                          # [W, 3c]

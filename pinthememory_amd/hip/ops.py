@@ -170,8 +170,7 @@ def _bn_train_bwd(dv, o, y, mean, invstd, gamma, beta, relu, group, want_dres, h
     if group is not None:
         # dgamma / dbeta are THIS rank's sums (torch.nn.SyncBatchNorm returns the local grad_weight / grad_bias and lets DDP average them);
         # only the input gradient needs the sums over all ranks
-        local = sums.clone()
-        sums = D.all_reduce_sum(sums, group)       # [sum dy | sum dy * xhat | count]: the global count travels with the sums (uneven batches)
+        sums = D.all_reduce_sum_copy(local, group)  # [sum dy | sum dy * xhat | count]: the global count travels with the sums (uneven batches); out of place
     count = float(y.shape[0] * y.shape[1] * y.shape[2]) if group is None else -1.0
     if hand_over:
         dy, _ = K.bn_bwd_apply(gm, None, y, mean, invstd, gamma, sums, count, 0, False)

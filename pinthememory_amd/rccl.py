@@ -86,6 +86,13 @@ class DirectComm:
                                      torch.cuda.current_stream(t.device).cuda_stream), 'ncclAllReduce')
         return t
 
+    def all_reduce_sum_into(self, out, t):
+        """out = sum over ranks of t; t is left untouched (the SyncBN backward keeps its rank-local sums without a copy)."""
+        assert t.is_cuda and t.is_contiguous() and out.is_contiguous() and out.numel() == t.numel() and out.dtype == t.dtype
+        _check(_load().ncclAllReduce(t.data_ptr(), out.data_ptr(), t.numel(), _dtype(t), NCCL_SUM, self.comm,
+                                     torch.cuda.current_stream(t.device).cuda_stream), 'ncclAllReduce')
+        return out
+
     def all_gather_into(self, out, t):
         assert t.is_cuda and t.is_contiguous() and out.is_contiguous() and out.numel() == self.world * t.numel() and out.dtype == t.dtype
         _check(_load().ncclAllGather(t.data_ptr(), out.data_ptr(), t.numel(), _dtype(t), self.comm,
