@@ -623,3 +623,49 @@ def test_input_edge_u8(K):
     ref = (img.float() / 255.0 - mean) / std
     assert (out[..., :3] - ref).abs().max().item() < 1e-6 and out[..., 3].abs().max().item() == 0
     assert torch.equal(K.labels_u8_to_i64(lab.cuda()).cpu(), lab.long())
+
+
+def test_c_abi_error_conventions(K):
+    """the library never throws or exits across the boundary -- bad calls return a negative pm_status and leave a message in
+    pm_last_error(); nothing is launched, the next good call works. Called through the raw ctypes table (hip/lib.py), as a foreign host would."""
+    from ctypes import byref
+    from pinthememory_amd.hip import lib as L
+    lib = L.load()
+    st = L.stream()
+    EINVAL, EWORKSPACE, EUNSUPPORTED = -1, -2, -4
+    x, y = nhwc(rnd(1, 64, 8, 8, seed=1)), torch.empty(1, 8, 8, 64, device='cuda')
+    w = rnd(64, 3, 3, 64, seed=2).cuda()
+    xd, yd = L.tdesc(x), L.tdesc(y)
+    p = L.PmConvParams(3, 3, 1, 1, 1, 0)
+    need = lib.pm_conv_workspace(byref(xd), byref(yd), byref(p), 0)
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device='cuda')
+    assert lib.pm_conv_fwd(byref(xd), None, byref(yd), byref(p), None, ws.data_ptr(), need, st) == EINVAL          # no weight
+    assert b'weight' in lib.pm_last_error()
+    y7 = L.tdesc(torch.empty(1, 7, 7, 64, device='cuda'))
+    assert lib.pm_conv_fwd(byref(xd), w.data_ptr(), byref(y7), byref(p), None, ws.data_ptr(), need, st) == EINVAL  # output extent does not follow from the geometry
+    # a large split-K / Winograd problem with no workspace
+    xl, yl = nhwc(rnd(1, 128, 24, 24, seed=3)), torch.empty(1, 24, 24, 128, device='cuda')
+    wl = rnd(128, 3, 3, 128, seed=4).cuda()
+    xld, yld = L.tdesc(xl), L.tdesc(yl)
+    assert lib.pm_conv_workspace(byref(xld), byref(yld), byref(p), 0) > 0
+    assert lib.pm_conv_fwd(byref(xld), wl.data_ptr(), byref(yld), byref(p), None, None, 0, st) == EWORKSPACE
+    assert b'workspace' in lib.pm_last_error()
+    # memory read: too many slots / a feature width the kernels are not built for
+    q, mem40 = nhwc(rnd(1, 256, 4, 4, seed=5)), rnd(40, 256, seed=6).cuda()
+    qr = torch.empty(1, 4, 4, 512, device='cuda')
+    sc = torch.empty(16, 40, device='cuda')
+    assert lib.pm_mem_read_fwd(byref(L.tdesc(q)), mem40.data_ptr(), 40, None, byref(L.tdesc(qr)), sc.data_ptr(), sc.data_ptr(), st) == EINVAL
+    q128 = nhwc(rnd(1, 128, 4, 4, seed=7))
+    assert lib.pm_mem_read_fwd(byref(L.tdesc(q128)), mem40.data_ptr(), 19, None, byref(L.tdesc(qr)), sc.data_ptr(), sc.data_ptr(), st) == EUNSUPPORTED
+    # BatchNorm statistics of a single value per channel (torch raises in train mode too); 64 classes for the fused CE (built for <= 32)
+    one = L.tdesc(torch.zeros(1, 1, 1, 64, device='cuda'))
+    m = torch.zeros(64, device='cuda')
+    wsb = torch.empty(1 << 16, dtype=torch.uint8, device='cuda')
+    assert lib.pm_bn_stats_finalize(byref(one), 1e-5, m.data_ptr(), m.data_ptr(), None, None, 0.1, wsb.data_ptr(), 1 << 16, st) == EINVAL
+    lg = L.tdesc(torch.zeros(1, 4, 4, 64, device='cuda'))
+    lab = torch.zeros(1, 16, 16, dtype=torch.int64, device='cuda')
+    assert lib.pm_upsample_ce_fwd(byref(lg), 1.0, lab.data_ptr(), 16, 16, m.data_ptr(), wsb.data_ptr(), 1 << 16, st) == EUNSUPPORTED
+    assert lib.pm_sliding_stitch(byref(lg), None, 1, 4, 4, 0, m.data_ptr(), 0, st) == EINVAL
+    # and the library is still usable
+    torch.cuda.synchronize()
+    assert rel(nchw(K.conv_fwd(x, w, 1, 1, 1)), F.conv2d(nchw(x), w.permute(0, 3, 1, 2).cpu(), padding=1)) < 2e-5
