@@ -715,3 +715,29 @@ def test_three_agg_steps_vs_oracle(env):
         for k in w_l:
             assert abs(float(g_all[step][k]) - float(w_l[k])) <= 5e-3 * max(1.0, abs(float(w_l[k]))), (step, k, float(g_all[step][k]), float(w_l[k]))
     assert (net.memory.m_items.cpu() - ref.memory.m_items).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize('bs,size', [(3, (321, 481)), (2, (513, 513)), (2, (256, 768)), (5, (129, 193))])
+def test_agg_step_shape_sweep_finite_and_deterministic(env, bs, size):
+    """Shapes off the beaten path (odd batch, the classic 321 / 513 crops, 1:3 aspect, maps that are no multiple of any tile): one agg step runs,
+    every loss / parameter / BatchNorm buffer / memory row stays finite, the memory rows keep unit norm, and a second run from the same state gives
+    the same bits (every reduction in the library is fixed-order)."""
+    synth, h = env['synth'], env['harness']
+    x, y = synth.make_batch(bs, size, seed=41)
+
+    def run():
+        torch.manual_seed(3)
+        net = synth.load_det_weights(env['deepv3plus'].DeepR50V3PlusD(synth.model_args(), 19, CRIT, CRIT)).cuda()
+        net.dsn[3].p = 0.0
+        opt, _ = h.make_optimizer(net)
+        losses = h.agg_train_step(net, opt, x.cuda(), y.cuda())
+        torch.cuda.synchronize()
+        return net, losses
+    net, losses = run()
+    assert all(torch.isfinite(v).all() for v in losses.values()), losses
+    assert all(torch.isfinite(v).all() for v in net.state_dict().values() if v.dtype.is_floating_point)
+    m = net.memory.m_items
+    assert torch.isfinite(m).all() and (m.norm(dim=1) - 1).abs().max().item() < 1e-5
+    net2, losses2 = run()
+    assert all(torch.equal(losses[k], losses2[k]) for k in losses) and torch.equal(m, net2.memory.m_items)
+    assert all(torch.equal(v, net2.state_dict()[k]) for k, v in net.state_dict().items())
