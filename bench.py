@@ -143,9 +143,18 @@ def cpu_baseline(batch, size, steps=2):
     torch.set_num_threads(best)
     times = [sweep[best]] + [one() for _ in range(steps)]
     dt = sum(times) / len(times)
+    # configs[0] -- the reference's own CPU-runnable case (1 x 3 x 256 x 256 eval forward) -- as the plumbing check, same thread count
+    x1, _ = synth.make_batch(1, 256)
+    net.eval()
+    with torch.no_grad():
+        net(x1)
+        t0 = time.time()
+        for _ in range(3):
+            net(x1)
+        c1_ms = (time.time() - t0) / 3 * 1e3
     torch.set_num_threads(prev)
     return {'value': batch / dt, 'unit': 'imgs/sec', 'cores': best, 'kind': 'port', 'cpu': cpu_model, 'physical_cores': phys,
-            'thread_sweep_s_per_step': {str(k): round(v, 2) for k, v in sweep.items()},
+            'thread_sweep_s_per_step': {str(k): round(v, 2) for k, v in sweep.items()}, 'config1_eval_forward_1x3x256x256_ms': round(c1_ms, 1),
             'sample': '%d timed agg train steps (fwd+bwd+SGD+memory-commit fwd) of a bs=%d sample of the bs=8 %dx%d fp32 workload, torch CPU oracle on %d threads '
                       '(the fastest of a one-step sweep over %s threads, each after its own warm-up step; %d physical cores), %.1f s per step'
                       % (len(times), batch, size, size, best, '/'.join(str(k) for k in sweep), phys, dt)}
