@@ -246,6 +246,7 @@ def test_one_rank_rccl_step_equals_plain_step():
 _TWO_RANK_PROBE = r'''
 import os, sys, torch
 out_path, world = sys.argv[1], int(sys.argv[2])
+split = [int(v) for v in sys.argv[3].split(',')]                     # images per rank (uneven splits: the element count travels with the BN sums)
 rank = int(os.environ.get('RANK', '0'))
 torch.cuda.set_device(0)
 if world > 1:
@@ -259,8 +260,9 @@ net.dsn[3].p = 0.0
 if world > 1:
     net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)          # train.py:95
 x, y = synth.make_batch(4, 128, seed=5)
-per = 4 // world
-x, y = x[rank * per:(rank + 1) * per].cuda(), y[rank * per:(rank + 1) * per].cuda()
+lo = sum(split[:rank]) if world > 1 else 0
+hi = lo + split[rank] if world > 1 else 4
+x, y = x[lo:hi].cuda(), y[lo:hi].cuda()
 net.train()
 outs = net(x, gts=y, aux_gts=y, memory_writing=True, writing_detach=True)
 # a loss that is a plain SUM over images: sum over ranks == the big-batch value, so all-reduced (SUM) gradients must equal the big-batch gradients
@@ -292,23 +294,25 @@ print('PROBE_DONE', rank)
 
 
 @pytest.mark.gpu
-def test_two_ranks_on_gpu_equal_single_process_big_batch(tmp_path):
+@pytest.mark.parametrize('split', ['2,2', '3,1'])
+def test_two_ranks_on_gpu_equal_single_process_big_batch(tmp_path, split):
     """World size 2 for real (two processes, gloo, both on the box's one GPU; RCCL refuses two ranks on one device): rank r runs images
     [2r, 2r + 2) through the HIP path with every BatchNorm converted to SyncBatchNorm (train.py:95) and the memory-slot all-reduce on. Against
     ONE process running all four images: the committed memory (C3), the BatchNorm running moments incl. Memory_sup's own and the 4-sample
     image-pooling BN (C2 forward), the summed loss to fp32 round-off, and the all-reduced gradients of eight parameters from stem to ASPP (C2 backward with the
-    all-reduced element count, C1) to the gradient gates of the parity tests."""
+    all-reduced element count, C1) to the gradient gates of the parity tests. The 3 + 1 split is the uneven last batch: rank 1's image-pooling BatchNorm sees ONE
+    value per channel locally, the merged statistics and the all-reduced count are those of the four images."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     one, two = str(tmp_path / 'one.pt'), str(tmp_path / 'two.pt')
-    r = subprocess.run([sys.executable, '-c', _TWO_RANK_PROBE, one, '1'], cwd=root, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, '-c', _TWO_RANK_PROBE, one, '1', '4'], cwd=root, capture_output=True, text=True, timeout=600)
     assert 'PROBE_DONE 0' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
     port = str(_free_port())
     procs = []
     for rank in range(2):
         env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=port, RANK=str(rank), WORLD_SIZE='2')
-        procs.append(subprocess.Popen([sys.executable, '-c', _TWO_RANK_PROBE, two, '2'], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        procs.append(subprocess.Popen([sys.executable, '-c', _TWO_RANK_PROBE, two, '2', split], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=900) for p in procs]
     assert all('PROBE_DONE' in o[0] for o in outs), ''.join(o[0][-1500:] + o[1][-3000:] for o in outs)
     a, b = torch.load(one), torch.load(two)
