@@ -294,7 +294,7 @@ print('PROBE_DONE', rank)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('split', ['2,2', '3,1'])
+@pytest.mark.parametrize('split', ['2,2', '3,1'])         # '1,1,1,1' (four ranks, one image each) also passes: 170 s of gloo round trips, run by hand
 def test_two_ranks_on_gpu_equal_single_process_big_batch(tmp_path, split):
     """World size 2 for real (two processes, gloo, both on the box's one GPU; RCCL refuses two ranks on one device): rank r runs images
     [2r, 2r + 2) through the HIP path with every BatchNorm converted to SyncBatchNorm (train.py:95) and the memory-slot all-reduce on. Against
@@ -310,9 +310,10 @@ def test_two_ranks_on_gpu_equal_single_process_big_batch(tmp_path, split):
     assert 'PROBE_DONE 0' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
     port = str(_free_port())
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=port, RANK=str(rank), WORLD_SIZE='2')
-        procs.append(subprocess.Popen([sys.executable, '-c', _TWO_RANK_PROBE, two, '2', split], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    world = len(split.split(','))                                     # '1,1,1,1': four ranks, one image each
+    for rank in range(world):
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+        procs.append(subprocess.Popen([sys.executable, '-c', _TWO_RANK_PROBE, two, str(world), split], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=900) for p in procs]
     assert all('PROBE_DONE' in o[0] for o in outs), ''.join(o[0][-1500:] + o[1][-3000:] for o in outs)
     a, b = torch.load(one), torch.load(two)
