@@ -235,15 +235,75 @@ def memory_path_roofline(batch, size):
     return out
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv, child=None, env=None):
+    """`python bench.py --gpus N` without a launcher environment: start N fresh rank processes (one per GPU, the reference's
+    `torch.distributed.launch --nproc_per_node N` hop, train.py:63-76 reads RANK / WORLD_SIZE / LOCAL_RANK the same way), relay
+    rank 0's JSON line and return the worst child exit code. This process has not touched the GPU (no torch import, no HIP call)
+    and never re-execs: the ranks are children. `child` = the command to run per rank (tests stub it)."""
+    import subprocess
+    import threading
+    base = dict(os.environ if env is None else env)
+    base.update({'WORLD_SIZE': str(n), 'LOCAL_WORLD_SIZE': str(n), 'MASTER_ADDR': '127.0.0.1',
+                 'MASTER_PORT': base.get('MASTER_PORT') or str(free_port()), 'PM_BENCH_LAUNCHED': '1'})
+    base.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = list(child) if child is not None else [sys.executable, os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        # rank 0's stdout carries the JSON line: captured and relayed; the other ranks print nothing on stdout by contract
+        procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    lines = []
+
+    def pump():
+        for line in procs[0].stdout:
+            lines.append(line)
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    t = threading.Thread(target=pump, daemon=True)
+    t.start()
+    # a rank that dies leaves the others in a collective: once one has failed, give the rest a grace period, then end them
+    import time as _t
+    rcs = [None] * n
+    failed_at = None
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+                if rcs[i] not in (None, 0) and failed_at is None:
+                    failed_at = _t.time()
+        if failed_at is not None and _t.time() - failed_at > 30:
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    p.kill()
+                    rcs[i] = p.wait() or 1
+        _t.sleep(0.05)
+    t.join(timeout=10)
+    worst = max((abs(rc) for rc in rcs), default=0)
+    if worst == 0 and not any(l.lstrip().startswith('{') for l in lines):
+        print('bench.py: rank 0 printed no JSON line', file=sys.stderr)
+        worst = 1
+    return min(worst, 255)
+
+
 def main():
     a = parse()
     if a.workload == 'config5':
         return config5(a)
+    if a.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert a.gpus == world, 'bench.py --gpus %d but the launcher environment says WORLD_SIZE=%d' % (a.gpus, world)
     assert torch.cuda.is_available(), 'bench.py needs a GPU: the HIP path has no CPU fallback'
     # one process per GPU; PM_BENCH_BACKEND=gloo lets two ranks share one GPU to rehearse the N > 1 code path on a 1-GPU box
     backend = os.environ.get('PM_BENCH_BACKEND', 'nccl')
@@ -317,10 +377,16 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    per_rank_ms, ranks_seen = [round(dt / a.steps * 1e3, 3)], 1
     if multi:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        t = torch.zeros(world, device=dev, dtype=torch.float64)
+        t[rank] = dt
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per_rank_ms = [round(v / a.steps * 1e3, 3) for v in t.tolist()]
+        dt = t.max().item()                              # the contract's MAX over ranks
+        from pinthememory_amd import rccl as _rccl
+        comm = _rccl.get(None)                           # the direct communicator every SyncBN / memory / gradient exchange of the step used
+        ranks_seen = comm.count() if comm is not None else dist.get_world_size()
     roof = None
     if prof:
         # Per-kernel timing brackets every conv launch with two HIP events, which costs ~1.7 ms per step (measured: 70.2 vs 68.5 ms),
@@ -394,6 +460,9 @@ def main():
                                                                                             'bf16-MFMA convolutions (bf16 operands in HBM and LDS, fp32 accumulation; fp32 activations between layers)' if a.dtype == 'bf16' else ('bf16-MFMA (fp32 tiles staged, rounded per fragment)' if bf16 else 'fp32'),
                                                                                             ', decoder skipped in the commit fwd' if a.truncate_second_forward else ''),
                           'global_batch': a.batch * world, 'crop': a.size, 'parallelism': 'dp%d' % world,
+                          'ranks_seen': ranks_seen, 'ranks_seen_source': ('ncclCommCount of the direct RCCL communicator' if multi and backend == 'nccl' and ranks_seen == world and _rccl.get(None) is not None
+                                                                           else ('torch.distributed world size (%s)' % backend if multi else 'single process')),
+                          'ms_per_step_per_rank': per_rank_ms,
                           'conv_tflop_per_step': round(gf_img * a.batch / 1e3, 3),
                           'conv_flop_convention': 'direct-algorithm FLOPs (SURVEY 8d); the Winograd F(4x4,3x3) / F(2x2,3x3) layers execute 4x / 2.25x fewer on the MFMA, so step_mfma_frac is a direct-equivalent rate, not MFMA utilisation',
                           'step_mfma_frac': round(gf_img * a.batch * world * a.steps / 1e3 / dt / (peak * world), 4),

@@ -33,26 +33,50 @@ def _stale():
 
 
 def build(force=False, verbose=True):
+    """Build if the sources changed since the library was built. Safe to call from every rank of a multi-process launch at once: one
+    process builds under an exclusive file lock (objects and the .so go to temporary names and are renamed into place, so a concurrent
+    dlopen never sees a half-written file), the others block on the lock, re-check the fingerprint and find the work done."""
     if not force and not _stale():
         return LIB
+    import fcntl
+    with open(LIB + '.lock', 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():      # another process built it while this one waited
+                return LIB
+            _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    return LIB
+
+
+def _build_locked(verbose):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    fp = _fingerprint()
     objs = []
     procs = []
     bdir = os.path.join(HERE, 'build')
     os.makedirs(bdir, exist_ok=True)
+    tag = '.%d.tmp' % os.getpid()
     for s in SOURCES:
         o = os.path.join(bdir, s.replace('.hip', '.o'))
         objs.append(o)
-        procs.append((s, subprocess.Popen([hipcc] + FLAGS + ['-c', os.path.join(CSRC, s), '-o', o])))
-    for s, p in procs:
-        if p.wait() != 0:
-            raise RuntimeError('hipcc failed on %s' % s)
-    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB])
-    with open(STAMP, 'w') as f:
-        f.write(_fingerprint())
+        procs.append((s, o, subprocess.Popen([hipcc] + FLAGS + ['-c', os.path.join(CSRC, s), '-o', o + tag])))
+    failed = [s for s, o, p in procs if p.wait() != 0]
+    if failed:
+        for s, o, p in procs:
+            if os.path.exists(o + tag):
+                os.remove(o + tag)
+        raise RuntimeError('hipcc failed on %s' % ', '.join(failed))
+    for s, o, p in procs:
+        os.replace(o + tag, o)
+    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB + tag])
+    os.replace(LIB + tag, LIB)
+    with open(STAMP + tag, 'w') as f:
+        f.write(fp)
+    os.replace(STAMP + tag, STAMP)
     if verbose:
         print('built', LIB, file=sys.stderr)
-    return LIB
 
 
 if __name__ == '__main__':

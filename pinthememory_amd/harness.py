@@ -15,9 +15,9 @@ LOSS_W = dict(aux=0.4, read=0.02, div=0.4, cls=0.2)    # train.py:1213-1215 defa
 
 def make_optimizer(net, lr=0.01, momentum=0.9, poly_exp=9):
     """optimizer.py:11-32: SGD over all named parameters, weight decay hard-coded 5e-4, lr * exp(-poly_exp*it/120000).
-    The optimizer is torch.optim.SGD (same state_dict) whose step() is one multi-tensor launch of the HIP library (optim.py)."""
+    The optimizer is torch.optim.SGD (same state_dict) whose step() is one multi-tensor launch of the HIP library (optim.py);
+    it registers the weights it owns with the transformed-filter cache (hip/kernels.py) and bumps their versions when it updates them."""
     from .optim import SGD
-    K.keep_transformed_filters(True)         # optim.SGD bumps the tensor versions the filter cache is keyed by (hip/kernels.py)
     opt = SGD([p for _, p in net.named_parameters()], lr=lr, weight_decay=5e-4, momentum=momentum, nesterov=False)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda it: math.exp(-1 * poly_exp * it / 120000))
     return opt, sched

@@ -61,41 +61,72 @@ BN_EPILOGUE = os.environ.get('PM_BN_EPILOGUE', '0') == '1'
 
 
 # Transformed filters -- the Winograd U = G w G^T, or the bf16 copy of the weights in the bf16 tier -- kept between calls: the eval-mode forward of
-# step t and the training forward of step t + 1 read the same weights. Keyed by the weight's storage address, shape and size of the transformed
-# filter; an entry holds a reference to the weight tensor (so its address cannot be handed to another tensor while the entry lives) and the tensor
-# VERSION its content was computed from: every in-place update through torch's ops bumps the version, and optim.SGD bumps it for its fused update.
-# What does NOT bump it is a write through `w.data` (legacy optimizers, manual EMA) or through raw pointers -- a stale filter would be silently wrong,
-# so the cache is OFF unless the caller vouches for its optimizer: harness.make_optimizer() (optim.SGD) switches it on, PM_KEEP_U=1 / 0 forces it.
-# Functional weights (train_memory_mldg's theta) are new tensors every step: they never hit and are evicted in turn.
-KEEP_WINOGRAD_U = os.environ.get('PM_KEEP_U', '0') == '1'
+# step t and the training forward of step t + 1 read the same weights. The cache is SCOPED TO AN OWNER that vouches for its updates: optim.SGD
+# registers the parameters it owns (register_filter_owners) and bumps their tensor VERSION for its fused raw-pointer update; only registered leaf
+# parameters are cached, keyed by storage address + transformed size, validated by (the owner is alive, still at that address, same version).
+# Every in-place update through torch's ops bumps the version too. What does NOT bump it is a write through `w.data` or raw pointers by code that
+# is not the owner (legacy optimizers, manual EMA, an in-place collective on parameters): weights nobody registered are never cached, so such code
+# cannot meet a stale filter. Entries hold a WEAK reference to the owner -- functional weights (train_memory_mldg's theta), `.contiguous()` copies and
+# models that are gone are neither cached nor retained. PM_KEEP_U=0 switches the cache off, PM_KEEP_U=1 caches every weight (A/B runs and tests).
+KEEP_WINOGRAD_U = {'0': False, '1': True}.get(os.environ.get('PM_KEEP_U', ''))      # None = owner-scoped (default)
 
-
-def keep_transformed_filters(on=True):
-    """Called by code that updates weights only through version-bumping ops (harness.make_optimizer); PM_KEEP_U in the environment wins."""
-    global KEEP_WINOGRAD_U
-    KEEP_WINOGRAD_U = (os.environ['PM_KEEP_U'] == '1') if 'PM_KEEP_U' in os.environ else bool(on)
-    if not KEEP_WINOGRAD_U:
-        _U_CACHE.clear()
-
-
-_U_CACHE = {}
+_U_OWNERS = {}      # storage address -> weakref to the registered leaf parameter
+_U_CACHE = {}       # key -> [weakref(owner) or the weight itself when forced, version, U]
 _U_CACHE_MAX = 256
 _U_CACHE_BYTES = int(os.environ.get('PM_KEEP_U_MB', '2048')) << 20     # one ResNet-50 DeepLabV3+ keeps 0.43 GB, a ResNet-101 DeepLabV2 0.65 GB
 
 
+def register_filter_owners(params):
+    """Called by an optimizer for the weights it owns: it promises that every update of them moves the tensor version (optim.SGD does)."""
+    import weakref
+    for p in params:
+        if isinstance(p, torch.nn.Parameter) and p.is_leaf and p.is_cuda and p.dim() == 4 and p.dtype == torch.float32:
+            _U_OWNERS[p.data_ptr()] = weakref.ref(p)
+
+
+def unregister_filter_owners(params=None):
+    """Forget the owner's weights (all of them when params is None) and drop their cached filters."""
+    ptrs = None if params is None else {p.data_ptr() for p in params}
+    for k in [k for k in _U_OWNERS if ptrs is None or k in ptrs]:
+        del _U_OWNERS[k]
+    for k in [k for k in _U_CACHE if ptrs is None or k[0] in ptrs]:
+        del _U_CACHE[k]
+
+
+def _filter_owner(w_krsc):
+    ref = _U_OWNERS.get(w_krsc.data_ptr())
+    p = ref() if ref is not None else None
+    if p is None:
+        if ref is not None:
+            del _U_OWNERS[w_krsc.data_ptr()]
+        return None
+    return p if (p.data_ptr() == w_krsc.data_ptr() and p.numel() == w_krsc.numel() and p.is_leaf) else None
+
+
 def _wino_u(lib, xd, yd, p, w_krsc):
+    if KEEP_WINOGRAD_U is False:
+        return None
+    owner = _filter_owner(w_krsc)
+    if owner is None and KEEP_WINOGRAD_U is not True:
+        return None
     nbu = lib.pm_conv_wxf_bytes(byref(xd), byref(yd), byref(p))
     if not nbu:
         return None
+    import weakref
     key = (w_krsc.data_ptr(), tuple(w_krsc.shape), nbu, w_krsc.device.index, p.prec)
     ent = _U_CACHE.pop(key, None)
+    if ent is not None and (ent[0]() if isinstance(ent[0], weakref.ref) else ent[0]) is not (owner if owner is not None else w_krsc):
+        ent = None                 # another tensor now lives at this address: the kept transform is somebody else's
     if ent is None:
         # oldest entries go first (dicts keep insertion order; hits are re-inserted): models that are gone release their buffers here
+        for k in [k for k, e in _U_CACHE.items() if isinstance(e[0], weakref.ref) and e[0]() is None]:
+            del _U_CACHE[k]
         while _U_CACHE and (len(_U_CACHE) >= _U_CACHE_MAX or sum(e[2].numel() * 4 for e in _U_CACHE.values()) + nbu > _U_CACHE_BYTES):
             _U_CACHE.pop(next(iter(_U_CACHE)))
-        ent = [w_krsc, -1, torch.empty(nbu // 4, dtype=torch.float32, device=w_krsc.device)]
-    valid = ent[1] == w_krsc._version
-    ent[1] = w_krsc._version
+        ent = [weakref.ref(owner) if owner is not None else w_krsc, -1, torch.empty(nbu // 4, dtype=torch.float32, device=w_krsc.device)]
+    version = (owner if owner is not None else w_krsc)._version
+    valid = ent[1] == version
+    ent[1] = version
     _U_CACHE[key] = ent
     p.wxf, p.wxf_bytes, p.wxf_valid = ent[2].data_ptr(), nbu, 1 if valid else 0
     return ent[2]
@@ -120,7 +151,7 @@ def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, res
         keep_v.append(v)
         if v is not None:
             p.wino_v, p.wino_v_bytes = v.data_ptr(), nbv
-    if KEEP_WINOGRAD_U and ((kh == 3 and CONV_PREC == 0) or CONV_PREC == 2):
+    if (kh == 3 and CONV_PREC == 0) or CONV_PREC == 2:
         _wino_u(lib, xd, yd, p, w_krsc)
     nb = lib.pm_conv_workspace(byref(xd), byref(yd), byref(p), 0)
     ws = workspace(nb, x.device) if nb else None

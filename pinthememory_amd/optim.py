@@ -19,7 +19,20 @@ def _dense_like(a, b):
 
 class SGD(torch.optim.SGD):
     def __init__(self, params, lr=0.01, momentum=0.9, weight_decay=5e-4, nesterov=False, **kw):
+        for k in ('foreach', 'fused', 'differentiable'):      # torch's implementation switches: step() here is its own implementation
+            if kw.get(k):
+                raise ValueError('pinthememory_amd.optim.SGD does not take %s=%r (step() is one multi-tensor launch of the HIP library)' % (k, kw[k]))
+            kw.pop(k, None)
         super().__init__(params, lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=nesterov, **kw)
+        self._register_filters()
+
+    def _register_filters(self):
+        """The transformed-filter cache (hip/kernels.py) keeps U = G w G^T only for weights whose owner bumps their version on every update."""
+        K.register_filter_owners(p for g in self.param_groups for p in g['params'])
+
+    def add_param_group(self, group):
+        super().add_param_group(group)
+        K.register_filter_owners(self.param_groups[-1]['params'])
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -49,6 +62,7 @@ class SGD(torch.optim.SGD):
                     buf = st['momentum_buffer'] = new
                 fused.append((p, g, buf))
             if fused:
+                K.register_filter_owners(p for p, _, _ in fused)      # parameters moved to the GPU after the optimizer was built
                 K.sgd_momentum_multi(fused, float(group['lr']), float(group['momentum']), float(group['weight_decay']))
                 # the kernel writes through raw pointers: tell autograd (saved-tensor checks) and the Winograd filter cache (hip/kernels.py)
                 torch.autograd.graph.increment_version([t for p, _, buf in fused for t in (p, buf)])
@@ -58,7 +72,8 @@ class SGD(torch.optim.SGD):
 
     def _torch_step(self, group, params):
         for p in params:
-            d = p.grad.add(p, alpha=group['weight_decay']) if group['weight_decay'] != 0 else p.grad
+            g = -p.grad if group.get('maximize', False) else p.grad      # torch.optim.sgd: the gradient is negated first
+            d = g.add(p, alpha=group['weight_decay']) if group['weight_decay'] != 0 else g
             if group['momentum'] != 0:
                 st = self.state[p]
                 buf = st.get('momentum_buffer')

@@ -40,6 +40,7 @@ def _load():
         lib.ncclGetUniqueId.argtypes = [ctypes.POINTER(_UniqueId)]
         lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _UniqueId, ctypes.c_int]
         lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        lib.ncclCommCount.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
         lib.ncclCommAbort.argtypes = [ctypes.c_void_p]
         lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         lib.ncclAllGather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
@@ -110,6 +111,12 @@ class DirectComm:
         while not ev.query() and time.time() < deadline:
             time.sleep(0.005)
         return bool(ev.query()) and float(t[0].item()) == float(self.world)
+
+    def count(self):
+        """Rank count the communicator itself reports (ncclCommCount) -- the bench line's evidence that RCCL carried `world` ranks."""
+        n = ctypes.c_int(0)
+        _check(_load().ncclCommCount(self.comm, ctypes.byref(n)), 'ncclCommCount')
+        return n.value
 
     def destroy(self, abort=False):
         if self.comm:

@@ -1,0 +1,184 @@
+"""GPU parity of the reference's DEFAULT configuration -- the one bench.py times: the memory reads with Gumbel noise in train AND eval mode
+(/root/reference/network/deepv3plus.py:472 `gumbel_read=(not args.gumbel_off)`, memory.py:181-184 `F.gumbel_softmax(score, dim=0 / 1)`) and the
+auxiliary head trains with Dropout2d(0.1) (deepv3plus.py:423) -- and of the reference's own initialisation (BatchNorm gamma = 1 everywhere,
+Resnet.py:441-448, mynn.py:27-44).
+
+Random draws cannot agree between a CPU and a GPU generator, so the ORACLE runs unmodified under a seed while its draws are recorded --
+every `Tensor.exponential_` result (F.gumbel_softmax's only random call: g = -log(Exp(1))) through a pass-through wrapper, and the channel mask
+of the stock nn.Dropout2d through a forward hook -- and the HIP model replays exactly those draws: `Memory_sup.noise_fn` (the hook the product
+has for this) and a fixed-mask stand-in for `dsn[3]`. Bars as for the noise-free tests: eval logits 1e-3 with margin-gated argmax, the five
+losses of an agg step 2e-4, committed memory 1e-4."""
+import contextlib
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+CRIT = torch.nn.CrossEntropyLoss(reduction='mean', ignore_index=255)
+LOGIT_TOL = 1e-3
+
+
+@pytest.fixture(scope='module')
+def env():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from oracle.ref_cpu import deeplab as o_deeplab, harness as o_harness
+    from pinthememory_amd import harness, synth
+    from pinthememory_amd.network import deepv3plus
+    return dict(o_deeplab=o_deeplab, o_harness=o_harness, harness=harness, synth=synth, deepv3plus=deepv3plus)
+
+
+@contextlib.contextmanager
+def recorded_exponentials(log):
+    """Every Tensor.exponential_() inside the block still draws from torch's own generator; a copy of each result is appended to `log`."""
+    orig = torch.Tensor.exponential_
+
+    def rec(self, *a, **k):
+        out = orig(self, *a, **k)
+        log.append(self.detach().clone())
+        return out
+    torch.Tensor.exponential_ = rec
+    try:
+        yield log
+    finally:
+        torch.Tensor.exponential_ = orig
+
+
+def record_dropout_mask(drop, log):
+    """Forward hook on the oracle's stock nn.Dropout2d: the [B, C] keep-mask it drew (a dropped channel is all zero although its input is not)."""
+    def hook(mod, inp, out):
+        if mod.training and mod.p > 0:
+            x = inp[0]
+            keep = (out.abs().flatten(2).sum(2) > 0) | (x.abs().flatten(2).sum(2) == 0)
+            log.append(keep.clone())
+    return drop.register_forward_hook(hook)
+
+
+class ReplayDropout2d(torch.nn.Module):
+    """torch.feature_dropout's arithmetic (input * (mask / (1 - p))) with the masks the oracle drew, in order."""
+
+    def __init__(self, p, masks):
+        super().__init__()
+        self.p, self.masks = p, list(masks)
+
+    def forward(self, x):
+        if not self.training or self.p == 0:
+            return x
+        noise = self.masks.pop(0).to(x.device, x.dtype).div_(1 - self.p)
+        return x * noise[:, :, None, None]
+
+
+def replay_noise(log):
+    """Memory_sup.noise_fn: one read draws twice, first for softmax(dim=0) then for softmax(dim=1) (memory.py:183-184)."""
+    queue = list(log)
+
+    def fn(rows, slots, device):
+        e0, e1 = queue.pop(0), queue.pop(0)
+        assert tuple(e0.shape) == tuple(e1.shape) == (rows, slots)
+        return (-e0.log()).to(device), (-e1.log()).to(device)      # the reference's own expression, evaluated on the same (CPU) bits
+    fn.queue = queue
+    return fn
+
+
+def argmax_gate(lg, ref_lg, tol=LOGIT_TOL):
+    top2 = ref_lg.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 2 * tol
+    a, b = lg.argmax(1), ref_lg.argmax(1)
+    return bool((a[safe] == b[safe]).all()), float((a == b).float().mean())
+
+
+def test_default_config_eval_forward_with_gumbel_read(env):
+    synth = env['synth']
+    args = synth.model_args(gumbel_off=False)
+    ref = synth.load_det_weights(env['o_deeplab'].DeepR50V3PlusD(args, 19, CRIT, CRIT)).eval()
+    net = synth.load_det_weights(env['deepv3plus'].DeepR50V3PlusD(args, 19, CRIT, CRIT)).cuda().eval()
+    assert ref.memory.gumbel_read and net.memory.gumbel_read
+    x, _ = synth.make_batch(2, 256, seed=5)
+    torch.manual_seed(1234)
+    with torch.no_grad(), recorded_exponentials([]) as log:
+        want = ref(x)
+    assert len(log) == 2
+    net.memory.noise_fn = replay_noise(log)
+    with torch.no_grad():
+        got = net(x.cuda())
+    assert not net.memory.noise_fn.queue
+    lg = got[0].cpu()
+    assert (lg - want[0]).abs().max().item() < LOGIT_TOL
+    ok, frac = argmax_gate(lg, want[0])
+    assert ok and frac > 0.9995, frac
+    assert (got[1][0].cpu() - want[1][0]).abs().max().item() < 1e-5          # gumbel softmax over queries
+    assert (got[1][1].cpu() - want[1][1]).abs().max().item() < 1e-4          # gumbel softmax over slots
+    # the noise is not a no-op: without it the slot softmax differs visibly
+    net.memory.noise_fn = lambda rows, slots, device: (torch.zeros(rows, slots, device=device), torch.zeros(rows, slots, device=device))
+    with torch.no_grad():
+        plain = net(x.cuda())
+    assert (plain[1][1].cpu() - want[1][1]).abs().max().item() > 1e-2
+
+
+def test_default_config_agg_step_with_gumbel_and_dropout(env):
+    """One reference-faithful agg step exactly as bench.py times it (gumbel read in both forwards, Dropout2d(0.1) in dsn): five losses 2e-4,
+    committed memory 1e-4, every post-step parameter / buffer 1e-4 of its norm against the oracle replaying nothing -- it draws, the HIP side replays."""
+    synth, h, o_h = env['synth'], env['harness'], env['o_harness']
+    args = synth.model_args(gumbel_off=False)
+    x, y = synth.make_batch(2, 128, seed=31)
+    ref = synth.load_det_weights(env['o_deeplab'].DeepR50V3PlusD(args, 19, CRIT, CRIT))
+    assert ref.dsn[3].p == 0.1
+    o_opt, _ = o_h.make_optimizer(ref)
+    masks = []
+    hook = record_dropout_mask(ref.dsn[3], masks)
+    torch.manual_seed(4321)
+    with recorded_exponentials([]) as log:
+        want = o_h.agg_train_step(ref, o_opt, x, y)
+    hook.remove()
+    assert len(log) == 4 and len(masks) == 1                   # two reads (train forward, eval-mode commit forward) x two draws; one dropout
+    assert 0 < int((~masks[0]).sum()) < masks[0].numel() // 4   # some channels really were dropped
+
+    net = synth.load_det_weights(env['deepv3plus'].DeepR50V3PlusD(args, 19, CRIT, CRIT)).cuda()
+    assert net.dsn[3].p == 0.1
+    net.dsn[3] = ReplayDropout2d(0.1, masks)
+    net.memory.noise_fn = replay_noise(log)
+    opt, _ = h.make_optimizer(net)
+    got = h.agg_train_step(net, opt, x.cuda(), y.cuda())
+    torch.cuda.synchronize()
+    assert not net.memory.noise_fn.queue and not net.dsn[3].masks
+    for k in ('loss1', 'loss2', 'readloss', 'div', 'cls', 'total'):
+        assert abs(float(got[k]) - float(want[k])) <= 2e-4 * max(1.0, abs(float(want[k]))), (k, float(got[k]), float(want[k]))
+    assert (net.memory.m_items.cpu() - ref.memory.m_items).abs().max().item() < 1e-4
+    worst = ('', 0.0)
+    rs = ref.state_dict()
+    for k, v in net.state_dict().items():
+        if k.startswith('dsn.3') or not v.dtype.is_floating_point:
+            continue
+        e = (v.cpu() - rs[k]).norm().item() / (rs[k].norm().item() + 1e-30)
+        worst = max(worst, (k, e), key=lambda t: t[1])
+    assert worst[1] < 1e-4, worst
+    # and the same step WITHOUT the replay (fresh GPU draws) lands elsewhere: the agreement above is due to the replay, not to insensitivity
+    net2 = synth.load_det_weights(env['deepv3plus'].DeepR50V3PlusD(args, 19, CRIT, CRIT)).cuda()
+    opt2, _ = h.make_optimizer(net2)
+    free = h.agg_train_step(net2, opt2, x.cuda(), y.cuda())
+    assert abs(float(free['loss2']) - float(want['loss2'])) > 1e-5 or abs(float(free['loss1']) - float(want['loss1'])) > 1e-5
+
+
+def test_reference_init_gamma_one_eval_forward(env):
+    """The reference's OWN initialisation (same torch seed -> the same init draws on both sides; BatchNorm gamma = 1, beta = 0, running moments
+    0 / 1 -- no damping of the residual branches): eval logits of configs[0]'s 1 x 3 x 256 x 256 input within 1e-3, argmax margin-gated."""
+    synth = env['synth']
+    args = synth.model_args()
+    torch.manual_seed(304)
+    ref = env['o_deeplab'].DeepR50V3PlusD(args, 19, CRIT, CRIT).eval()
+    torch.manual_seed(304)
+    net = env['deepv3plus'].DeepR50V3PlusD(args, 19, CRIT, CRIT)
+    sd, rd = net.state_dict(), ref.state_dict()
+    assert list(sd) == list(rd) and all(torch.equal(sd[k], rd[k]) for k in sd)          # same-seed init is bit-identical (tests/test_boundary.py)
+    assert torch.equal(net.memory.m_items, ref.memory.m_items)
+    assert float(sd['layer3.2.bn3.weight'].min()) == 1.0
+    net = net.cuda().eval()
+    x, _ = synth.make_batch(1, 256)
+    with torch.no_grad():
+        want, got = ref(x), net(x.cuda())
+    lg = got[0].cpu()
+    scale = want[0].abs().max().item()
+    assert (lg - want[0]).abs().max().item() < LOGIT_TOL * max(1.0, scale), ((lg - want[0]).abs().max().item(), scale)
+    ok, frac = argmax_gate(lg, want[0], tol=LOGIT_TOL * max(1.0, scale))
+    assert ok, frac
+    assert (got[1][1].cpu() - want[1][1]).abs().max().item() < 1e-4

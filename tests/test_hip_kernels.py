@@ -338,9 +338,23 @@ def test_winograd_filter_cache(K):
     assert wk.data_ptr() == w.data_ptr() and wk.is_contiguous()
     ref = lambda: F.conv2d(nchw(x), w.detach().cpu(), padding=1)
     K._U_CACHE.clear()
+    K.unregister_filter_owners()
     was = K.KEEP_WINOGRAD_U
-    K.KEEP_WINOGRAD_U = True                                  # off by default; harness.make_optimizer() switches it on
+    K.KEEP_WINOGRAD_U = None                                  # the default: only weights an optimizer registered are cached
+    y0 = K.conv_fwd(x, wk, 1, 1, 1)
+    assert len(K._U_CACHE) == 0                               # nobody vouches for this weight: never cached ...
+    with torch.no_grad():
+        w.data.mul_(2.0)                                      # ... so a write through .data (no version bump) cannot meet a stale filter
+    assert rel(nchw(K.conv_fwd(x, wk, 1, 1, 1)), ref()) < 2e-5 and len(K._U_CACHE) == 0
+    with torch.no_grad():
+        w.data.mul_(0.5)
+    assert torch.equal(K.conv_fwd(x, wk, 1, 1, 1), y0)
+    opt = optim.SGD([w], lr=0.1, momentum=0.9, weight_decay=0.0)      # the owner: registers w, bumps its version in step()
     y1 = K.conv_fwd(x, wk, 1, 1, 1)
+    assert torch.equal(y1, y0)
+    theta = w.detach().clone(memory_format=torch.preserve_format)      # a functional weight (mldg's theta): not registered, not cached, not retained
+    K.conv_fwd(x, theta.permute(0, 2, 3, 1), 1, 1, 1)
+    assert len(K._U_CACHE) == 1
     assert len(K._U_CACHE) == 1 and rel(nchw(y1), ref()) < 2e-5
     ent = next(iter(K._U_CACHE.values()))
     u_before = ent[2].clone()
@@ -351,16 +365,16 @@ def test_winograd_filter_cache(K):
     y3 = K.conv_fwd(x, wk, 1, 1, 1)
     assert rel(nchw(y3), ref()) < 2e-5 and not torch.equal(ent[2], u_before)
     w.grad = torch.ones_like(w)                               # one fused SGD step (raw-pointer update inside the library)
-    opt = optim.SGD([w], lr=0.1, momentum=0.9, weight_decay=0.0)
     opt.step()
     y4 = K.conv_fwd(x, wk, 1, 1, 1)
     assert rel(nchw(y4), ref()) < 2e-5 and rel(y4, y3) > 1e-3
     K.KEEP_WINOGRAD_U = False
     try:
         assert torch.equal(K.conv_fwd(x, wk, 1, 1, 1), y4)
-        with torch.no_grad():
-            w.data.mul_(2.0)                                  # a write through .data does NOT move the version: why the cache is opt-in
-        assert rel(nchw(K.conv_fwd(x, wk, 1, 1, 1)), ref()) < 2e-5
+        K.KEEP_WINOGRAD_U = None
+        K.unregister_filter_owners([w])                       # the owner lets go: entries dropped, nothing cached afterwards
+        assert len(K._U_CACHE) == 0
+        assert torch.equal(K.conv_fwd(x, wk, 1, 1, 1), y4) and len(K._U_CACHE) == 0
     finally:
         K.KEEP_WINOGRAD_U = was
 
@@ -451,6 +465,20 @@ def test_memory_read(K):
     _, _, pg = K.mem_read_fwd(xg, memg, noise.cuda())
     assert rel(pg, F.softmax(s.detach() + noise, 1)) < 2e-6
     assert rel(K.mem_colsoftmax(score, noise.cuda()), F.softmax(s.detach() + noise, 0)) < 2e-6
+    # ... and its BACKWARD (the default configuration reads with noise, deepv3plus.py:472): d/dx through R = softmax(S + g) M and the concat
+    # half, both kernels (MFMA dx-only and the dmem row kernel), against autograd of the same formula with the same noise
+    xn, mn = x.clone().requires_grad_(True), mem.clone().requires_grad_(True)
+    qn = F.normalize(xn, dim=1).permute(0, 2, 3, 1).contiguous()
+    sn = torch.matmul(qn, mn.t()).view(-1, m)
+    qrn = torch.cat((qn.view(-1, d), torch.matmul(F.softmax(sn + noise, 1), mn)), 1)
+    ((qrn * dqr).sum() + (sn * dsx).sum()).backward()
+    qg, _, _ = K.mem_read_fwd(xg, memg, noise.cuda())
+    assert rel(qg.view(-1, 2 * d), qrn.detach()) < 2e-6
+    dxn, dmn = K.mem_read_bwd(xg, memg, pg, dqr.view(n, h, w, 2 * d).cuda(), dsx.cuda(), want_dmem=True)
+    assert rel(nchw(dxn)[:, :, 1:], xn.grad[:, :, 1:]) < 2e-5 and rel(dmn, mn.grad) < 2e-5
+    dxn2, _ = K.mem_read_bwd(xg, memg, pg, dqr.view(n, h, w, 2 * d).cuda(), dsx.cuda())
+    assert rel(nchw(dxn2)[:, :, 1:], xn.grad[:, :, 1:]) < 2e-5
+    assert rel(nchw(dxn2)[:, :, 1:], xr.grad[:, :, 1:]) > 1e-3          # the noise does change the gradient: the comparison above is not vacuous
 
 
 def test_memory_read_more_rows_than_resident_tiles(K):

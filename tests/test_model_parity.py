@@ -693,8 +693,8 @@ def test_three_agg_steps_vs_oracle(env):
         try:
             net = synth.load_det_weights(env['deepv3plus'].DeepR50V3PlusD(synth.model_args(), 19, CRIT, CRIT)).cuda()
             net.dsn[3].p = 0.0
-            opt, _ = h.make_optimizer(net)                     # switches the cache on (its SGD bumps the versions) ...
-            K.KEEP_WINOGRAD_U = keep_u                         # ... this run decides for itself
+            opt, _ = h.make_optimizer(net)                     # its SGD registers the weights it owns with the filter cache and bumps their versions
+            K.KEEP_WINOGRAD_U = None if keep_u else False      # None = the default (owner-scoped cache), False = no cache
             losses = [h.agg_train_step(net, opt, x.cuda(), y.cuda()) for _ in range(3)]
             torch.cuda.synchronize()
             return net, losses
