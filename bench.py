@@ -186,6 +186,8 @@ def memory_path_roofline(batch, size):
     main.copy_(torch.randn(B, H // 4, H // 4, m, generator=g).cuda())
     lo_main = K.upsample_ce_fwd(main, lab, 1.0)
     z = K.mem_write_accum(x, lab, m)
+    lo_f, lo_field = K.upsample_ce_fwd_field(lg, lab, 1.0)
+    lo_mf, lo_mfield = K.upsample_ce_fwd_field(main, lab, 1.0)
     cases = [     # (name, reference lines, algorithmic bytes per launch, launch)
         ('mem_read_fwd', 'memory.py:317-336', N * d * 4 + m * d * 4 + N * 2 * d * 4 + 2 * N * m * 4, lambda: K.mem_read_fwd(x, mem)),
         ('mem_read_bwd', 'memory.py:317-336 (autograd)', N * 2 * d * 4 + 2 * N * d * 4 + 2 * N * m * 4, lambda: K.mem_read_bwd(x, mem, pmem, dqr, dsx)),
@@ -193,7 +195,15 @@ def memory_path_roofline(batch, size):
         ('mem_write_accum', 'memory.py:219-231', N * d * 4 + B * 4 * h * h * 8 + (m + 1) * (d + 1) * 4, lambda: K.mem_write_accum(x, lab, m)),
         ('readloss_fwd', 'memory.py:173-176', B * H * H * 8 + N * m * 4, lambda: K.upsample_ce_fwd(lg, lab, 1.0)),
         ('readloss_bwd', 'memory.py:173-176 (autograd)', B * H * H * 8 + 2 * N * m * 4, lambda: K.upsample_ce_bwd(lg, lab, lo, None, 1.0)),
+        ('readloss_fwd_with_grad_field', 'memory.py:173-176 (training forward: loss + column-reduced gradient field in one sweep)',
+         B * H * H * 8 + N * m * 4 + B * H * h * m * 4, lambda: K.upsample_ce_fwd_field(lg, lab, 1.0)),
+        ('readloss_bwd_from_field', 'memory.py:173-176 (autograd: row pass over the field)', B * H * h * m * 4 + N * m * 4,
+         lambda: K.upsample_ce_bwd_field(lg, (H, H), lo_f, lo_field, None, 1.0)),
         ('main_ce_fwd', 'deepv3plus.py:575-578', B * H * H * 8 + B * (H // 4) ** 2 * m * 4, lambda: K.upsample_ce_fwd(main, lab, 1.0)),
+        ('main_ce_fwd_with_grad_field', 'deepv3plus.py:575-578 (training forward: loss + column-reduced gradient field in one sweep)',
+         B * H * H * 8 + B * (H // 4) ** 2 * m * 4 + B * H * (H // 4) * m * 4, lambda: K.upsample_ce_fwd_field(main, lab, 1.0)),
+        ('main_ce_bwd_from_field', 'deepv3plus.py:575-578 (autograd: row pass over the field)', B * H * (H // 4) * m * 4 + B * (H // 4) ** 2 * m * 4,
+         lambda: K.upsample_ce_bwd_field(main, (H, H), lo_mf, lo_mfield, None, 1.0)),
         ('main_ce_bwd', 'deepv3plus.py:575-578 (autograd)', B * H * H * 8 + 2 * B * (H // 4) ** 2 * m * 4, lambda: K.upsample_ce_bwd(main, lab, lo_main, None, 1.0)),
     ]
     del z

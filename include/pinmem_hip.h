@@ -202,6 +202,17 @@ size_t pm_upsample_ce_bwd_workspace(const pm_tensor* logits, int H, int W);
 int pm_upsample_ce_bwd(const pm_tensor* logits, float inv_temp, const int64_t* labels, int H, int W, const float* loss_out,
                        const float* gscale, const pm_tensor* dlogits, void* ws, size_t ws_bytes, void* stream);
 
+/* Training forward (the logits carry a graph): the same loss, and in the same sweep over the labels the column-reduced gradient field
+ *   field[n][H][w][C] = sum over hi-res columns X of (softmax - onehot)(n, Y, X)[c] * (bilinear weight of X on low-res column x)
+ * (float, pm_upsample_ce_field_bytes) -- everything the backward needs from labels and up-sampled logits; the upstream scale is a scalar applied
+ * last. pm_upsample_ce_bwd_field is then the row pass alone: dlogits = gscale / valid * inv_temp * (field reduced over the supporting hi-res rows).
+ * Labels and logits are read once per step instead of twice (replaces autograd through deepv3plus.py:575-578 / memory.py:173-176). */
+size_t pm_upsample_ce_field_bytes(const pm_tensor* logits, int H, int W);
+int pm_upsample_ce_fwd_field(const pm_tensor* logits, float inv_temp, const int64_t* labels, int H, int W, float* loss_out, float* field,
+                             void* ws /* pm_upsample_ce_workspace */, size_t ws_bytes, void* stream);
+int pm_upsample_ce_bwd_field(const pm_tensor* logits /* shape only */, float inv_temp, int H, int W, const float* loss_out, const float* gscale,
+                             const float* field, const pm_tensor* dlogits, void* stream);
+
 /* ---- K7 memory read (memory.py:317-336 + get_score :167-189) ---------------------------------------------------
  * x: [N rows of d=256] (NHWC feature map); mem [m<=32][d]; writes qr = [qhat | P_m.M] (2d channels, input of
  * memory.output), score S [N][m] (raw cosine scores), P_m [N][m] (softmax over slots, or gumbel if noise given). */

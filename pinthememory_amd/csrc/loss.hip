@@ -269,6 +269,143 @@ __global__ __launch_bounds__(256) void ce_bwd_cols_kernel(const CEGeom g, const 
   }
 }
 
+// ---- forward and the first backward pass in ONE sweep over the labels ------------------------------------------------------------
+// The forward already evaluates the softmax of every hi-res pixel; softmax - onehot is all the backward needs from the labels and the
+// up-sampled logits, and the upstream scale is a scalar that can be applied last. So the training forward leaves the column-reduced field
+//   T[b][Y][x][c] = sum over hi-res columns X of (softmax - onehot)(b, Y, X)[c] * (bilinear weight of X on low-res column x)
+// behind, and the backward is the row pass (ce_bwd_cols_kernel) alone: the labels and the logits are read once per step instead of twice.
+// Block = one hi-res row (Y, image b): the label row (as bytes) and the two low-res logit rows it interpolates between are staged in LDS.
+// Lane group (low-res column x, part p of PARTS) walks its share of the hi-res pixels whose left tap is x -- every pixel is evaluated exactly
+// once -- and keeps two weighted sums per class: A (left-tap weight, stays in column x) and B (right-tap weight, goes to column x + 1).
+// The PARTS lanes of a column are combined by a fixed butterfly, columns exchange B through LDS, and T leaves as one contiguous row.
+// Fixed association order everywhere: run-to-run deterministic.
+__device__ __forceinline__ int ce_first_ge(float sx, int k, int w, int W) {   // first hi-res column whose left tap i0 is >= k (i0 is non-decreasing)
+  if (k <= 0) return 0;
+  if (k > w - 1 || sx <= 0.f) return W;
+  int X = (int)ceilf((float)k / sx);
+  X = max(0, min(W, X));
+  while (X > 0 && pm_ac_lerp(sx, X - 1, w).i0 >= k) --X;
+  while (X < W && pm_ac_lerp(sx, X, w).i0 < k) ++X;
+  return X;
+}
+
+template <int C_, int PARTS, bool WITH_T>
+__global__ __launch_bounds__(256) void ce_fused_rows_kernel(const CEGeom g, float* __restrict__ part, float* __restrict__ T) {
+  extern __shared__ float L[];
+  __shared__ float carry[MAXC];   // B of the last column of a round, owed to the first column of the next (rows wider than one round only)
+  const int C = C_ > 0 ? C_ : g.C;
+  const int CP = C | 1;
+  const int nt = (int)blockDim.x, tid = (int)threadIdx.x;
+  const int Y = blockIdx.x % g.H, b = blockIdx.x / g.H;
+  const pm_lerp ly = pm_ac_lerp(g.sy, Y, g.h);
+  float* L0 = L;
+  float* L1 = L + (size_t)g.w * CP;                                   // (+ C floats of slack behind it: bufB holds one column more than a round)
+  unsigned char* lab8 = reinterpret_cast<unsigned char*>(L1 + (size_t)g.w * CP + C);
+  const int64_t* lrow = g.labels + ((long)b * g.H + Y) * g.W;
+  for (int X = tid; X < g.W; X += nt) {
+    const int64_t l = lrow[X];
+    lab8[X] = (l >= 0 && l < 254) ? (unsigned char)l : (l == 255 ? 255 : 254);   // 254: a label no class matches (as the unfused kernels treat it)
+  }
+  auto stage_rows = [&]() {
+    for (int i = tid; i < g.w * C; i += nt) {
+      const int xl = i / C, c = i - xl * C;
+      L0[xl * CP + c] = g.logits[((long)(b * g.h + ly.i0) * g.w + xl) * g.lp + c] * g.inv_temp;
+      L1[xl * CP + c] = g.logits[((long)(b * g.h + ly.i1) * g.w + xl) * g.lp + c] * g.inv_temp;
+    }
+  };
+  stage_rows();
+  __syncthreads();
+  constexpr int CR = C_ > 0 ? C_ : MAXC;
+  float lsum = 0.f, lcnt = 0.f;
+  const int R = nt / PARTS;                       // low-res columns per round
+  const int rounds = (g.w + R - 1) / R;
+  for (int rd = 0; rd < rounds; ++rd) {
+    if (rd > 0) {                                 // the previous round recycled the staged rows as its exchange buffers
+      __syncthreads();
+      stage_rows();
+      __syncthreads();
+    }
+    const int xr0 = rd * R, xr1 = min(g.w, xr0 + R);
+    const int x = xr0 + tid / PARTS, p = tid % PARTS;
+    const bool live = x < xr1;
+    float A[CR], B[CR];
+#pragma unroll
+    for (int c = 0; c < CR; ++c) A[c] = B[c] = 0.f;
+    if (live) {
+      const int j0 = ce_first_ge(g.sx, x, g.w, g.W), j1 = ce_first_ge(g.sx, x + 1, g.w, g.W);
+      const int per = (j1 - j0 + PARTS - 1) / PARTS;
+      const int ja = j0 + p * per, jb = min(j1, ja + per);
+      for (int X = ja; X < jb; ++X) {
+        const int lab = lab8[X];
+        if (lab == 255) continue;
+        const pm_lerp lx = pm_ac_lerp(g.sx, X, g.w);
+        const float *p00 = L0 + lx.i0 * CP, *p01 = L0 + lx.i1 * CP, *p10 = L1 + lx.i0 * CP, *p11 = L1 + lx.i1 * CP;
+        float v[CR];
+        float mx = -INFINITY, vl = 0.f;
+#pragma unroll
+        for (int c = 0; c < CR; ++c)
+          if (c < C) {
+            v[c] = ly.w0 * (lx.w0 * p00[c] + lx.w1 * p01[c]) + ly.w1 * (lx.w0 * p10[c] + lx.w1 * p11[c]);   // same expression as interp_logits
+            mx = fmaxf(mx, v[c]);
+            if (c == lab) vl = v[c];
+          }
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < CR; ++c)
+          if (c < C) v[c] = __expf(v[c] - mx), se += v[c];
+        lsum += (mx + logf(se)) - vl;
+        lcnt += 1.f;
+        if constexpr (WITH_T) {
+          const float inv = 1.f / se;
+          const float wa = lx.i1 == lx.i0 ? lx.w0 + lx.w1 : lx.w0, wb = lx.i1 == lx.i0 ? 0.f : lx.w1;
+#pragma unroll
+          for (int c = 0; c < CR; ++c)
+            if (c < C) {
+              const float gq = v[c] * inv - (c == lab ? 1.f : 0.f);
+              A[c] += wa * gq, B[c] += wb * gq;
+            }
+        }
+      }
+    }
+    if constexpr (WITH_T) {
+      if constexpr (PARTS > 1) {
+#pragma unroll
+        for (int o = 1; o < PARTS; o <<= 1)
+#pragma unroll
+          for (int c = 0; c < CR; ++c)
+            if (c < C) A[c] += __shfl_xor(A[c], o, 64), B[c] += __shfl_xor(B[c], o, 64);
+      }
+      __syncthreads();                            // every lane is done with the staged rows: they become the exchange buffers
+      float* bufA = L0;                           // A of column x         -> bufA[x - xr0]
+      float* bufB = L1;                           // B of column x (owed to column x + 1) -> bufB[x - xr0 + 1]; bufB[0] = carry of the previous round
+      if (live && p == 0) {
+#pragma unroll
+        for (int c = 0; c < CR; ++c)
+          if (c < C) {
+            bufA[(x - xr0) * C + c] = A[c];
+            bufB[(x - xr0 + 1) * C + c] = B[c];
+          }
+      }
+      if (tid < C) bufB[tid] = rd == 0 ? 0.f : carry[tid];
+      __syncthreads();
+      float* Trow = T + (((long)b * g.H + Y) * g.w + xr0) * C;
+      for (int i = tid; i < (xr1 - xr0) * C; i += nt) Trow[i] = bufB[i] + bufA[i];
+      if (tid < C) carry[tid] = bufB[(xr1 - xr0) * C + tid];
+    }
+  }
+  __shared__ float sm[2][4];
+  lsum = pm_wave_sum(lsum);
+  lcnt = pm_wave_sum(lcnt);
+  if ((tid & 63) == 0) sm[0][tid >> 6] = lsum, sm[1][tid >> 6] = lcnt;
+  __syncthreads();
+  if (tid == 0) {
+    float a = 0.f, c = 0.f;
+    for (int wv = 0; wv < (nt >> 6); ++wv) a += sm[0][wv], c += sm[1][wv];
+    part[blockIdx.x * 2] = a;
+    part[blockIdx.x * 2 + 1] = c;
+  }
+}
+
 // low-res columns per pass-1 block: ~256 hi-res columns of support, LDS bounded by 60 KB
 inline int bwd_seg(const CEGeom& g, int& max_nx) {
   int xw = g.sx > 0.f ? std::max(1, std::min(g.w, (int)(256.f * g.sx))) : g.w;
@@ -358,3 +495,73 @@ extern "C" int pm_upsample_ce_bwd(const pm_tensor* logits, float inv_temp, const
                      (float*)dlogits->ptr, (long)dlogits->pitch);
   return pm_check_launch("upsample_ce_bwd");
 }
+
+// ---- fused forward + first backward pass (training forward: the logits carry a graph) -------------------------------------------------
+namespace {
+struct FusedPlan {
+  int parts, threads;
+  size_t lds;
+};
+inline FusedPlan fused_plan(const CEGeom& g) {
+  FusedPlan p;
+  // ~4 hi-res pixels per lane: PARTS lanes share a low-res column when the up-sampling ratio is large (the read loss: 768 / 48 = 16)
+  const int ratio = std::max(1, g.W / std::max(1, g.w));
+  p.parts = 1;
+  while (p.parts < 16 && p.parts * 8 <= ratio && g.w * p.parts * 2 <= 256) p.parts *= 2;
+  p.threads = std::min(256, std::max(64, (g.w * p.parts + 63) / 64 * 64));
+  p.lds = ((size_t)2 * g.w * (g.C | 1) + g.C) * sizeof(float) + (size_t)(g.W + 15) / 16 * 16;
+  return p;
+}
+template <bool WITH_T>
+int fused_launch(const CEGeom& g, const FusedPlan& p, float* part, float* T, hipStream_t st) {
+  const dim3 grid(g.n * g.H), blk(p.threads);
+#define PM_CE_LAUNCH(CC, PP) hipLaunchKernelGGL((ce_fused_rows_kernel<CC, PP, WITH_T>), grid, blk, p.lds, st, g, part, T)
+#define PM_CE_PARTS(CC)                         \
+  switch (p.parts) {                            \
+    case 1: PM_CE_LAUNCH(CC, 1); break;         \
+    case 2: PM_CE_LAUNCH(CC, 2); break;         \
+    case 4: PM_CE_LAUNCH(CC, 4); break;         \
+    case 8: PM_CE_LAUNCH(CC, 8); break;         \
+    default: PM_CE_LAUNCH(CC, 16); break;       \
+  }
+  if (g.C == 19) {
+    PM_CE_PARTS(19)
+  } else {
+    PM_CE_PARTS(0)
+  }
+#undef PM_CE_PARTS
+#undef PM_CE_LAUNCH
+  return pm_check_launch("upsample_ce_fused");
+}
+}  // namespace
+
+extern "C" size_t pm_upsample_ce_field_bytes(const pm_tensor* logits, int H, int W) {
+  (void)W;
+  return (size_t)logits->n * H * logits->w * logits->c * sizeof(float);
+}
+
+extern "C" int pm_upsample_ce_fwd_field(const pm_tensor* logits, float inv_temp, const int64_t* labels, int H, int W, float* loss_out, float* field,
+                                        void* ws, size_t ws_bytes, void* stream) {
+  CEGeom g;
+  if (int e = fill(g, logits, inv_temp, labels, H, W, "upsample_ce_fwd_field")) return e;
+  PM_REQUIRE(loss_out && field && ws && ws_bytes >= pm_upsample_ce_workspace(g.n, H, W), PM_EWORKSPACE, "upsample_ce_fwd_field: workspace too small / null field");
+  const FusedPlan p = fused_plan(g);
+  PM_REQUIRE(p.lds <= 64 * 1024 && (long)g.n * H <= (1l << 30), PM_EUNSUPPORTED, "upsample_ce_fwd_field: logit rows of %d x %d classes do not fit LDS", g.w, g.C);
+  hipStream_t st = (hipStream_t)stream;
+  if (int e = fused_launch<true>(g, p, (float*)ws, field, st)) return e;
+  hipLaunchKernelGGL(ce_final_kernel, dim3(1), dim3(CE_FINAL_T), 0, st, (const float*)ws, g.n * H, loss_out);
+  return pm_check_launch("upsample_ce_fwd_field");
+}
+
+extern "C" int pm_upsample_ce_bwd_field(const pm_tensor* logits, float inv_temp, int H, int W, const float* loss_out, const float* gscale, const float* field,
+                                        const pm_tensor* dlogits, void* stream) {
+  CEGeom g;
+  static const int64_t dummy = 0;
+  if (int e = fill(g, logits, inv_temp, &dummy, H, W, "upsample_ce_bwd_field")) return e;      // the row pass reads neither labels nor logits
+  PM_REQUIRE(loss_out && field && dlogits && dlogits->ptr && pm_same_shape(logits, dlogits), PM_EINVAL, "upsample_ce_bwd_field: bad args");
+  const long total = (long)g.n * g.h * g.w * g.C;
+  hipLaunchKernelGGL(ce_bwd_cols_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 1 << 20)), dim3(256), 0, (hipStream_t)stream, g, field, loss_out,
+                     gscale, (float*)dlogits->ptr, (long)dlogits->pitch);
+  return pm_check_launch("upsample_ce_bwd_field");
+}
+

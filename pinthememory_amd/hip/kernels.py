@@ -505,6 +505,27 @@ def upsample_ce_bwd(logits, labels, loss_out, gscale, inv_temp=1.0):
     return dl
 
 
+def upsample_ce_fwd_field(logits, labels, inv_temp=1.0):
+    """Training forward: -> (loss_out[2], field). The field is what upsample_ce_bwd_field needs instead of a second sweep over labels and logits."""
+    n, H, W = labels.shape
+    out = torch.empty(2, dtype=torch.float32, device=logits.device)
+    lib, ld = _lib(), tdesc(logits)
+    field = torch.empty(lib.pm_upsample_ce_field_bytes(byref(ld), H, W) // 4, dtype=torch.float32, device=logits.device)
+    nb = lib.pm_upsample_ce_workspace(n, H, W)
+    ws = workspace(nb, logits.device)
+    check(lib.pm_upsample_ce_fwd_field(byref(ld), inv_temp, labels.data_ptr(), H, W, out.data_ptr(), field.data_ptr(), ptr(ws), nb, stream()),
+          'pm_upsample_ce_fwd_field')
+    return out, field
+
+
+def upsample_ce_bwd_field(logits, label_hw, loss_out, field, gscale, inv_temp=1.0):
+    H, W = label_hw
+    dl = new(tuple(logits.shape), logits, pitch_pad=(logits.stride(2) != logits.shape[3]))   # same pitch as the logits
+    check(_lib().pm_upsample_ce_bwd_field(byref(tdesc(logits)), inv_temp, H, W, loss_out.data_ptr(), ptr(gscale), field.data_ptr(), byref(tdesc(dl)), stream()),
+          'pm_upsample_ce_bwd_field')
+    return dl
+
+
 # ---- memory ---------------------------------------------------------------------------------------------------------
 def mem_read_fwd(x, mem, noise=None):
     n, h, w, d = x.shape

@@ -446,22 +446,36 @@ def fanout(x, n):
     return _Fanout.apply(x, n)
 
 
+CE_FUSED = _os.environ.get('PM_CE_FUSED', '1') == '1'      # A/B knob: 0 = forward and backward each sweep labels and logits
+
+
 class _UpsampleCE(torch.autograd.Function):
-    """mean CE(ignore 255) of bilinearly up-sampled logits vs full-resolution labels, logits never materialised."""
+    """mean CE(ignore 255) of bilinearly up-sampled logits vs full-resolution labels, logits never materialised. With a graph attached the
+    forward also leaves the column-reduced gradient field (K.upsample_ce_fwd_field), so the backward is one short row pass."""
 
     @staticmethod
-    def forward(ctx, logits, labels, inv_temp):
+    def forward(ctx, logits, labels, inv_temp, want_grad):
         lv = nhwc(logits)
         labels = labels.contiguous()
-        out = K.upsample_ce_fwd(lv, labels, inv_temp)
-        ctx.inv_temp = inv_temp
-        ctx.save_for_backward(lv, labels, out)
+        ctx.inv_temp, ctx.hw = inv_temp, tuple(labels.shape[1:])
+        if want_grad and CE_FUSED:
+            out, field = K.upsample_ce_fwd_field(lv, labels, inv_temp)
+            ctx.fused = True
+            ctx.save_for_backward(lv, out, field)
+        else:
+            out = K.upsample_ce_fwd(lv, labels, inv_temp)
+            ctx.fused = False
+            ctx.save_for_backward(lv, labels, out)
         return out[0]
 
     @staticmethod
     def backward(ctx, g):
+        gs = g.reshape(1).float().contiguous()
+        if ctx.fused:
+            lv, out, field = ctx.saved_tensors
+            return nchw(K.upsample_ce_bwd_field(lv, ctx.hw, out, field, gs, ctx.inv_temp)), None, None, None
         lv, labels, out = ctx.saved_tensors
-        return nchw(K.upsample_ce_bwd(lv, labels, out, g.reshape(1).float().contiguous(), ctx.inv_temp)), None, None
+        return nchw(K.upsample_ce_bwd(lv, labels, out, gs, ctx.inv_temp)), None, None, None
 
 
 class _MemRead(torch.autograd.Function):
@@ -588,7 +602,7 @@ def add(a, b):
 
 
 def upsample_ce(logits, labels, inv_temp=1.0):
-    return _UpsampleCE.apply(logits, labels, float(inv_temp))
+    return _UpsampleCE.apply(logits, labels, float(inv_temp), bool(torch.is_grad_enabled() and logits.requires_grad))
 
 
 def mem_read(x, mem, noise=None):

@@ -394,7 +394,7 @@ def test_layout_and_labels(K):
 
 @pytest.mark.parametrize('hw,HW,temp,C', [((12, 12), (48, 48), 1.0, 19), ((6, 6), (96, 96), 0.5, 19), ((16, 16), (16, 16), 1.0, 19), ((5, 7), (33, 29), 2.0, 19),
                                           ((1, 1), (8, 8), 1.0, 19), ((24, 24), (384, 384), 0.07, 19), ((9, 9), (4, 6), 1.0, 19), ((7, 5), (30, 41), 1.0, 8),
-                                          ((192, 48), (768, 192), 1.0, 19)])
+                                          ((192, 48), (768, 192), 1.0, 19), ((3, 300), (7, 611), 1.0, 19), ((2, 130), (5, 2100), 1.0, 19), ((4, 4), (4, 700), 1.0, 5)])
 def test_upsample_ce(K, hw, HW, temp, C):
     n = 2
     lg = rnd(n, C, *hw, seed=1) * 3
@@ -413,6 +413,13 @@ def test_upsample_ce(K, hw, HW, temp, C):
     assert out[1].item() == (lab != 255).sum().item()
     dl = K.upsample_ce_bwd(lgg, labg, out, torch.tensor([1.7], device='cuda'), 1.0 / temp)
     assert rel(nchw(dl), lr.grad) < 2e-5
+    # the training forward that leaves the column-reduced gradient field behind + the row-pass-only backward (one sweep over the labels per step)
+    out_f, field = K.upsample_ce_fwd_field(lgg, labg, 1.0 / temp)
+    assert abs(out_f[0].item() - loss_ref.item()) < 2e-6 * max(1, abs(loss_ref.item())) and out_f[1].item() == out[1].item()
+    dlf = K.upsample_ce_bwd_field(lgg, HW, out_f, field, torch.tensor([1.7], device='cuda'), 1.0 / temp)
+    assert rel(nchw(dlf), lr.grad) < 2e-5 and rel(dlf, dl) < 1e-5
+    out_f2, field2 = K.upsample_ce_fwd_field(lgg, labg, 1.0 / temp)
+    assert torch.equal(out_f, out_f2) and torch.equal(field, field2)                       # fixed association order: run-to-run deterministic
     # edge cases of the reference's criterion (CrossEntropyLoss(ignore_index=255), loss.py:38-39): one image with every pixel ignored
     # contributes nothing; a batch with every pixel ignored gives NaN (0 / 0) exactly as torch does, and a valid-pixel count of zero
     lab1 = lab.clone()
@@ -424,6 +431,11 @@ def test_upsample_ce(K, hw, HW, temp, C):
     assert nchw(dl1)[0].abs().max().item() == 0.0                      # no gradient into the fully ignored image
     out0 = K.upsample_ce_fwd(lgg, torch.full_like(lab, 255).cuda(), 1.0 / temp)
     assert torch.isnan(out0[0]).item() and out0[1].item() == 0
+    o1f, f1 = K.upsample_ce_fwd_field(lgg, lab1.cuda(), 1.0 / temp)
+    assert abs(o1f[0].item() - ref1.item()) < 2e-6 * max(1, abs(ref1.item())) and o1f[1].item() == out1[1].item()
+    assert nchw(K.upsample_ce_bwd_field(lgg, HW, o1f, f1, None, 1.0 / temp))[0].abs().max().item() == 0.0
+    o0f, _ = K.upsample_ce_fwd_field(lgg, torch.full_like(lab, 255).cuda(), 1.0 / temp)
+    assert torch.isnan(o0f[0]).item() and o0f[1].item() == 0
 
 
 def test_memory_read(K):
