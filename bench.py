@@ -482,6 +482,22 @@ def main():
             out['config']['input_edge'] = edge
             out['data'] = 'synthetic, fresh uint8 batch from pinned host memory every step (PCIe-inclusive side measurement)'
         if roof is not None:
+            # the whole step against both rooflines, on EXECUTED FLOPs (2*M*N*K of every launch: the Winograd layers count their reduced work)
+            # and on the fabric traffic of the committed counter passes -- step_mfma_frac above is a direct-algorithm-equivalent rate, not utilisation
+            ex_tf = tot_fl / prof_steps / 1e12
+            step = {'executed_tflop': round(ex_tf, 3), 'mfma_frac_executed': round(ex_tf / (dt / a.steps) / peak, 4),
+                    'hbm_GB': None, 'hbm_frac': None, 'hbm_source': None}
+            try:
+                import glob
+                pj = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_1gpu%s_hbm_counters.json' % ('_bf16' if bf16 else ''))))[-1]
+                cj = json.load(open(pj))
+                gb = (cj['total_read_GB'] + cj['total_write_GB']) / float(cj.get('steps_counted', 2))
+                step.update(hbm_GB=round(gb, 1), hbm_frac=round(gb / (dt / a.steps) / PEAK_HBM_GBPS, 4),
+                            hbm_source='profiles/' + os.path.basename(pj) + ' (FETCH_SIZE x 2 + WRITE_SIZE over all kernels of the counted steps, separate --pmc passes), '
+                                       'divided by this run\'s step time and the 8 TB/s peak')
+            except (OSError, KeyError, ValueError, IndexError):
+                pass
+            roof['step'] = step
             try:
                 roof['memory_read'] = memory_path_roofline(a.batch, a.size)
             except Exception as e:      # noqa: BLE001 -- the metric line must not depend on the side measurement

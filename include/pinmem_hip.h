@@ -31,8 +31,11 @@ typedef struct pm_tensor {      /* NHWC fp32 activation view */
 
 typedef struct pm_conv_params { /* nn.Conv2d geometry (square kernels/strides as used by the reference) */
   int32_t kh, kw, stride, pad, dil;
-  int32_t prec;                 /* 0: fp32 MFMA (exact fp32 chain, parity path); 1: operands rounded to bf16 for
-                                   v_mfma_f32_32x32x16_bf16, fp32 accumulate and storage (BASELINE configs[2]) */
+  int32_t prec;                 /* 0: fp32 MFMA (exact fp32 chain, parity path, BASELINE configs[1]);
+                                   1: fp32 tiles staged in LDS, rounded to bf16 per fragment for v_mfma_f32_32x32x16_bf16, fp32 accumulate and storage;
+                                   2: BASELINE configs[2] -- operands converted to bf16 in HBM (one streaming pass) and bf16 tiles in LDS, fp32
+                                      accumulate and storage; call sites the form does not cover (3-channel stem, 19-class heads, stride-2 data
+                                      gradients, weight gradients) run as prec 1 */
   void* wino_v;                 /* optional caller-owned buffer for the Winograd-transformed input of this convolution (NULL: none).
                                    pm_conv_fwd writes it there instead of its workspace; pm_conv_bwd_weight then reads it instead of
                                    transforming x again. Size from pm_conv_winograd_v_bytes (0 = the layer does not take the route). */

@@ -166,89 +166,6 @@ __host__ __device__ __forceinline__ void support(float scale, int i, int out, in
 }
 __device__ __forceinline__ float tap_weight(const pm_lerp& l, int i) { return (l.i0 == i ? l.w0 : 0.f) + (l.i1 == i ? l.w1 : 0.f); }
 
-// pass 1: block = (low-res column segment [x0, x0 + XW), hi-res row Y, image b). Phase A: one thread per hi-res pixel of the
-// segment's support computes softmax - onehot (0 for ignored pixels) into LDS. Phase B: one thread per (low-res column, class) sums
-// its supporting hi-res columns in ascending order.
-template <int C_>
-__global__ __launch_bounds__(256) void ce_bwd_rows_kernel(const CEGeom g, int XW, int max_nx, int max_nl, float* __restrict__ T) {
-  extern __shared__ float G[];
-  const int C = C_ > 0 ? C_ : g.C;
-  const int CP = C | 1;   // odd pitch: conflict-free LDS rows
-  const int x0 = blockIdx.x * XW, x1 = min(g.w, x0 + XW);
-  const int Y = blockIdx.y, b = blockIdx.z;
-  int Xlo, Xhi, tmp;
-  support(g.sx, x0, g.W, Xlo, tmp);
-  support(g.sx, x1 - 1, g.W, tmp, Xhi);
-  const int nX = Xhi - Xlo + 1;
-  const pm_lerp ly = pm_ac_lerp(g.sy, Y, g.h);
-  // the two low-res logit rows this hi-res row interpolates between, columns [xa, xb], staged once (coalesced) and pre-scaled by 1/T:
-  // the per-pixel gathers below then hit LDS instead of issuing 4 x C scattered global loads per thread
-  const int xa = pm_ac_lerp(g.sx, Xlo, g.w).i0, xb = pm_ac_lerp(g.sx, Xhi, g.w).i1;
-  const int nL = xb - xa + 1;
-  float* L0 = G + (size_t)max_nx * CP;
-  float* L1 = L0 + (size_t)nL * CP;
-  float* TW = G + ((size_t)max_nx + 2 * (size_t)max_nl) * CP;   // per hi-res column: low-res index i0 (as float), weights w0, w1
-  int* first = reinterpret_cast<int*>(TW + 3 * (size_t)max_nx);   // first[k]: first staged hi-res column whose i0 >= x0 - 1 + k, k in [0, XW + 2]
-  for (int k = threadIdx.x; k < XW + 3; k += 256) first[k] = nX;
-  // labels of this thread's (up to three) hi-res pixels: requested now, so that they arrive while the logit rows are being staged
-  const int64_t* lrow = g.labels + ((long)b * g.H + Y) * g.W + Xlo;
-  int64_t labs[3];
-#pragma unroll
-  for (int u = 0; u < 3; ++u) labs[u] = (int)threadIdx.x + 256 * u < nX ? lrow[threadIdx.x + 256 * u] : 255;
-  for (int i = threadIdx.x; i < nL * C; i += 256) {
-    const int xl = i / C, c = i - xl * C;
-    L0[xl * CP + c] = g.logits[((long)(b * g.h + ly.i0) * g.w + xa + xl) * g.lp + c] * g.inv_temp;
-    L1[xl * CP + c] = g.logits[((long)(b * g.h + ly.i1) * g.w + xa + xl) * g.lp + c] * g.inv_temp;
-  }
-  __syncthreads();
-  for (int j = threadIdx.x, u = 0; j < nX; j += 256, ++u) {
-    const int X = Xlo + j;
-    const int64_t lab = u < 3 ? (u == 0 ? labs[0] : (u == 1 ? labs[1] : labs[2])) : lrow[j];
-    float* out = G + j * CP;
-    const pm_lerp lx = pm_ac_lerp(g.sx, X, g.w);
-    TW[3 * j] = (float)lx.i0, TW[3 * j + 1] = lx.i1 == lx.i0 ? lx.w0 + lx.w1 : lx.w0, TW[3 * j + 2] = lx.i1 == lx.i0 ? 0.f : lx.w1;
-    {   // i0 is non-decreasing in X: column j opens the range of every low-res index in (i0(j - 1), i0(j)]
-      const int prev = j == 0 ? x0 - 2 : pm_ac_lerp(g.sx, X - 1, g.w).i0;
-      for (int xx = max(prev + 1, x0 - 1); xx <= min(lx.i0, x0 + XW + 1); ++xx) first[xx - (x0 - 1)] = j;
-    }
-    if (lab == 255) {
-#pragma unroll
-      for (int c = 0; c < (C_ > 0 ? C_ : MAXC); ++c)
-        if (c < C) out[c] = 0.f;
-      continue;
-    }
-    const float *p00 = L0 + (lx.i0 - xa) * CP, *p01 = L0 + (lx.i1 - xa) * CP, *p10 = L1 + (lx.i0 - xa) * CP, *p11 = L1 + (lx.i1 - xa) * CP;
-    float v[C_ > 0 ? C_ : MAXC];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int c = 0; c < (C_ > 0 ? C_ : MAXC); ++c)
-      if (c < C) {
-        v[c] = ly.w0 * (lx.w0 * p00[c] + lx.w1 * p01[c]) + ly.w1 * (lx.w0 * p10[c] + lx.w1 * p11[c]);   // same expression as interp_logits
-        mx = fmaxf(mx, v[c]);
-      }
-    float se = 0.f;
-#pragma unroll
-    for (int c = 0; c < (C_ > 0 ? C_ : MAXC); ++c)
-      if (c < C) v[c] = __expf(v[c] - mx), se += v[c];   // v_exp_f32: ~2e-6 relative on the probabilities, well inside the gradient tolerance; 40 % of this kernel's ALU work otherwise
-    const float inv = 1.f / se;
-#pragma unroll
-    for (int c = 0; c < (C_ > 0 ? C_ : MAXC); ++c)
-      if (c < C) out[c] = v[c] * inv - (c == (int)lab ? 1.f : 0.f);
-  }
-  __syncthreads();
-  const int nout = (x1 - x0) * C;
-  for (int o = threadIdx.x; o < nout; o += 256) {
-    const int xl = o / C, c = o - xl * C, x = x0 + xl;
-    // low-res column x collects w1 of the hi-res columns with i0 == x - 1, then w0 of those with i0 == x: two contiguous runs, walked in
-    // ascending order (the same order and the same products as a scan over the whole support with zero weights elsewhere)
-    const int j0 = first[xl], j1 = first[xl + 1], j2 = first[xl + 2];
-    float acc = 0.f;
-    for (int j = j0; j < j1; ++j) acc += TW[3 * j + 2] * G[j * CP + c];
-    for (int j = j1; j < j2; ++j) acc += TW[3 * j + 1] * G[j * CP + c];
-    T[(((long)b * g.H + Y) * g.w + x) * C + c] = acc;
-  }
-}
-
 // pass 2: thread per (low-res pixel, class): supporting hi-res rows in ascending order, then the loss scale
 __global__ __launch_bounds__(256) void ce_bwd_cols_kernel(const CEGeom g, const float* __restrict__ T, const float* __restrict__ loss_out,
                                                           const float* __restrict__ gscale, float* __restrict__ dl, long dlp) {
@@ -406,23 +323,6 @@ __global__ __launch_bounds__(256) void ce_fused_rows_kernel(const CEGeom g, floa
   }
 }
 
-// low-res columns per pass-1 block: ~256 hi-res columns of support, LDS bounded by 60 KB
-inline int bwd_seg(const CEGeom& g, int& max_nx) {
-  int xw = g.sx > 0.f ? std::max(1, std::min(g.w, (int)(256.f * g.sx))) : g.w;
-  const int cp = g.C | 1;
-  for (;;) {
-    max_nx = 0;
-    for (int x0 = 0; x0 < g.w; x0 += xw) {
-      int lo, hi, tmp;
-      support(g.sx, x0, g.W, lo, tmp);
-      support(g.sx, std::min(g.w, x0 + xw) - 1, g.W, tmp, hi);
-      max_nx = std::max(max_nx, hi - lo + 1);
-    }
-    if ((((size_t)max_nx + 2 * (size_t)(xw + 3)) * cp + 3 * (size_t)max_nx + (size_t)xw + 3) * sizeof(float) <= 60 * 1024 || xw == 1) return xw;
-    xw = std::max(1, xw / 2);
-  }
-}
-
 inline int fwd_blocks(long total) { return (int)std::min<long>((total + 255) / 256, 4096); }
 
 int fill(CEGeom& g, const pm_tensor* logits, float inv_temp, const int64_t* labels, int H, int W, const char* who) {
@@ -461,41 +361,6 @@ extern "C" int pm_upsample_ce_fwd(const pm_tensor* logits, float inv_temp, const
   return pm_check_launch("upsample_ce_fwd");
 }
 
-extern "C" size_t pm_upsample_ce_bwd_workspace(const pm_tensor* logits, int H, int W) {
-  (void)W;
-  return pm_align_up((size_t)logits->n * H * logits->w * logits->c * sizeof(float), 256);
-}
-
-extern "C" int pm_upsample_ce_bwd(const pm_tensor* logits, float inv_temp, const int64_t* labels, int H, int W, const float* loss_out, const float* gscale,
-                                  const pm_tensor* dlogits, void* ws, size_t ws_bytes, void* stream) {
-  CEGeom g;
-  if (int e = fill(g, logits, inv_temp, labels, H, W, "upsample_ce_bwd")) return e;
-  PM_REQUIRE(loss_out && dlogits && dlogits->ptr && pm_same_shape(logits, dlogits), PM_EINVAL, "upsample_ce_bwd: bad args");
-  PM_REQUIRE(ws && ws_bytes >= pm_upsample_ce_bwd_workspace(logits, H, W), PM_EWORKSPACE, "upsample_ce_bwd: workspace too small");
-  PM_REQUIRE(H <= 65535 && g.n <= 65535, PM_EUNSUPPORTED, "upsample_ce_bwd: H or batch > 65535");
-  int max_nx = 0;
-  const int xw = bwd_seg(g, max_nx);
-  int max_nl = 0;   // widest low-res column range one segment interpolates from (same index math as pm_ac_lerp)
-  auto lo_i0 = [&](int X) { return std::min((int)(g.sx * (float)X), g.w - 1); };
-  for (int x0 = 0; x0 < g.w; x0 += xw) {
-    int lo, hi, tmp;
-    support(g.sx, x0, g.W, lo, tmp);
-    support(g.sx, std::min(g.w, x0 + xw) - 1, g.W, tmp, hi);
-    const int xa = lo_i0(lo), xb = std::min(lo_i0(hi) + 1, g.w - 1);
-    max_nl = std::max(max_nl, xb - xa + 1);
-  }
-  const size_t lds = (((size_t)max_nx + 2 * (size_t)max_nl) * (g.C | 1) + 3 * (size_t)max_nx + (size_t)xw + 3) * sizeof(float);
-  PM_REQUIRE(lds <= 64 * 1024, PM_EUNSUPPORTED, "upsample_ce_bwd: one low-res column is supported by %d hi-res columns (LDS)", max_nx);
-  hipStream_t st = (hipStream_t)stream;
-  dim3 grid(pm_cdiv(g.w, xw), H, g.n);
-  if (g.C == 19) hipLaunchKernelGGL(ce_bwd_rows_kernel<19>, grid, dim3(256), lds, st, g, xw, max_nx, max_nl, (float*)ws);
-  else hipLaunchKernelGGL(ce_bwd_rows_kernel<0>, grid, dim3(256), lds, st, g, xw, max_nx, max_nl, (float*)ws);
-  const long total = (long)g.n * g.h * g.w * g.C;
-  hipLaunchKernelGGL(ce_bwd_cols_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 1 << 20)), dim3(256), 0, st, g, (const float*)ws, loss_out, gscale,
-                     (float*)dlogits->ptr, (long)dlogits->pitch);
-  return pm_check_launch("upsample_ce_bwd");
-}
-
 // ---- fused forward + first backward pass (training forward: the logits carry a graph) -------------------------------------------------
 namespace {
 struct FusedPlan {
@@ -512,10 +377,19 @@ inline FusedPlan fused_plan(const CEGeom& g) {
   p.lds = ((size_t)2 * g.w * (g.C | 1) + g.C) * sizeof(float) + (size_t)(g.W + 15) / 16 * 16;
   return p;
 }
+constexpr size_t FUSED_MAX_LDS = 160 * 1024 - 512;
+template <int CC, int PP, bool WITH_T>
+void fused_launch_one(const CEGeom& g, const FusedPlan& p, float* part, float* T, hipStream_t st) {
+  static const bool attr_set = [] {   // > 64 KB of dynamic LDS (logit rows wider than ~420 pixels x 19 classes) needs an explicit opt-in, once per kernel
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ce_fused_rows_kernel<CC, PP, WITH_T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return true;
+  }();
+  (void)attr_set;
+  hipLaunchKernelGGL((ce_fused_rows_kernel<CC, PP, WITH_T>), dim3(g.n * g.H), dim3(p.threads), p.lds, st, g, part, T);
+}
 template <bool WITH_T>
 int fused_launch(const CEGeom& g, const FusedPlan& p, float* part, float* T, hipStream_t st) {
-  const dim3 grid(g.n * g.H), blk(p.threads);
-#define PM_CE_LAUNCH(CC, PP) hipLaunchKernelGGL((ce_fused_rows_kernel<CC, PP, WITH_T>), grid, blk, p.lds, st, g, part, T)
+#define PM_CE_LAUNCH(CC, PP) fused_launch_one<CC, PP, WITH_T>(g, p, part, T, st)
 #define PM_CE_PARTS(CC)                         \
   switch (p.parts) {                            \
     case 1: PM_CE_LAUNCH(CC, 1); break;         \
@@ -546,7 +420,7 @@ extern "C" int pm_upsample_ce_fwd_field(const pm_tensor* logits, float inv_temp,
   if (int e = fill(g, logits, inv_temp, labels, H, W, "upsample_ce_fwd_field")) return e;
   PM_REQUIRE(loss_out && field && ws && ws_bytes >= pm_upsample_ce_workspace(g.n, H, W), PM_EWORKSPACE, "upsample_ce_fwd_field: workspace too small / null field");
   const FusedPlan p = fused_plan(g);
-  PM_REQUIRE(p.lds <= 64 * 1024 && (long)g.n * H <= (1l << 30), PM_EUNSUPPORTED, "upsample_ce_fwd_field: logit rows of %d x %d classes do not fit LDS", g.w, g.C);
+  PM_REQUIRE(p.lds <= FUSED_MAX_LDS && (long)g.n * H <= (1l << 30), PM_EUNSUPPORTED, "upsample_ce_fwd_field: logit rows of %d x %d classes do not fit LDS", g.w, g.C);
   hipStream_t st = (hipStream_t)stream;
   if (int e = fused_launch<true>(g, p, (float*)ws, field, st)) return e;
   hipLaunchKernelGGL(ce_final_kernel, dim3(1), dim3(CE_FINAL_T), 0, st, (const float*)ws, g.n * H, loss_out);
@@ -563,5 +437,25 @@ extern "C" int pm_upsample_ce_bwd_field(const pm_tensor* logits, float inv_temp,
   hipLaunchKernelGGL(ce_bwd_cols_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 1 << 20)), dim3(256), 0, (hipStream_t)stream, g, field, loss_out,
                      gscale, (float*)dlogits->ptr, (long)dlogits->pitch);
   return pm_check_launch("upsample_ce_bwd_field");
+}
+
+// Backward without a field from the forward (the caller ran pm_upsample_ce_fwd): the field is rebuilt into the workspace by the same fused sweep
+// (its loss partials are discarded), then the row pass. Same results as pm_upsample_ce_fwd_field + pm_upsample_ce_bwd_field.
+extern "C" size_t pm_upsample_ce_bwd_workspace(const pm_tensor* logits, int H, int W) {
+  return pm_align_up(pm_upsample_ce_field_bytes(logits, H, W), 256) + pm_upsample_ce_workspace(logits->n, H, W);
+}
+
+extern "C" int pm_upsample_ce_bwd(const pm_tensor* logits, float inv_temp, const int64_t* labels, int H, int W, const float* loss_out, const float* gscale,
+                                  const pm_tensor* dlogits, void* ws, size_t ws_bytes, void* stream) {
+  CEGeom g;
+  if (int e = fill(g, logits, inv_temp, labels, H, W, "upsample_ce_bwd")) return e;
+  PM_REQUIRE(loss_out && dlogits && dlogits->ptr && pm_same_shape(logits, dlogits), PM_EINVAL, "upsample_ce_bwd: bad args");
+  PM_REQUIRE(ws && ws_bytes >= pm_upsample_ce_bwd_workspace(logits, H, W), PM_EWORKSPACE, "upsample_ce_bwd: workspace too small");
+  const FusedPlan p = fused_plan(g);
+  PM_REQUIRE(p.lds <= FUSED_MAX_LDS, PM_EUNSUPPORTED, "upsample_ce_bwd: logit rows of %d x %d classes do not fit LDS", g.w, g.C);
+  float* field = (float*)ws;
+  float* part = (float*)((char*)ws + pm_align_up(pm_upsample_ce_field_bytes(logits, H, W), 256));
+  if (int e = fused_launch<true>(g, p, part, field, (hipStream_t)stream)) return e;
+  return pm_upsample_ce_bwd_field(logits, inv_temp, H, W, loss_out, gscale, field, dlogits, stream);
 }
 
