@@ -377,11 +377,11 @@ inline FusedPlan fused_plan(const CEGeom& g) {
   p.lds = ((size_t)2 * g.w * (g.C | 1) + g.C) * sizeof(float) + (size_t)(g.W + 15) / 16 * 16;
   return p;
 }
-constexpr size_t FUSED_MAX_LDS = 160 * 1024 - 512;
+constexpr size_t FUSED_MAX_LDS = 159 * 1024;   // dynamic part; the kernel also declares 160 B of static LDS
 template <int CC, int PP, bool WITH_T>
 void fused_launch_one(const CEGeom& g, const FusedPlan& p, float* part, float* T, hipStream_t st) {
   static const bool attr_set = [] {   // > 64 KB of dynamic LDS (logit rows wider than ~420 pixels x 19 classes) needs an explicit opt-in, once per kernel
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ce_fused_rows_kernel<CC, PP, WITH_T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ce_fused_rows_kernel<CC, PP, WITH_T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_MAX_LDS);
     return true;
   }();
   (void)attr_set;

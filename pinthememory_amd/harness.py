@@ -128,9 +128,29 @@ def sliding_logits(net, img, crop, overlap=1.0 / 3, flips=(False, True), batch_t
             src = torch.flip(img, dims=[2]) if flip else img
             crops = torch.stack([src[:, y1:y2, x1:x2] for (x1, y1, x2, y2) in tiles])
             outs = net(crops)[0] if batch_tiles else torch.cat([net(cr[None])[0] for cr in crops])   # eval.py:379-390 (--faster batches)
-            # one kernel per flip: float64 sum of the covering tiles (tile order) / count, written un-flipped into the accumulator
-            acc = K.sliding_stitch(ops.nhwc(outs), tiles, h, w, flip, acc)
+            if len(tiles) <= STITCH_MAX_TILES and outs.is_cuda:
+                # one kernel per flip: float64 sum of the covering tiles (tile order) / count, written un-flipped into the accumulator
+                acc = K.sliding_stitch(ops.nhwc(outs), tiles, h, w, flip, acc)
+            else:
+                acc = _stitch_torch(outs, tiles, h, w, flip, acc)
     return acc / len(flips)
+
+
+STITCH_MAX_TILES = 64      # pm_sliding_stitch takes the tile table by value in its kernel arguments
+
+
+def _stitch_torch(outs, tiles, h, w, flip, acc):
+    """The same stitching in stock float64 torch ops for what the kernel does not take: more than 64 tiles per image (a 1024 x 2048 image at
+    crop 256 has 72) -- same sums in the same tile order, the same division by the true count, the same un-flip."""
+    full = torch.zeros(outs.shape[1], h, w, dtype=torch.float64, device=outs.device)
+    cnt = torch.zeros(1, h, w, dtype=torch.float64, device=outs.device)
+    for lg, (x1, y1, x2, y2) in zip(outs, tiles):
+        full[:, y1:y2, x1:x2] += lg.to(torch.float64)
+        cnt[:, y1:y2, x1:x2] += 1
+    full = full / cnt
+    if flip:
+        full = torch.flip(full, dims=[2])
+    return full if acc is None else acc + full
 
 
 def fast_hist(pred, gt, n=19):

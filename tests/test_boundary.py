@@ -71,3 +71,25 @@ def test_synthetic_domain_source_is_deterministic():
     s = input_edge.SyntheticDomainSource(1, 2, 32, n_buffers=2, seed=2, static=True)
     first = [next(s)[0].clone() for _ in range(4)]
     assert torch.equal(first[0], first[2]) and torch.equal(first[1], first[3]) and not torch.equal(first[0], first[1])
+
+
+def test_stitching_beyond_64_tiles_takes_the_torch_formulation():
+    """pm_sliding_stitch takes at most 64 tiles by value; a 1024 x 2048 image at crop 256 has 72 (eval.py:158-182). harness.sliding_logits then stitches
+    with the float64 torch formulation (any device, no cap): same sums in tile order / true count / un-flip as the oracle's sliding_logits."""
+    import torch
+    from oracle.ref_cpu import harness as o_h
+    from pinthememory_amd import harness as h
+    tiles = h.sliding_tiles(1024, 2048, 256)
+    assert tiles == o_h.sliding_tiles(1024, 2048, 256) and len(tiles) == 72 > h.STITCH_MAX_TILES
+    g = torch.Generator().manual_seed(3)
+    acc, ref = None, None
+    for flip in (False, True):
+        lg = torch.randn(len(tiles), 3, 256, 256, generator=g)
+        full, cnt = torch.zeros(3, 1024, 2048, dtype=torch.float64), torch.zeros(1, 1024, 2048, dtype=torch.float64)
+        for t, (x1, y1, x2, y2) in zip(lg, tiles):
+            full[:, y1:y2, x1:x2] += t.double()
+            cnt[:, y1:y2, x1:x2] += 1
+        full = full / cnt
+        ref = (torch.flip(full, dims=[2]) if flip else full) + (0 if ref is None else ref)
+        acc = h._stitch_torch(lg, tiles, 1024, 2048, flip, acc)
+    assert torch.equal(acc, ref)
