@@ -22,21 +22,22 @@ def main():
     cur = sqlite3.connect(sys.argv[1]).cursor()
     nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     rows = cur.execute("select name, start, end from kernels order by start").fetchall()
-    fw = [i for i, r in enumerate(rows) if 'nchw_to_nhwc' in r[0]]
+    fw = [i for i, r in enumerate(rows) if 'nchw_to_nhwc' in r[0]]          # once per step: both forwards read the same converted batch
     sg = [i for i, r in enumerate(rows) if 'sgd_multi' in r[0]]
-    # a step = forward mark, ..., sgd..., forward mark (commit), ..., next forward mark
     steps = []
-    for a, b, c in zip(fw[0::2], fw[1::2], fw[2::2]):
-        s = [i for i in sg if a < i < b]
+    for a, c in zip(fw[:-1], fw[1:]):
+        s = [i for i in sg if a < i < c]
         if not s:
             continue
-        ce = [i for i in range(a, s[0]) if re.search(r'ce_(fwd|fused)', rows[i][0])]
-        steps.append((a, ce[-1] if ce else a, s[0], s[-1], b, c))
+        bw = [i for i in range(a, s[0]) if 'ce_bwd_cols' in rows[i][0]]        # the first backward kernels: the losses' row passes
+        if not bw:
+            continue
+        steps.append((a, bw[0], s[0], s[-1], c, c))
     steps = steps[-nsteps:]
     tot = collections.OrderedDict((k, 0.0) for k in ('train forward', 'backward', 'sgd', 'commit forward', 'step'))
     famt = {k: collections.Counter() for k in tot}
     for a, ce, s0, s1, b, c in steps:
-        cuts = {'train forward': (rows[a][1], rows[ce][2]), 'backward': (rows[ce][2], rows[s0][1]), 'sgd': (rows[s0][1], rows[s1][2]),
+        cuts = {'train forward': (rows[a][1], rows[ce][1]), 'backward': (rows[ce][1], rows[s0][1]), 'sgd': (rows[s0][1], rows[s1][2]),
                 'commit forward': (rows[s1][2], rows[c][1]), 'step': (rows[a][1], rows[c][1])}
         for k, (t0, t1) in cuts.items():
             tot[k] += (t1 - t0) / 1e6
