@@ -1,6 +1,7 @@
 """Callers either side of the hot path, on the GPU: the aggregation train step, memory initialisation, sliding-window
 evaluation and mIoU -- the build's counterparts of /root/reference/train.py:284-374 (+ calculate_loss :213-244),
 train.py:1000-1042, eval.py:148-274,340-405 and utils/misc.py:65-73."""
+import contextlib
 import math
 
 import torch
@@ -44,12 +45,31 @@ def memory_only_forward(net, x, gts):
     ops.flush_bn_counters()
 
 
+# The memory-commit forward of step t (eval mode, no graph, post-SGD weights) and the training forward of step t + 1 are independent up to the
+# memory read of the latter: the commit forward runs on its own stream, and the next step's HBM-bound BatchNorm / transform passes run under its
+# GEMMs (and vice versa). Ordering: (1) it starts after the SGD launches; (2) the main stream continues once the commit forward's ONE fold launch has
+# read every BatchNorm running moment (ops.last_prefold_event) -- the next training forward updates them; (3) Memory_sup waits for the committed memory
+# where it is first read (Memory_sup.pending); (4) transformed filters the commit forward wrote are event-ordered per cache entry (hip/kernels.py);
+# (5) the next SGD is behind (3) on the main stream, so the weights are not written under it. Results are bit-identical to the serial order.
+# Single process only: with more than one rank every collective of a step stays on one stream (dist.py). PM_COMMIT_OVERLAP=0 disables it.
+COMMIT_OVERLAP = __import__('os').environ.get('PM_COMMIT_OVERLAP', '1') == '1'
+_commit_streams = {}
+
+
+def _commit_stream(device):
+    if device.index not in _commit_streams:
+        _commit_streams[device.index] = torch.cuda.Stream(device=device)
+    return _commit_streams[device.index]
+
+
 def agg_train_step(net, opt, x, gts, aux_gts=None, sched=None, buckets=None, truncate_second_forward=False):
     """One iteration of train_memory_agg. `buckets` (dist.GradBuckets) replaces DDP's reducer for N > 1."""
     aux_gts = gts if aux_gts is None else aux_gts
     m = net.module if hasattr(net, 'module') else net
     net.train()
-    mem_t = m.memory.m_items.clone().detach()
+    # the memory is re-assigned, never written in place (memory.py:253,256; Memory_sup.write here), so holding the tensor is the reference's clone
+    # without a copy kernel at the head of the step (which would wait for an overlapped commit forward)
+    mem_t = m.memory._m_items.detach()
     if x.is_cuda and x.shape[1] == 3:
         # both forward passes of the step read the same batch: lay it out once as the stem's NHWC / 4-channel input
         x = ops.nchw(K.nchw_to_nhwc(x.float(), c_pad=4))
@@ -63,14 +83,28 @@ def agg_train_step(net, opt, x, gts, aux_gts=None, sched=None, buckets=None, tru
     if buckets is not None:
         buckets.finish()
     opt.step()
-    with torch.no_grad():
+    overlap = COMMIT_OVERLAP and x.is_cuda and buckets is None and not D.is_dist()
+    main = torch.cuda.current_stream() if x.is_cuda else None
+    side = _commit_stream(x.device) if overlap else None
+    if overlap:
+        side.wait_stream(main)
+        for t in (x, gts, aux_gts, mem_t):
+            t.record_stream(side)
+    with torch.no_grad(), (torch.cuda.stream(side) if overlap else contextlib.nullcontext()):
         net.eval()
         m.memory.m_items = mem_t
+        ops.last_prefold_event, ops.fold_misses = None, 0
         if truncate_second_forward:
             memory_only_forward(net, x, gts)
         else:
             net(x, gts=gts, aux_gts=aux_gts, memory_writing=True)
         net.train()
+        if overlap:
+            done = side.record_event()
+            m.memory.pending = done
+    if overlap:
+        # the next training forward rewrites the BatchNorm running moments: wait for the fold launch that read them (or, without one, for everything)
+        main.wait_event(ops.last_prefold_event if (ops.last_prefold_event is not None and ops.fold_misses == 0) else done)
     if sched is not None:
         sched.step()
     return dict(loss1=outputs[0].detach(), loss2=outputs[1].detach(), readloss=outputs[-2].detach(), div=outputs[-3][0].detach(),

@@ -123,13 +123,16 @@ def _wino_u(lib, xd, yd, p, w_krsc):
             del _U_CACHE[k]
         while _U_CACHE and (len(_U_CACHE) >= _U_CACHE_MAX or sum(e[2].numel() * 4 for e in _U_CACHE.values()) + nbu > _U_CACHE_BYTES):
             _U_CACHE.pop(next(iter(_U_CACHE)))
-        ent = [weakref.ref(owner) if owner is not None else w_krsc, -1, torch.empty(nbu // 4, dtype=torch.float32, device=w_krsc.device)]
+        ent = [weakref.ref(owner) if owner is not None else w_krsc, -1, torch.empty(nbu // 4, dtype=torch.float32, device=w_krsc.device), None, None]
     version = (owner if owner is not None else w_krsc)._version
     valid = ent[1] == version
     ent[1] = version
     _U_CACHE[key] = ent
     p.wxf, p.wxf_bytes, p.wxf_valid = ent[2].data_ptr(), nbu, 1 if valid else 0
-    return ent[2]
+    cur = torch.cuda.current_stream()
+    if valid and ent[3] is not None and ent[4] != cur.cuda_stream:
+        cur.wait_event(ent[3])          # the transform was written by a launch on another stream (harness: the commit forward runs on its own)
+    return ent if not valid else None
 
 
 def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, residual=None, relu=False, out=None, keep_v=None, bn_partials=None):
@@ -151,8 +154,9 @@ def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, res
         keep_v.append(v)
         if v is not None:
             p.wino_v, p.wino_v_bytes = v.data_ptr(), nbv
+    fresh_u = None
     if (kh == 3 and CONV_PREC == 0) or CONV_PREC == 2:
-        _wino_u(lib, xd, yd, p, w_krsc)
+        fresh_u = _wino_u(lib, xd, yd, p, w_krsc)      # the cache entry this call is about to (re)write, if any
     nb = lib.pm_conv_workspace(byref(xd), byref(yd), byref(p), 0)
     ws = workspace(nb, x.device) if nb else None
     part = None
@@ -166,6 +170,9 @@ def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, res
         ep = PmConvEpilogue(ptr(bias), ptr(scale), ptr(shift), rd.ptr if rd else None, rd.pitch if rd else 0, 1 if relu else 0, ptr(part),
                             part.numel() * 4 if part is not None else 0)
     check(lib.pm_conv_fwd(byref(xd), w_krsc.data_ptr(), byref(yd), byref(p), byref(ep) if ep else None, ptr(ws), nb, stream()), 'pm_conv_fwd')
+    if fresh_u is not None:             # later hits from another stream wait for this launch
+        cur = torch.cuda.current_stream()
+        fresh_u[3], fresh_u[4] = cur.record_event(), cur.cuda_stream
     return y
 
 

@@ -240,6 +240,8 @@ class _Bottleneck(torch.autograd.Function):
 # fold for anything not covered (a conv with a bias, a module swapped in later). PM_FOLD_BATCH=0 disables it.
 FOLD_BATCH = _os.environ.get('PM_FOLD_BATCH', '1') == '1'
 _fold_cache = None
+fold_misses = 0
+last_prefold_event = None      # recorded right after the one fold launch: from there on the forward no longer reads any BatchNorm running moment
 
 
 class prefold:
@@ -247,7 +249,8 @@ class prefold:
         self.model, self.active = model, False
 
     def __enter__(self):
-        global _fold_cache
+        global _fold_cache, last_prefold_event
+        last_prefold_event = None
         m = self.model
         if not FOLD_BATCH or m.training or torch.is_grad_enabled() or _fold_cache is not None:
             return self
@@ -275,6 +278,7 @@ class prefold:
         arena = K.bn_fold_multi(table, dcs, doffs, len(cs), max(cs), tot, bns[0].eps)
         _fold_cache = {b.running_mean.data_ptr(): (arena[o:o + c], arena[tot + o:tot + o + c]) for b, c, o in zip(bns, cs, offs)}
         self.active = True
+        last_prefold_event = torch.cuda.current_stream().record_event() if len(bns) == len(m.__dict__['_pm_bn_list']) else None
         return self
 
     def __exit__(self, *exc):
@@ -298,6 +302,9 @@ class _ConvBnAct(torch.autograd.Function):
         needs_grad = bn.grad_enabled and any(ctx.needs_input_grad[:6])   # needs_input_grad alone ignores torch.no_grad()
         if not bn.training and not needs_grad:     # inference: BN folded into the conv epilogue, nothing saved
             hit = _fold_cache.get(bn.running_mean.data_ptr()) if (_fold_cache is not None and bias is None) else None
+            if hit is None:
+                global fold_misses
+                fold_misses += 1                   # this forward reads running moments after its fold launch (harness: no early hand-back of the main stream)
             scale, shift = hit if hit is not None else K.bn_fold(gamma, beta, bn.running_mean, bn.running_var, bn.eps, bias)
             o = K.conv_fwd(xv, wk, stride, pad, dil, scale=scale, shift=shift, residual=rv, relu=relu, out=ov)
             return nchw(o)

@@ -51,9 +51,28 @@ class Memory_sup(nn.Module):
         self.celoss = nn.CrossEntropyLoss(ignore_index=255)
         self.gumbel_read = gumbel_read
         self.writeTF = lambda x: x.clone()
+        self.pending = None       # event after which m_items is complete, when its producer ran on another stream (harness: overlapped commit forward)
         self.m_items = F.normalize(torch.rand((memory_size, feature_dim), dtype=torch.float), dim=1)
         initialize_weights(self)
         self.noise_fn = None      # parity hook: callable(rows, slots, device) -> (noise_dim0, noise_dim1)
+
+    # m_items stays the reference's plain get / set attribute (train.py:312,332,547,558,580,1040; optimizer.py:65). Behind it: when the tensor was
+    # produced on another stream (harness.agg_train_step runs the commit forward on its own), the first READ from anywhere -- the next memory read,
+    # a checkpoint, a test -- orders the reader's stream behind the producer; harness code that only passes the tensor on uses _m_items.
+    @property
+    def m_items(self):
+        if self.pending is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(self.pending)
+            if self._m_items.is_cuda:
+                self._m_items.record_stream(cur)
+            self.pending = None
+        return self._m_items
+
+    @m_items.setter
+    def m_items(self, value):
+        self.pending = None
+        self._m_items = value
 
     def _apply(self, fn, *args, **kwargs):
         # m_items / mem_cls are plain attributes in the reference (hard .cuda() at memory.py:111,120); follow the module instead

@@ -741,3 +741,33 @@ def test_agg_step_shape_sweep_finite_and_deterministic(env, bs, size):
     net2, losses2 = run()
     assert all(torch.equal(losses[k], losses2[k]) for k in losses) and torch.equal(m, net2.memory.m_items)
     assert all(torch.equal(v, net2.state_dict()[k]) for k, v in net.state_dict().items())
+
+
+def test_commit_forward_on_its_own_stream_is_bit_identical(env):
+    """harness.agg_train_step runs the memory-commit forward of step t on a second stream under the training forward of step t + 1 (ordered by
+    events: the BatchNorm fold launch, the committed memory at its first read, the kept filter transforms per cache entry). Three steps with the
+    overlap must carry the bits of three steps in serial order -- every kernel is deterministic, so any lost ordering would show."""
+    synth, h = env['synth'], env['harness']
+    x, y = synth.make_batch(2, 192, seed=41)
+
+    def run(overlap):
+        prev = h.COMMIT_OVERLAP
+        h.COMMIT_OVERLAP = overlap
+        try:
+            net = synth.load_det_weights(env['deepv3plus'].DeepR50V3PlusD(synth.model_args(gumbel_off=True), 19, CRIT, CRIT)).cuda()
+            net.dsn[3].p = 0.0
+            opt, _ = h.make_optimizer(net)
+            xs, ys = x.cuda(), y.cuda()
+            losses = [h.agg_train_step(net, opt, xs, ys) for _ in range(3)]
+            assert (net.memory.pending is not None) == overlap          # the last commit forward is still in flight until someone reads the memory
+            mem = net.memory.m_items.clone()                            # the read orders this stream behind the commit stream
+            torch.cuda.synchronize()
+            return net, losses, mem
+        finally:
+            h.COMMIT_OVERLAP = prev
+    n1, l1, m1 = run(True)
+    n0, l0, m0 = run(False)
+    for a_, b_ in zip(l1, l0):
+        assert all(torch.equal(a_[k], b_[k]) for k in a_)
+    assert torch.equal(m1, m0)
+    assert all(torch.equal(v, n0.state_dict()[k]) for k, v in n1.state_dict().items())
