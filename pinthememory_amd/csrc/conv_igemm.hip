@@ -97,8 +97,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   constexpr bool B_KC = (MODE == MODE_FWD);    // B tile stored [BN][LDK] else [BK][BN]
   constexpr bool FAST = (KM == K_FAST) && (MODE != MODE_WGRAD);
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int A_FLOATS = A_KC ? BM * LDK : BK * BM;
-  constexpr int B_FLOATS = B_KC ? BN * LDK : BK * BN;
+  // PREC 3 (weight gradient of the bf16 tier): the pixel-major (m-contiguous) tiles are kept in LDS as bf16 [BK][BM + 32] -- rounded once, as the
+  // gathered fp32 rows are stored -- and the MFMA fragments (8 consecutive k per lane) come out of them through the hardware transpose read
+  // ds_read_b64_tr_b16. The 32-element pad puts the four k-rows one read touches on four disjoint bank quarters (row stride = 64 B mod 256 B).
+  constexpr bool TR = (PREC == 3);
+  static_assert(!TR || MODE == MODE_WGRAD, "PREC 3 is the weight-gradient form");
+  constexpr int LDA_T = BM + 32, LDB_T = BN + 32;   // bf16 elements per k-row
+  constexpr int A_FLOATS = A_KC ? BM * LDK : (TR ? BK * LDA_T / 2 : BK * BM);
+  constexpr int B_FLOATS = B_KC ? BN * LDK : (TR ? BK * LDB_T / 2 : BK * BN);
   constexpr int STAGE = A_FLOATS + B_FLOATS;
   constexpr int A_N = BM / 32, B_N = BN / 32;  // float4 per thread and tile
   static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BK == 32, "bad tile config");
@@ -352,17 +358,25 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
     }
   };
 
+  auto pack4 = [](const float4& v) {   // four fp32 -> four bf16 (RNE), 8 bytes
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    bf16x4 o;
+    o[0] = (__bf16)v.x, o[1] = (__bf16)v.y, o[2] = (__bf16)v.z, o[3] = (__bf16)v.w;
+    return __builtin_bit_cast(float2, o);
+  };
   auto store_tiles = [&](int buf) {
     float* As = smem + buf * STAGE;
     float* Bs = As + A_FLOATS;
 #pragma unroll
     for (int i = 0; i < A_N; ++i) {
       if constexpr (A_KC) *reinterpret_cast<float4*>(As + (r + 32 * i) * LDK + g * 4) = ra[i];
+      else if constexpr (TR) *reinterpret_cast<float2*>(reinterpret_cast<char*>(As) + (r * LDA_T + (g + 8 * i) * 4) * 2) = pack4(ra[i]);
       else *reinterpret_cast<float4*>(As + r * BM + (g + 8 * i) * 4) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < B_N; ++i) {
       if constexpr (B_KC) *reinterpret_cast<float4*>(Bs + (r + 32 * i) * LDK + g * 4) = rb[i];
+      else if constexpr (TR) *reinterpret_cast<float2*>(reinterpret_cast<char*>(Bs) + (r * LDB_T + (g + 8 * i) * 4) * 2) = pack4(rb[i]);
       else *reinterpret_cast<float4*>(Bs + r * BN + (g + 8 * i) * 4) = rb[i];
     }
   };
@@ -378,7 +392,33 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   auto compute_kg = [&](int buf, int kg) {   // one 8-k group (fp32) or one 16-k block (bf16: kg = 0, 2 cover the slab)
     const float* As = smem + buf * STAGE;
     const float* Bs = As + A_FLOATS;
-    if constexpr (PREC == 2) {
+    if constexpr (TR) {
+      // bf16 [k][m] tiles, fragments through ds_read_b64_tr_b16: within a 16-lane group lane i hands in the address of row (i >> 2), column block
+      // (i & 3) * 4 and receives column i of those four rows (tools/micro/tr_probe.hip) -- four consecutive k of its own m. Two reads = the lane's
+      // eight k of v_mfma_f32_32x32x16_bf16 (lanes 32..63: the upper eight k of the 16-k block).
+      if (kg & 1) return;                                   // two 16-k blocks per slab, issued on the even groups
+      typedef short s16x4 __attribute__((ext_vector_type(4)));
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      const int krow = (kg >> 1) * 16 + half * 8 + ((lane & 15) >> 2);
+      const int cofs = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+      auto frag = [&](const float* T, int ld, int col0) {
+        const short* base = reinterpret_cast<const short*>(T) + krow * ld + col0 + cofs;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * ld));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+      };
+      bf16x8 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = frag(As, LDA_T, wm * (BM / WM) + i * 32);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) fb[i] = frag(Bs, LDB_T, wn * (BN / WN) + i * 32);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+          acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[n], acc[i][n], 0, 0, 0);
+    } else if constexpr (PREC == 2) {
       // bf16 operands in HBM and LDS (bf16.hip): the tensors enter as fp32-typed views with half the channels, so one float4 of a
       // k-contiguous LDS row is 8 consecutive bf16 k-values -- exactly this lane-half's operand of v_mfma_f32_32x32x16_bf16. Gather,
       // LDS layout (128-byte rows = 64 k, padded to 144 B) and epilogue are the fp32 code unchanged; 8 x fewer MFMA cycles per slab.
@@ -991,7 +1031,10 @@ void launch_inst(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
   if constexpr (MODE == MODE_FWD && KM == K_FAST && BN >= 64) {
     if (k.prec == 2) return launch_prec<MODE, BM, BN, WM, WN, KM, 2>(k, grid, smem, st);
   }
-  if (k.prec == 1) launch_prec<MODE, BM, BN, WM, WN, KM, 1>(k, grid, smem, st);
+  if constexpr (MODE == MODE_WGRAD && BN >= 64) {
+    if (k.prec == 3) return launch_prec<MODE, BM, BN, WM, WN, KM, 3>(k, grid, smem, st);
+  }
+  if (k.prec != 0) launch_prec<MODE, BM, BN, WM, WN, KM, 1>(k, grid, smem, st);
   else launch_prec<MODE, BM, BN, WM, WN, KM, 0>(k, grid, smem, st);
 }
 template <int MODE, int BM, int BN, int WM, int WN>
@@ -1029,7 +1072,11 @@ int launch(const ConvK& k0, const Plan& p, hipStream_t st, int batch = 1, double
     (void)hipEventRecord(rec.a, st);
   }
   constexpr bool akc = MODE != MODE_WGRAD, bkc = MODE == MODE_FWD;
-  auto smem = [&](int bm, int bn) { return (size_t)2 * ((akc ? bm * LDK : BK * bm) + (bkc ? bn * LDK : BK * bn)) * sizeof(float); };
+  const bool tr = MODE == MODE_WGRAD && k.prec == 3 && p.bn >= 64;      // bf16 [k][m + 32] tiles: 2 bytes per element
+  auto smem = [&](int bm, int bn) {
+    if (tr) return (size_t)2 * (BK * (bm + 32) + BK * (bn + 32)) * 2;
+    return (size_t)2 * ((akc ? bm * LDK : BK * bm) + (bkc ? bn * LDK : BK * bn)) * sizeof(float);
+  };
   if (p.bm == 64) {
     if (p.bn == 128) launch_one<MODE, 64, 128, 2, 2>(k, grid, smem(64, 128), st);
     else launch_one<MODE, 64, 64, 2, 2>(k, grid, smem(64, 64), st);
@@ -1634,6 +1681,10 @@ extern "C" int pm_conv_bwd_weight(const pm_tensor* x, const pm_tensor* dy, float
   }
   ConvK k;
   fill_geom(k, x, dy, p);
+  // configs[2]: the weight gradient gathers the fp32 rows as before, rounds them to bf16 on the way into LDS and reads its fragments through the
+  // transpose read (PREC 3): no transposed / per-tap copies of x in HBM. PM_BF16_WGRAD_TR=0 keeps the staged-fp32 form (A/B runs).
+  static const int tr_on = getenv("PM_BF16_WGRAD_TR") ? atoi(getenv("PM_BF16_WGRAD_TR")) : 1;
+  if (p->prec == 2 && tr_on) k.prec = 3;
   k.A = (const float*)dy->ptr, k.B = (const float*)x->ptr;
   k.M = (int)M, k.Nn = (int)Nn, k.K = (int)K;
   k.a_bytes = (unsigned)(pm_pixels(dy) * dy->pitch * 4), k.b_bytes = (unsigned)(pm_pixels(x) * x->pitch * 4), k.kmode = dy->w >= BK ? 1 : 2;
