@@ -90,6 +90,10 @@ int pm_conv_bwd_weight(const pm_tensor* x, const pm_tensor* dy, float* dw_krsc, 
  * ~3e-6 of the output scale for F(4x4), ~4e-7 for F(2x2); the direct MFMA chain: ~5e-7).
  * mode: 0 = direct implicit GEMM everywhere, 2 = F(2x2) only, 4 = prefer F(4x4) (default). */
 int pm_set_winograd(int mode);
+/* F(4x4) layers: the 36 point GEMMs and the output transform in ONE kernel, so that the products M = V U^T never reach HBM (one block = 32 tiles x
+ * 32 channels x all 36 points). Same results to fp32 round-off; measured slower than GEMM + output-transform pass on every flagship layer
+ * (DESIGN.md section 7), hence off by default: 0 off, 1 on. Process-wide like pm_set_winograd. */
+int pm_set_winograd_fused(int on);
 /* prec = 2 weight gradients on pixel-contiguous bf16 copies of x (one per tap) and dy instead of the staged-fp32 form: 0 off (default: the
  * copies cost more HBM time than the GEMM saves), 1 on. Process-wide like pm_set_winograd. */
 int pm_set_bf16_wgrad(int on);

@@ -1132,6 +1132,7 @@ void fill_geom(ConvK& k, const pm_tensor* x, const pm_tensor* y, const pm_conv_p
 // dilation sub-lattices tile the image without too much padding: the m in {4, 2} with the fewest multiplies per output, if that is
 // below 0.6 of the direct algorithm's (m = 4 for d = 1, 2, 6, 12, 18 on the 48x48 maps and d = 1 on 192x192).
 int g_wino_mode = 4;   // 0 off, 2 F(2x2) only, 4 prefer F(4x4)
+int g_wino_fused = getenv("PM_WINO_FUSED") ? atoi(getenv("PM_WINO_FUSED")) : 0;   // F(4x4) GEMMs + output transform in one kernel (opt-in, see wino_conv)
 struct WinoPlan {
   bool use;
   pm_wino_geom g;
@@ -1198,6 +1199,27 @@ int wino_conv(const pm_tensor* xin, const float* w, int w_cout, int w_cin, bool 
   k.a_bytes = (unsigned)(wp.g.tiles * wp.Kp * 4), k.b_bytes = (unsigned)((long)cout * wp.Kp * 4), k.kmode = K_FAST;
   k.c_pitch = cout, k.c_split = 0;
   k.a_bs = wp.g.tiles * wp.Kp, k.b_bs = (long)cout * wp.Kp, k.c_bs = wp.g.tiles * cout;
+  // F(4x4): the 36 GEMMs and the output transform as ONE kernel -- M never reaches HBM (winograd.hip, wino_fused_f4_kernel). Correct (the Winograd
+  // kernel tests pass on it) and SLOWER: 76.4 vs 64.2 ms/step, 1.59 vs 1.07 ms on final1.3, 1.28 vs 0.52 ms on ASPP d6 (same box, round 3). Holding all
+  // 36 points of a tile in one block caps the block tile at 32 x 32 per point (registers), i.e. 8 FLOP per byte staged through LDS instead of the
+  // 32 of the 128 x 128 GEMM tile: 144 KB per 16-k slab per CU, one LDS stage, the stage's write phase (~1900 cycles at 79 B/clk) not overlapped with its
+  // 4600 MFMA cycles. Bounds measured on the unfused path: a GEMM that never stores M -3.3 ms/step, no output-transform pass either -5.6 ms/step.
+  // Kept as an opt-in (PM_WINO_FUSED=1) with its tests; the default is the batched GEMM + wino_output_kernel.
+  if (g_wino_fused && wp.g.m == 4 && wp.Kp % 16 == 0) {
+    ProfRec rec;
+    if (g_prof_on) {
+      (void)hipEventCreate(&rec.a), (void)hipEventCreate(&rec.b);
+      rec.mode = 3, rec.bm = 32, rec.bn = 32, rec.km = 0, rec.prec = 0, rec.nst = 1, rec.M = (int)wp.g.tiles, rec.Nn = cout, rec.K = wp.Kp, rec.batch = wp.P, rec.ksplit = 1;
+      rec.flops = 2.0 * wp.P * (double)wp.g.tiles * cout * xin->c;
+      (void)hipEventRecord(rec.a, st);
+    }
+    const int e = pm_wino_fused_f4(V, U, cout, wp.Kp, wp.g, (float*)yout->ptr, yout->pitch, ep.bias, ep.scale, ep.shift, ep.residual, ep.residual_pitch, ep.relu, st);
+    if (g_prof_on) {
+      (void)hipEventRecord(rec.b, st);
+      g_prof.push_back(rec);
+    }
+    return e;
+  }
   if (int e = launch<MODE_FWD>(k, wp.pl, st, wp.P, 2.0 * wp.P * (double)wp.g.tiles * cout * xin->c)) return e;
   return pm_wino_output_xf(Mo, cout, wp.g, (float*)yout->ptr, yout->pitch, ep.bias, ep.scale, ep.shift, ep.residual, ep.residual_pitch, ep.relu, st);
 }
@@ -1379,6 +1401,10 @@ void gemm_dims(int which, const pm_tensor* x, const pm_tensor* y, const pm_conv_
 extern "C" int pm_set_winograd(int mode) {
   PM_REQUIRE(mode == 0 || mode == 2 || mode == 4, PM_EINVAL, "pm_set_winograd: mode %d (0 off, 2 F(2x2,3x3), 4 prefer F(4x4,3x3))", mode);
   g_wino_mode = mode;
+  return PM_OK;
+}
+extern "C" int pm_set_winograd_fused(int on) {
+  g_wino_fused = on != 0;
   return PM_OK;
 }
 extern "C" int pm_set_bf16_wgrad(int on) {

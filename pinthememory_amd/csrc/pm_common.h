@@ -45,6 +45,8 @@ int pm_wino_input_xf(const float* x, long pitch, int C, int Kp, const pm_wino_ge
 int pm_wino_filter_xf(const float* w, int Cout, int Cin, int Kp, bool dgrad, int m, float* U, hipStream_t st);
 int pm_wino_output_xf(const float* M, int Cout, const pm_wino_geom& g, float* y, long ypitch, const float* bias, const float* scale, const float* shift,
                       const float* residual, long res_pitch, int relu, hipStream_t st);
+int pm_wino_fused_f4(const float* V, const float* U, int Cout, int Kp, const pm_wino_geom& g, float* y, long ypitch, const float* bias, const float* scale,
+                     const float* shift, const float* residual, long res_pitch, int relu, hipStream_t st);
 int pm_wino_dy_xf(const float* dy, long pitch, int Cout, const pm_wino_geom& g, float* Z, hipStream_t st);
 int pm_wino_dw_xf(const float* slab, int ks, int Cout, int Cin, int Kp, int m, float* dw, hipStream_t st);
 

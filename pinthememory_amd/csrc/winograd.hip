@@ -353,6 +353,167 @@ __global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ 
   }
 }
 
+// ---- F(4x4,3x3): the 36 point GEMMs AND the output transform in one kernel -- M = V U^T never reaches HBM ------------------------------
+// One block = 32 transform tiles x 32 output channels x ALL 36 points: 12 waves, wave w owns points 3w .. 3w + 2, one 32 x 32 MFMA tile
+// (v_mfma_f32_32x32x2_f32, exact fp32 chain) per point = 48 accumulator registers per lane. K (input channels) runs outermost in slabs of 16:
+// per slab the block stages 36 x (32 tile rows of V + 32 channel rows of U) x 64 B = 144 KB in LDS (16-byte chunks XOR-swizzled by (row >> 2) & 3:
+// conflict-free ds_read_b128 without padding), next slab's rows prefetched to registers under the MFMAs. After the K loop the accumulators are
+// parked in the same LDS as M[36][32][32 (+1)] and every (tile, channel) pair applies y = At M A + the fused epilogue (bias / affine / residual /
+// ReLU, same expressions as wino_output_kernel), stores leave as 128-byte channel runs. Against GEMM + wino_output_kernel this removes the write
+// and the read of M (2.25 x the output each) and one launch; the price is U / V re-read from L2 (Cout / 32 and tiles / 32 times).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WinoFusedArgs {
+  const float* V;      // [36][tiles][Kp]
+  const float* U;      // [36][Cout][Kp]
+  float* y;
+  long yp;
+  int Cout, Kp;
+  pm_wino_geom g;
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  const float* residual;
+  long rp;
+  int relu;
+  int ncb;             // channel blocks (Cout / 32, rounded up); gridDim.x = tile blocks * ncb
+};
+
+constexpr int WF_THREADS = 768, WF_TB = 32, WF_CB = 32, WF_BK = 16, WF_P = 36;
+constexpr size_t WF_LDS = (size_t)WF_P * WF_TB * (WF_CB + 1) * sizeof(float);   // the parked accumulators (152 064 B) >= the operand stage (147 456 B)
+
+__device__ __forceinline__ int wf_xcd_remap(int bid, int nwg) {   // consecutive logical ids (they share the V rows) on one XCD's L2
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+__global__ __launch_bounds__(WF_THREADS) void wino_fused_f4_kernel(const WinoFusedArgs a) {
+  extern __shared__ __align__(16) float4 lds4[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lid = wf_xcd_remap(blockIdx.x, gridDim.x);
+  const int tb = lid / a.ncb, cb = lid - tb * a.ncb;
+  const long tile0 = (long)tb * WF_TB;
+  const int co0 = cb * WF_CB;
+
+  // ---- loader: thread -> one 16-byte chunk of one row, the same (row, chunk) for the points pgrp, pgrp + 3, ... (12 per thread) ----------------
+  const int rem = tid & 255, row = rem >> 2, chunk = rem & 3, pgrp = tid >> 8;
+  const bool is_a = row < WF_TB;
+  bool valid;
+  const float* gp;
+  long plane;
+  if (is_a) {
+    const long tile = tile0 + row;
+    valid = tile < a.g.tiles;
+    gp = a.V + (valid ? tile : 0) * a.Kp + chunk * 4;
+    plane = a.g.tiles * (long)a.Kp;
+  } else {
+    const int co = co0 + row - WF_TB;
+    valid = co < a.Cout;
+    gp = a.U + (long)(valid ? co : 0) * a.Kp + chunk * 4;
+    plane = (long)a.Cout * a.Kp;
+  }
+  gp += (long)pgrp * plane;
+  const long pstep = 3 * plane;
+  const int ldsw = pgrp * 256 + row * 4 + (chunk ^ ((row >> 2) & 3));
+  float4 r[12];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < 12; ++it) r[it] = valid ? PM_LD4(gp + it * pstep + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int it = 0; it < 12; ++it) lds4[it * 768 + ldsw] = r[it];
+  };
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+  const int l31 = lane & 31, half = lane >> 5;
+  // fragment rows: A row l31, B row 32 + l31; this lane-half's 8 k are chunks 2 half, 2 half + 1 of the row (swizzled)
+  const int sa = (l31 >> 2) & 3, sb = ((32 + l31) >> 2) & 3;
+  const int ia0 = l31 * 4 + ((2 * half) ^ sa), ia1 = l31 * 4 + ((2 * half + 1) ^ sa);
+  const int ib0 = (32 + l31) * 4 + ((2 * half) ^ sb), ib1 = (32 + l31) * 4 + ((2 * half + 1) ^ sb);
+  auto compute = [&]() {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float4* T = lds4 + (wave * 3 + j) * 256;
+      const float4 a0 = T[ia0], a1 = T[ia1], b0 = T[ib0], b1 = T[ib1];
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc[j], 0, 0, 0);
+    }
+  };
+
+  const int nk = a.Kp / WF_BK;
+  gload(0);
+  lstore();
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gload((kt + 1) * WF_BK);      // in flight under the 24 MFMAs of this slab
+    compute();
+    __syncthreads();                                // every wave is done reading the stage
+    if (kt + 1 < nk) {
+      lstore();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: park the 36 products of every (tile, channel) pair in LDS, then y = At M A per pair -----------------------------------------
+  float* Ms = reinterpret_cast<float*>(lds4);       // [36][32 tiles][33]
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int pnt = wave * 3 + j;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Ms[(pnt * WF_TB + (q & 3) + 8 * (q >> 2) + 4 * half) * (WF_CB + 1) + l31] = acc[j][q];
+  }
+  __syncthreads();
+  constexpr int MT = 4, A = 6;
+  for (int idx = tid; idx < WF_TB * WF_CB; idx += WF_THREADS) {
+    const int t = idx >> 5, c = idx & 31;
+    const long tile = tile0 + t;
+    const int co = co0 + c;
+    if (tile >= a.g.tiles || co >= a.Cout) continue;
+    const TileId ti = decode_tile((unsigned)tile, a.g);
+    Vec<1> sv[MT][A];
+#pragma unroll
+    for (int b = 0; b < A; ++b) {   // At m
+      Vec<1> col[A], o[MT];
+#pragma unroll
+      for (int aa = 0; aa < A; ++aa) col[aa].v[0] = Ms[((aa * A + b) * WF_TB + t) * (WF_CB + 1) + c];
+      mat_apply<MT, W_AT>(col, o);
+#pragma unroll
+      for (int aa = 0; aa < MT; ++aa) sv[aa][b] = o[aa];
+    }
+    const float bi = a.bias ? a.bias[co] : 0.f, sc = a.scale ? a.scale[co] : 0.f, sh = a.scale ? a.shift[co] : 0.f;
+#pragma unroll
+    for (int aa = 0; aa < MT; ++aa) {
+      const int yy = ti.ry + a.g.d * (MT * ti.ty + aa);
+      Vec<1> o[MT];
+      mat_apply<MT, W_AT>(sv[aa], o);   // (At m) A
+#pragma unroll
+      for (int b = 0; b < MT; ++b) {
+        const int xx = ti.rx + a.g.d * (MT * ti.tx + b);
+        if (yy >= a.g.H || xx >= a.g.W) continue;
+        const long pix = (long)(ti.n * a.g.H + yy) * a.g.W + xx;
+        float v = o[b].v[0];
+        if (a.bias) v += bi;
+        if (a.scale) v = v * sc + sh;
+        if (a.residual) v += a.residual[pix * a.rp + co];
+        if (a.relu) v = fmaxf(v, 0.f);
+        a.y[pix * a.yp + co] = v;
+      }
+    }
+  }
+}
+
 inline unsigned nblocks(long total) { return (unsigned)std::min<long>((total + 255) / 256, 1 << 20); }
 
 }  // namespace
@@ -407,3 +568,21 @@ int pm_wino_dw_xf(const float* slab, int ks, int Cout, int Cin, int Kp, int m, f
   else hipLaunchKernelGGL(wino_dw_kernel<2>, dim3(nb), dim3(256), 0, st, slab, ks, Cout, Cin, Kp, dw);
   return pm_check_launch("wino_dw");
 }
+
+// GEMMs + output transform in one kernel (F(4x4) only): V [36][tiles][Kp] x U [36][Cout][Kp] -> y with the fused epilogue.
+int pm_wino_fused_f4(const float* V, const float* U, int Cout, int Kp, const pm_wino_geom& g, float* y, long ypitch, const float* bias, const float* scale,
+                     const float* shift, const float* residual, long res_pitch, int relu, hipStream_t st) {
+  static const bool attr_set = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_fused_f4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WF_LDS);
+    return true;
+  }();
+  (void)attr_set;
+  WinoFusedArgs a;
+  a.V = V, a.U = U, a.y = y, a.yp = ypitch, a.Cout = Cout, a.Kp = Kp, a.g = g;
+  a.bias = bias, a.scale = scale, a.shift = shift, a.residual = residual, a.rp = res_pitch, a.relu = relu;
+  a.ncb = (Cout + WF_CB - 1) / WF_CB;
+  const long ntb = (g.tiles + WF_TB - 1) / WF_TB;
+  hipLaunchKernelGGL(wino_fused_f4_kernel, dim3((unsigned)(ntb * a.ncb)), dim3(WF_THREADS), WF_LDS, st, a);
+  return pm_check_launch("wino_fused_f4");
+}
+

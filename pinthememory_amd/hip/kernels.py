@@ -621,6 +621,11 @@ def set_winograd(mode):
     check(_lib().pm_set_winograd(mode), 'pm_set_winograd')
 
 
+def set_winograd_fused(on):
+    """F(4x4) layers: GEMMs + output transform in one kernel (opt-in; slower than the two-pass form on the flagship layers)."""
+    check(_lib().pm_set_winograd_fused(1 if on else 0), 'pm_set_winograd_fused')
+
+
 def set_bf16_wgrad(on):
     check(_lib().pm_set_bf16_wgrad(1 if on else 0), 'pm_set_bf16_wgrad')
 

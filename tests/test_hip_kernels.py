@@ -146,6 +146,20 @@ def test_conv_winograd(K, case):
     # wide-dilation production maps a tile size may be rejected (too much sub-lattice padding) and falls back to the direct kernel
     taken = [wino for wino in (4, 2) if not torch.equal(res[wino][0], res[0][0])]
     assert taken == [wino for wino in (4, 2) if wino_route(h, w, d, wino)] and 4 in taken, (case, taken)
+    # F(4x4) with the point GEMMs and the output transform in ONE kernel (pm_set_winograd_fused: M = V U^T never reaches HBM): forward with the
+    # fused epilogue into a channel slice, and the data gradient with its fused skip add, against the same fp64 truth; the kernel is really
+    # taken (other bits than the two-pass form) wherever F(4x4) is
+    K.set_winograd(4)
+    K.set_winograd_fused(True)
+    try:
+        buf.zero_()
+        yf = nchw(K.conv_fwd(xg, wg, 1, d, d, bias=b.cuda(), out=buf[..., 32:32 + cout])).clone()
+        dxf = nchw(K.conv_bwd_data(dyg, wg, tuple(xg.shape), 1, d, d, add=addg))
+    finally:
+        K.set_winograd_fused(False)
+    assert buf[..., :32].abs().max().item() == 0 and buf[..., 32 + cout:].abs().max().item() == 0
+    assert rel(yf, y_ref.detach()) < 2e-5 and rel(dxf, xr.grad + add.double()) < 2e-5
+    assert torch.equal(yf, res[4][0]) == (wino_route(h, w, d, 4) != 4)
 
 
 @pytest.mark.parametrize('case', [(2, 64, 24, 20, 256, 1, 1, 0, 1), (3, 64, 45, 37, 64, 3, 1, 1, 1), (2, 256, 47, 33, 64, 1, 1, 0, 1), (1, 32, 40, 36, 128, 3, 2, 1, 1)])
