@@ -29,7 +29,12 @@ typedef struct pm_tensor {      /* NHWC fp32 activation view */
   int64_t pitch;                /* floats between consecutive pixels */
 } pm_tensor;
 
+/* ABI version of this header (pm_version() returns the library's). The two structs below carry their own size as first member: an entry point that
+ * receives a struct built against another header returns PM_EINVAL instead of reading past the caller's object (they grew in rounds 2 and 3). */
+#define PM_ABI_VERSION 300
+
 typedef struct pm_conv_params { /* nn.Conv2d geometry (square kernels/strides as used by the reference) */
+  int32_t struct_size;          /* = sizeof(pm_conv_params) */
   int32_t kh, kw, stride, pad, dil;
   int32_t prec;                 /* 0: fp32 MFMA (exact fp32 chain, parity path, BASELINE configs[1]);
                                    1: fp32 tiles staged in LDS, rounded to bf16 per fragment for v_mfma_f32_32x32x16_bf16, fp32 accumulate and storage;
@@ -50,6 +55,7 @@ typedef struct pm_conv_params { /* nn.Conv2d geometry (square kernels/strides as
 } pm_conv_params;
 
 typedef struct pm_conv_epilogue { /* optional fused epilogue of pm_conv_fwd; all pointers may be NULL */
+  int64_t struct_size;          /* = sizeof(pm_conv_epilogue) */
   const float* bias;            /* [Cout]  conv bias (deepv3plus.py:417,420,424) */
   const float* scale;           /* [Cout]  folded eval-mode BN: y = conv*scale + shift (mynn.py:8-14 in .eval()) */
   const float* shift;           /* [Cout] */

@@ -1096,6 +1096,8 @@ int launch(const ConvK& k0, const Plan& p, hipStream_t st, int batch = 1, double
 
 int check_common(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p) {
   PM_REQUIRE(x && y && p && x->ptr && y->ptr, PM_EINVAL, "conv: null tensor");
+  PM_REQUIRE(p->struct_size == (int32_t)sizeof(pm_conv_params), PM_EINVAL, "conv: pm_conv_params.struct_size %d != %zu -- caller built against another pinmem_hip.h (library ABI %d)",
+             p->struct_size, sizeof(pm_conv_params), PM_ABI_VERSION);
   PM_REQUIRE(p->kh >= 1 && p->kw >= 1 && p->dil >= 1 && p->pad >= 0, PM_EINVAL, "conv: bad geometry");
   PM_REQUIRE(p->stride == 1 || p->stride == 2, PM_EUNSUPPORTED, "conv: stride %d unsupported (1 or 2)", p->stride);
   const int ho = (x->h + 2 * p->pad - p->dil * (p->kh - 1) - 1) / p->stride + 1;
@@ -1191,7 +1193,7 @@ int wino_conv(const pm_tensor* xin, const float* w, int w_cout, int w_cin, bool 
     if (int e = pm_wino_filter_xf(w, w_cout, w_cin, wp.Kp, dgrad, wp.g.m, U, st)) return e;
   const pm_tensor xv = {V, 1, 1, (int32_t)wp.g.tiles, wp.Kp, wp.Kp};
   const pm_tensor yv = {Mo, 1, 1, (int32_t)wp.g.tiles, cout, cout};
-  const pm_conv_params p1 = {1, 1, 1, 0, 1, 0};
+  const pm_conv_params p1 = {(int32_t)sizeof(pm_conv_params), 1, 1, 1, 0, 1, 0};
   ConvK k;
   fill_geom(k, &xv, &yv, &p1);
   k.A = V, k.B = U, k.C = Mo;
@@ -1256,7 +1258,7 @@ int wino_wgrad(const pm_tensor* x, const pm_tensor* dy, float* dw, const WinoPla
   if (int e = pm_wino_dy_xf((const float*)dy->ptr, dy->pitch, cout, wp.g, Z, st)) return e;
   const pm_tensor xv = {V, 1, 1, (int32_t)wp.g.tiles, wp.Kp, wp.Kp};
   const pm_tensor zv = {Z, 1, 1, (int32_t)wp.g.tiles, cout, cout};
-  const pm_conv_params p1 = {1, 1, 1, 0, 1, 0};
+  const pm_conv_params p1 = {(int32_t)sizeof(pm_conv_params), 1, 1, 1, 0, 1, 0};
   ConvK k;
   fill_geom(k, &xv, &zv, &p1);
   k.A = Z, k.B = V, k.C = slab;
@@ -1372,7 +1374,7 @@ int conv_wgrad_bf16(const pm_tensor* x, const pm_tensor* dy, float* dw, const pm
   const int Pf = (int)(b.P / 2);
   const pm_tensor av = {dyt, 1, 1, (int32_t)b.M, Pf, Pf};          // fp32-typed views: rows of P / 2 floats
   const pm_tensor cv = {dw, 1, 1, (int32_t)b.M, (int32_t)b.Nn, b.Nn};
-  const pm_conv_params p1 = {1, 1, 1, 0, 1, 2};
+  const pm_conv_params p1 = {(int32_t)sizeof(pm_conv_params), 1, 1, 1, 0, 1, 2};
   ConvK k;
   fill_geom(k, &av, &cv, &p1);
   k.prec = 2;
@@ -1541,6 +1543,9 @@ extern "C" size_t pm_conv_workspace(const pm_tensor* x, const pm_tensor* y, cons
 extern "C" int pm_conv_fwd(const pm_tensor* x, const float* w, const pm_tensor* y, const pm_conv_params* p,
                            const pm_conv_epilogue* ep, void* ws, size_t ws_bytes, void* stream) {
   if (int e = check_common(x, y, p)) return e;
+  PM_REQUIRE(!ep || ep->struct_size == (int64_t)sizeof(pm_conv_epilogue), PM_EINVAL,
+             "conv_fwd: pm_conv_epilogue.struct_size %ld != %zu -- caller built against another pinmem_hip.h (library ABI %d)", ep ? (long)ep->struct_size : 0l,
+             sizeof(pm_conv_epilogue), PM_ABI_VERSION);
   if (ep && ep->bn_partials) {
     PM_REQUIRE(!ep->relu && !ep->residual, PM_EINVAL, "conv_fwd: bn_partials are the statistics of the convolution output (no residual / ReLU)");
     const size_t need = pm_conv_bn_partials_bytes(x, y, p);
@@ -1548,7 +1553,7 @@ extern "C" int pm_conv_fwd(const pm_tensor* x, const float* w, const pm_tensor* 
   }
   PM_REQUIRE(w && pm_aligned16(w), PM_EINVAL, "conv_fwd: weight null or unaligned");
   {
-    pm_conv_epilogue e1 = {nullptr, nullptr, nullptr, nullptr, 0, 0};
+    pm_conv_epilogue e1 = {(int64_t)sizeof(pm_conv_epilogue), nullptr, nullptr, nullptr, nullptr, 0, 0};
     if (ep) e1 = *ep;
     PM_REQUIRE((e1.scale == nullptr) == (e1.shift == nullptr), PM_EINVAL, "conv_fwd: scale and shift go together");
     const WinoPlan wp = wino_plan(x, y->c, p);
@@ -1562,7 +1567,7 @@ extern "C" int pm_conv_fwd(const pm_tensor* x, const float* w, const pm_tensor* 
   if (p->prec == 2) {
     const Bf16Plan b = bf16_plan(x, y, p);
     if (b.use) {
-      pm_conv_epilogue e2 = {nullptr, nullptr, nullptr, nullptr, 0, 0};
+      pm_conv_epilogue e2 = {(int64_t)sizeof(pm_conv_epilogue), nullptr, nullptr, nullptr, nullptr, 0, 0};
       if (ep) e2 = *ep;
       PM_REQUIRE((e2.scale == nullptr) == (e2.shift == nullptr), PM_EINVAL, "conv_fwd: scale and shift go together");
       PM_REQUIRE(ws && ws_bytes >= bf16_ws(b), PM_EWORKSPACE, "conv_fwd(bf16): workspace %zu < %zu", ws_bytes, bf16_ws(b));
@@ -1579,7 +1584,7 @@ extern "C" int pm_conv_fwd(const pm_tensor* x, const float* w, const pm_tensor* 
   k.A = (const float*)x->ptr, k.B = w;
   k.M = (int)M, k.Nn = (int)Nn, k.K = (int)K;
   k.a_bytes = (unsigned)(pm_pixels(x) * x->pitch * 4), k.b_bytes = (unsigned)((long)y->c * K * 4), k.kmode = x->c % BK == 0 ? 0 : (x->c >= BK ? 1 : 2);
-  pm_conv_epilogue e0 = {nullptr, nullptr, nullptr, nullptr, 0, 0};
+  pm_conv_epilogue e0 = {(int64_t)sizeof(pm_conv_epilogue), nullptr, nullptr, nullptr, nullptr, 0, 0};
   if (ep) e0 = *ep;
   PM_REQUIRE((e0.scale == nullptr) == (e0.shift == nullptr), PM_EINVAL, "conv_fwd: scale and shift go together");
   hipStream_t st = (hipStream_t)stream;
@@ -1652,7 +1657,7 @@ extern "C" int pm_conv_bwd_data(const pm_tensor* dy, const float* w, const pm_te
     const Bf16Plan b = bf16_plan(dy, dx, &q);
     if (b.use) {
       PM_REQUIRE(ws && ws_bytes >= bf16_ws(b), PM_EWORKSPACE, "conv_bwd_data(bf16): workspace %zu < %zu", ws_bytes, bf16_ws(b));
-      const pm_conv_epilogue e1 = {nullptr, nullptr, nullptr, addp, add_pitch, 0};
+      const pm_conv_epilogue e1 = {(int64_t)sizeof(pm_conv_epilogue), nullptr, nullptr, nullptr, addp, add_pitch, 0};
       return conv_bf16(dy, w, dy->c, dx->c, true, dx, &q, b, e1, ws, st0);
     }
   }
@@ -1660,7 +1665,7 @@ extern "C" int pm_conv_bwd_data(const pm_tensor* dy, const float* w, const pm_te
     const WinoPlan wp = wino_plan(dy, dx->c, p);
     if (wp.use) {
       PM_REQUIRE(ws && ws_bytes >= wino_ws(wp), PM_EWORKSPACE, "conv_bwd_data(winograd): workspace %zu < %zu", ws_bytes, wino_ws(wp));
-      const pm_conv_epilogue e1 = {nullptr, nullptr, nullptr, addp, add_pitch, 0};
+      const pm_conv_epilogue e1 = {(int64_t)sizeof(pm_conv_epilogue), nullptr, nullptr, nullptr, addp, add_pitch, 0};
       return wino_conv(dy, w, dy->c, dx->c, true, dx, wp, e1, ws, st0);
     }
   }

@@ -12,7 +12,7 @@ void pm_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* pm_last_error(void) { return g_err; }
-extern "C" int pm_version(void) { return 100; }
+extern "C" int pm_version(void) { return PM_ABI_VERSION; }
 
 #define LD4 PM_LD4
 #define ST4 PM_ST4

@@ -146,7 +146,7 @@ def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, res
     ho, wo = conv_out_hw(h, w_, kh, stride, pad, dil)
     y = out if out is not None else new((n, ho, wo, cout), x, pitch_pad=True)
     xd, yd = tdesc(x), tdesc(y)
-    p = PmConvParams(kh, kw, stride, pad, dil, CONV_PREC)
+    p = L.conv_params(kh, kw, stride, pad, dil, CONV_PREC)
     lib = _lib()
     if keep_v is not None:
         nbv = lib.pm_conv_winograd_v_bytes(byref(xd), byref(yd), byref(p)) if KEEP_WINOGRAD_V else 0
@@ -167,7 +167,7 @@ def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, res
     ep = None
     if bias is not None or scale is not None or residual is not None or relu or part is not None:
         rd = tdesc(residual) if residual is not None else None
-        ep = PmConvEpilogue(ptr(bias), ptr(scale), ptr(shift), rd.ptr if rd else None, rd.pitch if rd else 0, 1 if relu else 0, ptr(part),
+        ep = L.conv_epilogue(ptr(bias), ptr(scale), ptr(shift), rd.ptr if rd else None, rd.pitch if rd else 0, 1 if relu else 0, ptr(part),
                             part.numel() * 4 if part is not None else 0)
     check(lib.pm_conv_fwd(byref(xd), w_krsc.data_ptr(), byref(yd), byref(p), byref(ep) if ep else None, ptr(ws), nb, stream()), 'pm_conv_fwd')
     if fresh_u is not None:             # later hits from another stream wait for this launch
@@ -180,7 +180,7 @@ def conv_bwd_data(dy, w_krsc, x_shape, stride, pad, dil, add=None):
     cout, kh, kw, cin = w_krsc.shape
     dx = new(x_shape, dy)
     dyd, dxd = tdesc(dy), tdesc(dx)
-    p = PmConvParams(kh, kw, stride, pad, dil, CONV_PREC)
+    p = L.conv_params(kh, kw, stride, pad, dil, CONV_PREC)
     lib = _lib()
     nb = lib.pm_conv_workspace(byref(dxd), byref(dyd), byref(p), 1)
     ws = workspace(nb, dy.device) if nb else None
@@ -194,7 +194,7 @@ def conv_bwd_weight(x, dy, w_shape_krsc, stride, pad, dil, want_bias=False, wino
     dw = torch.empty(w_shape_krsc, dtype=torch.float32, device=x.device)
     db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_bias else None
     xd, dyd = tdesc(x), tdesc(dy)
-    p = PmConvParams(kh, kw, stride, pad, dil, CONV_PREC)
+    p = L.conv_params(kh, kw, stride, pad, dil, CONV_PREC)
     if wino_v is not None:       # Winograd-transformed x kept by conv_fwd(keep_v=...)
         p.wino_v, p.wino_v_bytes = wino_v.data_ptr(), wino_v.numel() * 4
     lib = _lib()

@@ -19,14 +19,25 @@ class PmSgdEntry(ctypes.Structure):
 
 
 class PmConvParams(ctypes.Structure):
-    _fields_ = [('kh', c_int32), ('kw', c_int32), ('stride', c_int32), ('pad', c_int32), ('dil', c_int32), ('prec', c_int32),
+    _fields_ = [('struct_size', c_int32), ('kh', c_int32), ('kw', c_int32), ('stride', c_int32), ('pad', c_int32), ('dil', c_int32), ('prec', c_int32),
                 ('wino_v', c_void_p), ('wino_v_bytes', c_int64),
                 ('wxf', c_void_p), ('wxf_bytes', c_int64), ('wxf_valid', c_int32)]
 
 
 class PmConvEpilogue(ctypes.Structure):
-    _fields_ = [('bias', c_void_p), ('scale', c_void_p), ('shift', c_void_p), ('residual', c_void_p),
+    _fields_ = [('struct_size', c_int64), ('bias', c_void_p), ('scale', c_void_p), ('shift', c_void_p), ('residual', c_void_p),
                 ('residual_pitch', c_int64), ('relu', c_int32), ('bn_partials', c_void_p), ('bn_partials_bytes', c_int64)]
+
+
+def conv_params(kh, kw, stride, pad, dil, prec=0):
+    return PmConvParams(ctypes.sizeof(PmConvParams), kh, kw, stride, pad, dil, prec)
+
+
+def conv_epilogue(*fields):
+    return PmConvEpilogue(ctypes.sizeof(PmConvEpilogue), *fields)
+
+
+ABI_VERSION = 300          # include/pinmem_hip.h PM_ABI_VERSION this binding was written against
 
 
 class PinmemError(RuntimeError):
@@ -124,6 +135,8 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the header and the library drift apart
         fn.restype, fn.argtypes = res, args
+    if lib.pm_version() != ABI_VERSION:
+        raise PinmemError('%s reports ABI %d, this binding is written against %d (include/pinmem_hip.h)' % (LIB_PATH, lib.pm_version(), ABI_VERSION))
     _lib = lib
     return lib
 

@@ -23,8 +23,30 @@ def test_library_builds_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), 'missing export ' + n
     assert sorted(L.SIGNATURES) == names, 'ctypes table and header drifted apart'
-    assert lib.pm_version() >= 100
+    hdr = int(re.search(r'#define PM_ABI_VERSION (\d+)', open(os.path.join(ROOT, 'include', 'pinmem_hip.h')).read()).group(1))
+    assert lib.pm_version() == hdr == L.ABI_VERSION          # library, header and ctypes binding agree on the struct layouts
     assert lib.pm_last_error() is not None
+
+
+def test_struct_size_guards_reject_a_caller_built_against_another_header():
+    """pm_conv_params / pm_conv_epilogue grew in rounds 2 and 3; their first member is their own size, and an entry point that receives another size
+    (a consumer compiled against an older header) refuses the call instead of reading past the caller's object."""
+    import ctypes
+    from ctypes import byref
+    lib = L.load()
+    assert ctypes.sizeof(L.PmConvParams) == L.conv_params(3, 3, 1, 1, 1).struct_size
+    buf = (ctypes.c_float * 64)()
+    x = L.PmTensor(ctypes.addressof(buf), 1, 2, 2, 4, 4)
+    y = L.PmTensor(ctypes.addressof(buf), 1, 2, 2, 4, 4)
+    p = L.conv_params(1, 1, 1, 0, 1)
+    p.struct_size -= 8                                     # "older header"
+    assert lib.pm_conv_fwd(byref(x), ctypes.addressof(buf), byref(y), byref(p), None, None, 0, None) == -1
+    assert b'struct_size' in lib.pm_last_error()
+    p = L.conv_params(1, 1, 1, 0, 1)
+    ep = L.conv_epilogue(None, None, None, None, 0, 0, None, 0)
+    ep.struct_size = 48
+    assert lib.pm_conv_fwd(byref(x), ctypes.addressof(buf), byref(y), byref(p), byref(ep), None, 0, None) == -1
+    assert b'pm_conv_epilogue.struct_size' in lib.pm_last_error()
 
 
 def test_argument_validation_without_gpu():

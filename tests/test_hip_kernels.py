@@ -693,7 +693,7 @@ def test_c_abi_error_conventions(K):
     x, y = nhwc(rnd(1, 64, 8, 8, seed=1)), torch.empty(1, 8, 8, 64, device='cuda')
     w = rnd(64, 3, 3, 64, seed=2).cuda()
     xd, yd = L.tdesc(x), L.tdesc(y)
-    p = L.PmConvParams(3, 3, 1, 1, 1, 0)
+    p = L.conv_params(3, 3, 1, 1, 1, 0)
     need = lib.pm_conv_workspace(byref(xd), byref(yd), byref(p), 0)
     ws = torch.empty(max(need, 16), dtype=torch.uint8, device='cuda')
     assert lib.pm_conv_fwd(byref(xd), None, byref(yd), byref(p), None, ws.data_ptr(), need, st) == EINVAL          # no weight

@@ -5,6 +5,8 @@ import torch
 from pinthememory_amd import harness, synth
 from pinthememory_amd.network import deepv3plus
 crit = torch.nn.CrossEntropyLoss(reduction='mean', ignore_index=255)
+from pinthememory_amd.hip import kernels as _K
+_K.set_conv_precision(os.environ.get('DTYPE', 'f32'))      # DTYPE=bf16: is the configs[2] tier host-bound?
 buckets = None
 force = os.environ.get('PM_DIST_FORCE', '0') == '1'      # one-rank RCCL rehearsal: what do the collectives of the N > 1 path cost?
 if force:
