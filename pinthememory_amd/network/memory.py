@@ -35,6 +35,12 @@ class Writingnet(nn.Module):
         return ops.conv_bn_act(x, self.writefeat[0], self.writefeat[1], relu=True, residual=x)
 
 
+# Memory_sup -> event after which its m_items is complete, when the tensor was produced on another stream (harness.agg_train_step runs the commit
+# forward on its own). Kept OUTSIDE the module: the reference's callers deep-copy networks (train.py:246-277 get_updated_network) and pickle them, and a
+# stream event is neither.
+_PENDING = __import__('weakref').WeakKeyDictionary()
+
+
 class Memory_sup(nn.Module):
     def __init__(self, memory_size, input_feature_dim, feature_dim, momentum, temperature, gumbel_read):
         super().__init__()
@@ -51,7 +57,6 @@ class Memory_sup(nn.Module):
         self.celoss = nn.CrossEntropyLoss(ignore_index=255)
         self.gumbel_read = gumbel_read
         self.writeTF = lambda x: x.clone()
-        self.pending = None       # event after which m_items is complete, when its producer ran on another stream (harness: overlapped commit forward)
         self.m_items = F.normalize(torch.rand((memory_size, feature_dim), dtype=torch.float), dim=1)
         initialize_weights(self)
         self.noise_fn = None      # parity hook: callable(rows, slots, device) -> (noise_dim0, noise_dim1)
@@ -60,18 +65,29 @@ class Memory_sup(nn.Module):
     # produced on another stream (harness.agg_train_step runs the commit forward on its own), the first READ from anywhere -- the next memory read,
     # a checkpoint, a test -- orders the reader's stream behind the producer; harness code that only passes the tensor on uses _m_items.
     @property
+    def pending(self):
+        return _PENDING.get(self)
+
+    @pending.setter
+    def pending(self, event):
+        if event is None:
+            _PENDING.pop(self, None)
+        else:
+            _PENDING[self] = event
+
+    @property
     def m_items(self):
-        if self.pending is not None:
+        ev = _PENDING.pop(self, None)
+        if ev is not None:
             cur = torch.cuda.current_stream()
-            cur.wait_event(self.pending)
+            cur.wait_event(ev)
             if self._m_items.is_cuda:
                 self._m_items.record_stream(cur)
-            self.pending = None
         return self._m_items
 
     @m_items.setter
     def m_items(self, value):
-        self.pending = None
+        _PENDING.pop(self, None)
         self._m_items = value
 
     def _apply(self, fn, *args, **kwargs):
