@@ -100,10 +100,6 @@ int pm_set_winograd(int mode);
  * 32 channels x all 36 points). Same results to fp32 round-off; measured slower than GEMM + output-transform pass on every flagship layer
  * (DESIGN.md section 7), hence off by default: 0 off, 1 on. Process-wide like pm_set_winograd. */
 int pm_set_winograd_fused(int on);
-/* 1x1 / stride-1 convolutions with a reduction of 64 or 128 (forward with Cin = 64 / 128: Resnet.py:145-150 layer1 / layer2 expansions; data gradient
- * with Cout = 64 / 128) run on a streaming kernel: the weight chunk stays in LDS for the lifetime of a persistent block, every wave streams its own
- * 32-row tiles without block barriers (csrc/pointwise.hip). 1 on (default), 0 = the tiled implicit-GEMM kernel. Process-wide. */
-int pm_set_pointwise_stream(int on);
 /* prec = 2 weight gradients on pixel-contiguous bf16 copies of x (one per tap) and dy instead of the staged-fp32 form: 0 off (default: the
  * copies cost more HBM time than the GEMM saves), 1 on. Process-wide like pm_set_winograd. */
 int pm_set_bf16_wgrad(int on);

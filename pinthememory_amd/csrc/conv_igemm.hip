@@ -1391,33 +1391,6 @@ int conv_wgrad_bf16(const pm_tensor* x, const pm_tensor* dy, float* dw, const pm
   return launch<MODE_FWD>(k, b.pl, st, 1, flops);
 }
 
-// Short-reduction 1x1 convolutions (K = 64 / 128, stride 1, no padding, fp32) on the streaming kernel of pointwise.hip. PM_PW_STREAM=0: tiled kernel.
-int g_pw_stream = getenv("PM_PW_STREAM") ? atoi(getenv("PM_PW_STREAM")) : 1;
-// -> PM_OK (launched), PM_EUNSUPPORTED (not taken), or an error
-int try_pointwise_stream(const pm_tensor* in, const float* w, bool transb, const pm_tensor* out, const pm_conv_params* p, const pm_conv_epilogue& ep, hipStream_t st) {
-  if (!g_pw_stream || p->kh != 1 || p->kw != 1 || p->stride != 1 || p->pad != 0 || p->prec != 0 || ep.bn_partials) return PM_EUNSUPPORTED;
-  if (!(in->c == 64 || in->c == 128) || pm_pixels(out) < 4096) return PM_EUNSUPPORTED;
-  if (((in->pitch | out->pitch | (ep.residual ? ep.residual_pitch : 0)) & 3) || (out->c & 31)) return PM_EUNSUPPORTED;
-  ProfRec rec;
-  if (g_prof_on) {
-    (void)hipEventCreate(&rec.a), (void)hipEventCreate(&rec.b);
-    rec.mode = transb ? MODE_DGRAD : MODE_FWD, rec.bm = 32, rec.bn = 256, rec.km = 0, rec.prec = 0, rec.nst = 0, rec.M = (int)pm_pixels(out), rec.Nn = out->c, rec.K = in->c, rec.batch = 1,
-    rec.ksplit = 1, rec.flops = 2.0 * (double)pm_pixels(out) * out->c * in->c;
-    (void)hipEventRecord(rec.a, st);
-  }
-  const int e = pm_pointwise_stream((const float*)in->ptr, in->pitch, w, transb, (float*)out->ptr, out->pitch, pm_pixels(out), out->c, in->c, ep.bias, ep.scale, ep.shift,
-                                    ep.residual, ep.residual_pitch, ep.relu, st);
-  if (g_prof_on) {
-    if (e == PM_OK) {
-      (void)hipEventRecord(rec.b, st);
-      g_prof.push_back(rec);
-    } else {
-      (void)hipEventDestroy(rec.a), (void)hipEventDestroy(rec.b);
-    }
-  }
-  return e;
-}
-
 void gemm_dims(int which, const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p, long& M, long& Nn, long& K) {
   const long T = (long)p->kh * p->kw;
   if (which == MODE_FWD) M = pm_pixels(y), Nn = y->c, K = T * x->c;
@@ -1434,10 +1407,6 @@ extern "C" int pm_set_winograd(int mode) {
 }
 extern "C" int pm_set_winograd_fused(int on) {
   g_wino_fused = on != 0;
-  return PM_OK;
-}
-extern "C" int pm_set_pointwise_stream(int on) {
-  g_pw_stream = on != 0;
   return PM_OK;
 }
 extern "C" int pm_set_bf16_wgrad(int on) {
@@ -1595,12 +1564,6 @@ extern "C" int pm_conv_fwd(const pm_tensor* x, const float* w, const pm_tensor* 
       return wino_conv(x, w, y->c, x->c, false, y, wp, e1, ws, (hipStream_t)stream, keep, uext, p->wxf_valid != 0);
     }
   }
-  {
-    pm_conv_epilogue e3 = {(int64_t)sizeof(pm_conv_epilogue), nullptr, nullptr, nullptr, nullptr, 0, 0};
-    if (ep) e3 = *ep;
-    const int e = try_pointwise_stream(x, w, false, y, p, e3, (hipStream_t)stream);
-    if (e != PM_EUNSUPPORTED) return e;
-  }
   if (p->prec == 2) {
     const Bf16Plan b = bf16_plan(x, y, p);
     if (b.use) {
@@ -1688,11 +1651,6 @@ extern "C" int pm_conv_bwd_data(const pm_tensor* dy, const float* w, const pm_te
                        (long)(tmp_bytes / sizeof(float)), valid_mask, (float*)dx->ptr, (long)dx->pitch, dx->n, dx->h, dx->w, dx->c, addp,
                        add_pitch);
     return pm_check_launch("dgrad_s2_interleave");
-  }
-  {
-    const pm_conv_epilogue e3 = {(int64_t)sizeof(pm_conv_epilogue), nullptr, nullptr, nullptr, addp, add_pitch, 0};
-    const int e = try_pointwise_stream(dy, w, true, dx, p, e3, st0);      // dx[M][Cin] = dy[M][Cout] . w[Cout][Cin]: B = w as it lies ([K][N])
-    if (e != PM_EUNSUPPORTED) return e;
   }
   if (dgrad_bf16_ok(p)) {      // data gradient of a stride-1 convolution = forward convolution of dy with the rotated / transposed filter
     const pm_conv_params q = dgrad_as_fwd(p);

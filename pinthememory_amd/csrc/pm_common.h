@@ -50,10 +50,6 @@ int pm_wino_fused_f4(const float* V, const float* U, int Cout, int Kp, const pm_
 int pm_wino_dy_xf(const float* dy, long pitch, int Cout, const pm_wino_geom& g, float* Z, hipStream_t st);
 int pm_wino_dw_xf(const float* slab, int ks, int Cout, int Cin, int Kp, int m, float* dw, hipStream_t st);
 
-// ---- streaming kernel of the short-reduction 1x1 convolutions (pointwise.hip); PM_EUNSUPPORTED = not this kernel's shape ------------------------
-int pm_pointwise_stream(const float* A, long lda, const float* B, bool transb, float* C, long ldc, long M, int N, int K, const float* bias, const float* scale,
-                        const float* shift, const float* res, long ldr, int relu, hipStream_t st);
-
 // ---- bf16 operand preparation of the convolution kernels (bf16.hip; prec = 2) ----------------------------------------------------------
 int pm_bf16_cast_rows(const float* x, long pitch, int C, int Cp, long P, void* out, hipStream_t st);
 int pm_bf16_cast_weights(const float* w, int Cout, int T, int Cin, int Cp, bool rotate, void* out, hipStream_t st);

@@ -626,11 +626,6 @@ def set_winograd_fused(on):
     check(_lib().pm_set_winograd_fused(1 if on else 0), 'pm_set_winograd_fused')
 
 
-def set_pointwise_stream(on):
-    """Short-reduction 1x1 convolutions (K = 64 / 128) on the streaming kernel of csrc/pointwise.hip (default on); False = tiled implicit GEMM."""
-    check(_lib().pm_set_pointwise_stream(1 if on else 0), 'pm_set_pointwise_stream')
-
-
 def set_bf16_wgrad(on):
     check(_lib().pm_set_bf16_wgrad(1 if on else 0), 'pm_set_bf16_wgrad')
 

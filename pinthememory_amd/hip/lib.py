@@ -59,7 +59,6 @@ SIGNATURES = {
     'pm_conv_bwd_weight': (_i, [_T, _T, _vp, _vp, _P, _vp, _sz, _vp]),
     'pm_set_winograd': (_i, [_i]),
     'pm_set_winograd_fused': (_i, [_i]),
-    'pm_set_pointwise_stream': (_i, [_i]),
     'pm_profile_enable': (_i, [_i]),
     'pm_profile_dump': (_i, [ctypes.c_char_p]),
     'pm_profile_read': (_i, [_i, _i, _i, _i, _i, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64), _i]),

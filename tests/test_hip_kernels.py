@@ -51,56 +51,6 @@ CONV_CASES = [
 ]
 
 
-PW_STREAM_CASES = [
-    # n, cin, h, w, cout: 1x1 / stride 1 convolutions whose forward (Cin = 64 / 128) or data gradient (Cout = 64 / 128) takes the streaming kernel
-    (2, 64, 64, 48, 256),      # layer1 conv3 / downsample (Resnet.py:145-150): K = 64, one 256-column chunk
-    (1, 64, 67, 71, 64),       # layer1.0.conv1 shape class, ragged last row tile (4757 rows), 64-column chunks
-    (1, 64, 72, 64, 192),      # three 64-column chunks
-    (2, 128, 48, 48, 512),     # layer2 conv3: K = 128, four 128-column chunks
-    (1, 128, 70, 66, 128),
-    (2, 256, 64, 48, 64),      # layer1 conv1 (256 -> 64): its DATA GRADIENT has K = 64, N = 256
-    (1, 512, 66, 70, 128),     # layer2 conv1 (512 -> 128): data gradient K = 128, N = 512
-]
-
-
-@pytest.mark.parametrize('case', PW_STREAM_CASES)
-def test_pointwise_stream_kernel(K, case):
-    """csrc/pointwise.hip against torch, forward with every fused epilogue (bias, affine, residual, ReLU, channel-slice output) and the data gradient
-    with its fused skip add; the streaming kernel is really taken (other bits than the tiled kernel, PM_PW_STREAM=0 equivalent via pm_set_pointwise_stream)."""
-    n, cin, h, w, cout = case
-    x = rnd(n, cin, h, w, seed=1)
-    wt = rnd(cout, cin, 1, 1, seed=2, scale=(2.0 / cin) ** 0.5)
-    b, sc, sh = rnd(cout, seed=3), rnd(cout, seed=5).abs() + 0.5, rnd(cout, seed=6)
-    res = rnd(n, cout, h, w, seed=7)
-    xr, wr = x.double().requires_grad_(True), wt.double().requires_grad_(True)
-    y_ref = F.conv2d(xr, wr)
-    dy = rnd(*y_ref.shape, seed=4)
-    y_ref.backward(dy.double())
-    add = rnd(n, cin, h, w, seed=8)
-    xg, wg, dyg, addg, resg = nhwc(x), wt.permute(0, 2, 3, 1).contiguous().cuda(), nhwc(dy), nhwc(add), nhwc(res)
-    out = {}
-    for stream_on in (True, False):
-        K.set_pointwise_stream(stream_on)
-        try:
-            buf = torch.zeros(n, h, w, cout + 64, device='cuda')
-            y0 = K.conv_fwd(xg, wg, 1, 0, 1)
-            y1 = K.conv_fwd(xg, wg, 1, 0, 1, bias=b.cuda(), out=buf[..., 32:32 + cout])
-            assert buf[..., :32].abs().max().item() == 0 and buf[..., 32 + cout:].abs().max().item() == 0
-            y2 = K.conv_fwd(xg, wg, 1, 0, 1, scale=sc.cuda(), shift=sh.cuda(), residual=resg, relu=True)
-            dx = K.conv_bwd_data(dyg, wg, tuple(xg.shape), 1, 0, 1, add=addg)
-            out[stream_on] = (nchw(y0).clone(), nchw(y1).clone(), nchw(y2), nchw(dx))
-        finally:
-            K.set_pointwise_stream(True)
-    yd = y_ref.detach()
-    for got in out.values():
-        assert rel(got[0], yd) < 2e-5
-        assert rel(got[1], yd + b.double()[None, :, None, None]) < 2e-5
-        assert rel(got[2], torch.relu(yd * sc.double()[None, :, None, None] + sh.double()[None, :, None, None] + res.double())) < 2e-5
-        assert rel(got[3], xr.grad + add.double()) < 2e-5
-    taken_fwd, taken_bwd = cin in (64, 128), cout in (64, 128)
-    assert torch.equal(out[True][0], out[False][0]) != taken_fwd and torch.equal(out[True][3], out[False][3]) != taken_bwd
-
-
 @pytest.mark.parametrize('case', CONV_CASES)
 def test_conv_fwd_bwd(K, case):
     n, cin, h, w, cout, k, s, p, d, has_bias = case

@@ -1,3 +1,9 @@
+// LAB KERNEL, NOT PART OF THE LIBRARY (round 3; it was wired into pm_conv_fwd / pm_conv_bwd_data at commit "Streaming kernel for the short-reduction
+// 1x1 convolutions", passed the kernel tests there -- bit-identical to the tiled kernel: the same k pairing per MFMA -- and measured SLOWER on the
+// same box: 64 -> 256 @192^2 0.140 vs 0.135 ms, 128 -> 512 @96^2 0.130 vs 0.114 ms, data gradient of 256 -> 64 0.149 vs 0.137 ms, step 65.5 vs 64.3 ms).
+// These shapes sit where both rooflines meet (9.66 GFLOP = 61 us of fp32 MFMA; 370 MB = 62 us of HBM at 6 TB/s): the tiled kernel and this one both
+// land at ~2.2 x that, with exactly algorithmic traffic (tools/gpu_shape_traffic.sh). Kept for the record next to gemm_lab.hip.
+//
 // Streaming kernel for the short-reduction 1x1 convolutions (Cin = 64 / 128 forward, Cout = 64 / 128 data gradient): layer1's 64 -> 256 and
 // 64 -> 64 (Resnet.py:145-150 at 192 x 192), layer2's 128 -> 512, and the data gradients of the 256 -> 64 / 512 -> 128 reductions.
 //   C[M][N] = A[M][K] . B[N][K]^T,  K in {64, 128}: 2 / 4 K-steps of the tiled implicit-GEMM kernel, whose blocks then live for one load phase, a
@@ -9,7 +15,7 @@
 // under another's loads and stores: the next tile's rows are in flight (registers) during the current tile's MFMAs, a finished 32 x 32 tile goes
 // through the wave's stage into whole 128-byte row segments. v_mfma_f32_32x32x2_f32, k ascending per lane pair: the same fp32 products as the
 // tiled kernel, accumulated in a different (fixed) order.
-#include "pm_common.h"
+#include "../../pinthememory_amd/csrc/pm_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
