@@ -134,6 +134,13 @@ int pm_bn_finalize(const float* moments, int c, float eps, float* mean, float* i
 /* y = relu?( (x-mean)*invstd*gamma + beta + residual? ) */
 int pm_bn_apply(const pm_tensor* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
                 const pm_tensor* residual /*nullable*/, int relu, const pm_tensor* y, void* stream);
+/* the same, and (mask != NULL) one byte per float4 channel group of y: bit e set <=> element e of the group is positive BEFORE the ReLU clamp, i.e. the
+ * ReLU passes its gradient. Dense [pixels][c / 4] bytes whatever the pitches. pm_bn_bwd_reduce_mask then masks the incoming gradient from these bytes
+ * instead of re-reading the forward output (BN + residual + ReLU, Resnet.py:207-216): 1 / 16 of the bytes. */
+int pm_bn_apply_mask(const pm_tensor* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                     const pm_tensor* residual /*nullable*/, int relu, const pm_tensor* y, uint8_t* mask /*nullable*/, void* stream);
+int pm_bn_bwd_reduce_mask(const pm_tensor* dy, const uint8_t* mask, const pm_tensor* x, const float* mean, const float* invstd,
+                          const pm_tensor* gmask /*nullable*/, float* sums, void* ws, size_t ws_bytes, void* stream);
 /* backward: dyz = dy * mask, sums[2*C] = sum(dyz) | sum(dyz * xhat).  relu: 0 no activation (mask = 1); 1 mask = y > 0 read from the
  * forward output (BN + residual + ReLU, Resnet.py:207-216); 2 mask rebuilt from x with gamma / beta (BN + ReLU without a residual:
  * one tensor less to read).  gmask (nullable, relu != 0): dyz is also stored there -- it is the gradient of the residual branch, and

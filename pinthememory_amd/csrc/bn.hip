@@ -158,6 +158,7 @@ __global__ __launch_bounds__(256) void bn_partials_final(const float* __restrict
 // RELU 0: no activation. 1: mask = y > 0 read from the forward output (needed when a residual was added before the ReLU).
 // 2: mask rebuilt from x (y = relu(bn(x)), no residual) -- one tensor less to read. GOUT: also store dyz (the gradient of the
 // residual branch), so that the apply pass reads one tensor (dyz) instead of two (dy, y).
+// 3: mask from the byte per float4 group bn_apply left behind (bit e = output e of the group was positive): 1 / 16 of the bytes of reading y.
 template <int RELU, bool GOUT>
 __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ dy, long dpitch, const float* __restrict__ y, long ypitch,
                                                       const float* __restrict__ x, long xpitch, const float* __restrict__ mean,
@@ -178,6 +179,9 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
       if (RELU == 1) {
         const float4 o = PM_LD4(y + p * ypitch + c);
         d.x = o.x > 0.f ? d.x : 0.f, d.y = o.y > 0.f ? d.y : 0.f, d.z = o.z > 0.f ? d.z : 0.f, d.w = o.w > 0.f ? d.w : 0.f;
+      } else if (RELU == 3) {
+        const unsigned mb = reinterpret_cast<const unsigned char*>(y)[p * (C >> 2) + (c >> 2)];
+        d.x = (mb & 1u) ? d.x : 0.f, d.y = (mb & 2u) ? d.y : 0.f, d.z = (mb & 4u) ? d.z : 0.f, d.w = (mb & 8u) ? d.w : 0.f;
       } else if (RELU == 2) {
         d.x = bn_affine(v.x, mu.x, is.x, ga.x, be.x) > 0.f ? d.x : 0.f, d.y = bn_affine(v.y, mu.y, is.y, ga.y, be.y) > 0.f ? d.y : 0.f;
         d.z = bn_affine(v.z, mu.z, is.z, ga.z, be.z) > 0.f ? d.z : 0.f, d.w = bn_affine(v.w, mu.w, is.w, ga.w, be.w) > 0.f ? d.w : 0.f;
@@ -360,6 +364,11 @@ extern "C" int pm_bn_fold_multi(const void* table, const int* cs, const int* off
 
 extern "C" int pm_bn_apply(const pm_tensor* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const pm_tensor* res,
                            int relu, const pm_tensor* y, void* stream) {
+  return pm_bn_apply_mask(x, mean, invstd, gamma, beta, res, relu, y, nullptr, stream);
+}
+
+extern "C" int pm_bn_apply_mask(const pm_tensor* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const pm_tensor* res,
+                                int relu, const pm_tensor* y, uint8_t* mask, void* stream) {
   if (int e = check_bn(x, "bn_apply")) return e;
   if (int e = check_bn(y, "bn_apply")) return e;
   PM_REQUIRE(pm_same_shape(x, y) && mean && invstd && gamma && beta, PM_EINVAL, "bn_apply: bad args");
@@ -369,7 +378,7 @@ extern "C" int pm_bn_apply(const pm_tensor* x, const float* mean, const float* i
   }
   const float *px = (const float*)x->ptr, *pr = res ? (const float*)res->ptr : nullptr;
   float* py = (float*)y->ptr;
-  const long a = x->pitch, b = res ? res->pitch : 0, c = y->pitch;
+  const long a = x->pitch, b = res ? res->pitch : 0, c = y->pitch, cq = x->c >> 2;
   return pm_ew_launch(true, pm_pixels(x), x->c, (hipStream_t)stream, "bn_apply", [=] __device__(long p, int ch) {
     const float4 v = PM_LD4(px + p * a + ch), mu = PM_LD4(mean + ch), is = PM_LD4(invstd + ch), ga = PM_LD4(gamma + ch), be = PM_LD4(beta + ch);
     float4 o = make_float4(bn_affine(v.x, mu.x, is.x, ga.x, be.x), bn_affine(v.y, mu.y, is.y, ga.y, be.y), bn_affine(v.z, mu.z, is.z, ga.z, be.z),
@@ -378,6 +387,7 @@ extern "C" int pm_bn_apply(const pm_tensor* x, const float* mean, const float* i
       const float4 q = PM_LD4(pr + p * b + ch);
       o.x += q.x, o.y += q.y, o.z += q.z, o.w += q.w;
     }
+    if (mask) mask[p * cq + (ch >> 2)] = (unsigned char)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
     if (relu) o.x = fmaxf(o.x, 0.f), o.y = fmaxf(o.y, 0.f), o.z = fmaxf(o.z, 0.f), o.w = fmaxf(o.w, 0.f);
     PM_ST4(py + p * c + ch, o);
   });
@@ -412,6 +422,31 @@ extern "C" int pm_bn_bwd_reduce(const pm_tensor* dy, const pm_tensor* y, const p
 #undef PM_BN_BWD_PARTIAL
   hipLaunchKernelGGL(bn_bwd_final, dim3(pm_cdiv(x->c, FC)), dim3(256), 0, st, (const float*)ws, nb, x->c, sums);
   return pm_check_launch("bn_bwd_reduce");
+}
+
+// BN + residual + ReLU backward reduce with the ReLU mask taken from pm_bn_apply_mask's bytes instead of the forward output: sums and the masked
+// gradient gmask (= the gradient of the residual branch), as pm_bn_bwd_reduce(relu = 1) gives them -- same values, 1 / 16 of the mask bytes.
+extern "C" int pm_bn_bwd_reduce_mask(const pm_tensor* dy, const uint8_t* mask, const pm_tensor* x, const float* mean, const float* invstd,
+                                     const pm_tensor* gmask, float* sums, void* ws, size_t ws_bytes, void* stream) {
+  if (int e = check_bn(dy, "bn_bwd_reduce_mask")) return e;
+  if (int e = check_bn(x, "bn_bwd_reduce_mask")) return e;
+  PM_REQUIRE(pm_same_shape(dy, x) && mean && invstd && sums && mask, PM_EINVAL, "bn_bwd_reduce_mask: bad args");
+  PM_REQUIRE(!gmask || (pm_vec4(gmask) && pm_same_shape(gmask, x)), PM_EINVAL, "bn_bwd_reduce_mask: gmask must have the shape of x");
+  PM_REQUIRE(ws && ws_bytes >= pm_bn_workspace(x), PM_EWORKSPACE, "bn_bwd_reduce_mask: workspace too small");
+  const long P = pm_pixels(x);
+  const int rows = chunk_rows(P, x->c), nb = pm_cdiv(P, rows);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(nb, pm_cdiv(x->c, CB));
+  float* pg = gmask ? (float*)gmask->ptr : nullptr;
+  const long gp = gmask ? gmask->pitch : 0;
+  if (gmask)
+    hipLaunchKernelGGL((bn_bwd_partial<3, true>), grid, dim3(256), 0, st, (const float*)dy->ptr, (long)dy->pitch, reinterpret_cast<const float*>(mask), 0l,
+                       (const float*)x->ptr, (long)x->pitch, mean, invstd, (const float*)nullptr, (const float*)nullptr, pg, gp, P, x->c, rows, (float*)ws);
+  else
+    hipLaunchKernelGGL((bn_bwd_partial<3, false>), grid, dim3(256), 0, st, (const float*)dy->ptr, (long)dy->pitch, reinterpret_cast<const float*>(mask), 0l,
+                       (const float*)x->ptr, (long)x->pitch, mean, invstd, (const float*)nullptr, (const float*)nullptr, pg, gp, P, x->c, rows, (float*)ws);
+  hipLaunchKernelGGL(bn_bwd_final, dim3(pm_cdiv(x->c, FC)), dim3(256), 0, st, (const float*)ws, nb, x->c, sums);
+  return pm_check_launch("bn_bwd_reduce_mask");
 }
 
 extern "C" int pm_bn_bwd_apply(const pm_tensor* dy, const pm_tensor* y, const pm_tensor* x, const float* mean, const float* invstd, const float* gamma,

@@ -287,12 +287,31 @@ def bn_fold(gamma, beta, running_mean, running_var, eps, conv_bias=None):
     return scale, shift
 
 
-def bn_apply(x, mean, invstd, gamma, beta, residual=None, relu=False, out=None):
+def bn_apply(x, mean, invstd, gamma, beta, residual=None, relu=False, out=None, want_mask=False):
+    """want_mask: also -> uint8 [pixels, C / 4], bit e of a byte = output e of that float4 group is positive (the ReLU mask for bn_bwd_reduce_mask)."""
     y = out if out is not None else torch.empty_like(x, memory_format=torch.contiguous_format)
     rd = tdesc(residual) if residual is not None else None
-    check(_lib().pm_bn_apply(byref(tdesc(x)), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), byref(rd) if rd else None,
-                             1 if relu else 0, byref(tdesc(y)), stream()), 'pm_bn_apply')
-    return y
+    mask = torch.empty((x.shape[0] * x.shape[1] * x.shape[2], x.shape[3] // 4), dtype=torch.uint8, device=x.device) if want_mask else None
+    check(_lib().pm_bn_apply_mask(byref(tdesc(x)), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), byref(rd) if rd else None,
+                                  1 if relu else 0, byref(tdesc(y)), ptr(mask), stream()), 'pm_bn_apply_mask')
+    return (y, mask) if want_mask else y
+
+
+def bn_bwd_reduce_mask(dy, mask, x, mean, invstd, want_gmask=True, with_count=False):
+    """bn_bwd_reduce(relu=1) with the ReLU mask read from bn_apply(want_mask=True)'s bytes instead of the forward output."""
+    c = x.shape[3]
+    sums = torch.empty(2 * c + (1 if with_count else 0), dtype=torch.float32, device=x.device)
+    if with_count:
+        sums[2 * c:].fill_(float(x.shape[0] * x.shape[1] * x.shape[2]))
+    xd = tdesc(x)
+    lib = _lib()
+    nb = lib.pm_bn_workspace(byref(xd))
+    ws = workspace(nb, x.device)
+    gm = torch.empty(x.shape, dtype=torch.float32, device=x.device) if want_gmask else None
+    gd = tdesc(gm) if want_gmask else None
+    check(lib.pm_bn_bwd_reduce_mask(byref(tdesc(dy)), mask.data_ptr(), byref(xd), mean.data_ptr(), invstd.data_ptr(), byref(gd) if gd else None,
+                                    sums.data_ptr(), ptr(ws), nb, stream()), 'pm_bn_bwd_reduce_mask')
+    return sums, gm
 
 
 def scale_shift_act(x, scale, shift, residual=None, relu=False):

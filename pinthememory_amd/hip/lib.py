@@ -72,6 +72,8 @@ SIGNATURES = {
     'pm_bn_fold': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp]),
     'pm_bn_fold_multi': (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp]),
     'pm_bn_apply': (_i, [_T, _vp, _vp, _vp, _vp, _T, _i, _T, _vp]),
+    'pm_bn_apply_mask': (_i, [_T, _vp, _vp, _vp, _vp, _T, _i, _T, _vp, _vp]),
+    'pm_bn_bwd_reduce_mask': (_i, [_T, _vp, _T, _vp, _vp, _T, _vp, _vp, _sz, _vp]),
     'pm_bn_bwd_reduce': (_i, [_T, _T, _T, _vp, _vp, _vp, _vp, _i, _T, _vp, _vp, _sz, _vp]),
     'pm_bn_bwd_apply': (_i, [_T, _T, _T, _vp, _vp, _vp, _vp, _vp, _f, _i, _T, _T, _vp]),
     'pm_relu_bwd': (_i, [_T, _T, _T, _vp]),

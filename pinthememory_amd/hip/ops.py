@@ -135,7 +135,10 @@ def _wgrad(x, dy, wshape, geom, want_bias=False, deferred=False, wino_v=None):
 BN_FUSED_FINALIZE = _os.environ.get('PM_BN_FUSED', '1') == '1'      # A/B knob: 0 = separate bn_stats / bn_finalize launches
 
 
-def _bn_train_fwd(y, gamma, beta, bn, residual, relu, out=None, partials=None):
+RELU_MASK_BYTES = _os.environ.get('PM_BN_MASK', '1') == '1'      # A/B knob: 0 = the residual BatchNorms' backward re-reads the forward output for its ReLU mask
+
+
+def _bn_train_fwd(y, gamma, beta, bn, residual, relu, out=None, partials=None, want_mask=False):
     """Batch statistics (merged across ranks for SyncBN) -> normalise + residual + ReLU. Returns (o, mean, invstd).
     partials: the (mean, M2) slab partials the producing convolution's epilogue emitted for y (K.conv_fwd(bn_partials=...)), or None:
     with them no kernel re-reads y for its statistics."""
@@ -155,17 +158,23 @@ def _bn_train_fwd(y, gamma, beta, bn, residual, relu, out=None, partials=None):
         if bn.group is not None:
             mom = D.merge_moments(mom, c, bn.group)
         mean, invstd = K.bn_finalize(mom, c, bn.eps, bn.running_mean, bn.running_var, bn.momentum)
+    if want_mask:      # BN + residual + ReLU: one byte per float4 group tells the backward which gradients the ReLU passes (1 / 16 of re-reading the output)
+        o, mask = K.bn_apply(y, mean, invstd, gamma, beta, residual=residual, relu=relu, out=out, want_mask=True)
+        return o, mean, invstd, mask
     return K.bn_apply(y, mean, invstd, gamma, beta, residual=residual, relu=relu, out=out), mean, invstd
 
 
-def _bn_train_bwd(dv, o, y, mean, invstd, gamma, beta, relu, group, want_dres, has_res):
+def _bn_train_bwd(dv, o, y, mean, invstd, gamma, beta, relu, group, want_dres, has_res, mask=None):
     """-> (dy, dres, dgamma, dbeta): gradient of the conv output, of the residual input, and of the affine parameters.
     ReLU mask: rebuilt from the conv output when no residual entered the activation (the forward output is not read at all);
     otherwise taken from the forward output once, in the reduce pass, which then hands the masked gradient (= dres) to the apply pass."""
     c = y.shape[3]
     mode = 0 if not relu else (1 if has_res else 2)
     hand_over = mode == 1 and want_dres
-    sums, gm = K.bn_bwd_reduce(dv, o, y, mean, invstd, mode, gamma, beta, want_gmask=hand_over, with_count=group is not None)
+    if hand_over and mask is not None:
+        sums, gm = K.bn_bwd_reduce_mask(dv, mask, y, mean, invstd, want_gmask=True, with_count=group is not None)
+    else:
+        sums, gm = K.bn_bwd_reduce(dv, o, y, mean, invstd, mode, gamma, beta, want_gmask=hand_over, with_count=group is not None)
     local = sums
     if group is not None:
         # dgamma / dbeta are THIS rank's sums (torch.nn.SyncBatchNorm returns the local grad_weight / grad_bias and lets DDP average them);
@@ -203,17 +212,20 @@ class _Bottleneck(torch.autograd.Function):
         else:
             kd = yd = md = idd = None
             res = xv
-        out, m3, i3 = _bn_train_fwd(y3, g3, b3, bns[2], res, True, partials=ps[2])
+        if RELU_MASK_BYTES:
+            out, m3, i3, mask3 = _bn_train_fwd(y3, g3, b3, bns[2], res, True, partials=ps[2], want_mask=True)
+        else:
+            (out, m3, i3), mask3 = _bn_train_fwd(y3, g3, b3, bns[2], res, True, partials=ps[2]), None
         ctx.geoms, ctx.groups, ctx.has_ds, ctx.deferred = geoms, [b.group for b in bns], wd is not None, deferred
-        ctx.save_for_backward(xv, k1, k2, k3, kd, y1, o1, y2, o2, y3, yd, out, m1, i1, m2, i2, m3, i3, md, idd, g1, g2, g3, gd, b1, b2, b3, kv[0])
+        ctx.save_for_backward(xv, k1, k2, k3, kd, y1, o1, y2, o2, y3, yd, out, m1, i1, m2, i2, m3, i3, md, idd, g1, g2, g3, gd, b1, b2, b3, kv[0], mask3)
         return nchw(out)
 
     @staticmethod
     def backward(ctx, dout):
-        xv, k1, k2, k3, kd, y1, o1, y2, o2, y3, yd, out, m1, i1, m2, i2, m3, i3, md, idd, g1, g2, g3, gd, b1, b2, b3, v2 = ctx.saved_tensors
+        xv, k1, k2, k3, kd, y1, o1, y2, o2, y3, yd, out, m1, i1, m2, i2, m3, i3, md, idd, g1, g2, g3, gd, b1, b2, b3, v2, mask3 = ctx.saved_tensors
         ge, gr, df = ctx.geoms, ctx.groups, ctx.deferred
         dv = _grad_view(dout)
-        dy3, dres, dg3, db3 = _bn_train_bwd(dv, out, y3, m3, i3, g3, b3, True, gr[2], True, True)
+        dy3, dres, dg3, db3 = _bn_train_bwd(dv, out, y3, m3, i3, g3, b3, True, gr[2], True, True, mask=mask3)
         dw3, _ = _wgrad(o2, dy3, tuple(k3.shape), ge[2], deferred=df[2])
         do2 = K.conv_bwd_data(dy3, k3, tuple(o2.shape), *ge[2])
         dy2, _, dg2, db2 = _bn_train_bwd(do2, o2, y2, m2, i2, g2, b2, True, gr[1], False, False)

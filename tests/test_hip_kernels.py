@@ -271,6 +271,12 @@ def test_batchnorm_train(K, shape, relu, res):
         sums3, gm = K.bn_bwd_reduce(dyg, y, xg, mean, invstd, 1, want_gmask=True)
         dx3, _ = K.bn_bwd_apply(gm, None, xg, mean, invstd, g, sums3, n * h * w, 0, False)
         assert torch.equal(sums3, sums) and torch.equal(dx3, dx) and torch.equal(gm, dres)
+        # ... with the ReLU mask read from the byte per float4 group the forward left behind instead of the forward output: the same bits
+        y_m, mask = K.bn_apply(xg, mean, invstd, g, b, residual=nhwc(r), relu=True, want_mask=True)
+        assert torch.equal(y_m, y) and tuple(mask.shape) == (n * h * w, c // 4) and mask.dtype == torch.uint8
+        assert torch.equal(((mask.view(n, h, w, c // 4, 1) >> torch.arange(4, device='cuda', dtype=torch.uint8)) & 1).view(n, h, w, c).bool(), y > 0)
+        sums4, gm4 = K.bn_bwd_reduce_mask(dyg, mask, xg, mean, invstd)
+        assert torch.equal(sums4, sums) and torch.equal(gm4, gm)
 
 
 def test_pool_and_resize(K):
