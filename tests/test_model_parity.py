@@ -771,3 +771,32 @@ def test_commit_forward_on_its_own_stream_is_bit_identical(env):
         assert all(torch.equal(a_[k], b_[k]) for k in a_)
     assert torch.equal(m1, m0)
     assert all(torch.equal(v, n0.state_dict()[k]) for k, v in n1.state_dict().items())
+
+
+def test_commit_forward_overlap_flagship_size_default_config(env):
+    """The same bit-equality at the benchmark's own size and configuration (bs=8, 768 x 768, gumbel read in both forwards, Dropout2d(0.1)): kernels long
+    enough for the two streams to really run side by side; same seeds -> same draws (torch's generator hands out its offsets at enqueue time, whatever
+    the stream). Six steps, overlap on vs off: losses, committed memory and all 397 state entries."""
+    synth, h = env['synth'], env['harness']
+    x, y = synth.make_batch(8, 768)
+    x, y = x.cuda(), y.cuda()
+
+    def run(overlap):
+        prev = h.COMMIT_OVERLAP
+        h.COMMIT_OVERLAP = overlap
+        try:
+            torch.manual_seed(7)
+            torch.cuda.manual_seed(7)
+            net = synth.load_det_weights(env['deepv3plus'].DeepR50V3PlusD(synth.model_args(gumbel_off=False), 19, CRIT, CRIT)).cuda()
+            opt, sched = h.make_optimizer(net)
+            losses = [h.agg_train_step(net, opt, x, y, sched=sched) for _ in range(6)]
+            mem = net.memory.m_items.clone()
+            torch.cuda.synchronize()
+            return {k: v.clone() for k, v in net.state_dict().items()}, losses, mem
+        finally:
+            h.COMMIT_OVERLAP = prev
+    s1, l1, m1 = run(True)
+    s0, l0, m0 = run(False)
+    for a_, b_ in zip(l1, l0):
+        assert all(torch.equal(a_[k], b_[k]) for k in a_)
+    assert torch.equal(m1, m0) and all(torch.equal(s1[k], s0[k]) for k in s1)
