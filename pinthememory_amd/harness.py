@@ -51,7 +51,10 @@ def memory_only_forward(net, x, gts):
 # read every BatchNorm running moment (ops.last_prefold_event) -- the next training forward updates them; (3) Memory_sup waits for the committed memory
 # where it is first read (Memory_sup.pending); (4) transformed filters the commit forward wrote are event-ordered per cache entry (hip/kernels.py);
 # (5) the next SGD is behind (3) on the main stream, so the weights are not written under it. Results are bit-identical to the serial order.
-# Single process only: with more than one rank every collective of a step stays on one stream (dist.py). PM_COMMIT_OVERLAP=0 disables it.
+# With more than one rank every collective of a step stays on the MAIN stream (dist.py: one communicator, program order): the commit forward's only
+# exchange -- the memory-slot sum of its write -- is deferred to the next reader of m_items (Memory_sup.defer_sync: the all-reduce and the momentum
+# update are then issued where the next training forward reads the memory), eval-mode BatchNorm has none. Not under the reference's DDP wrapper, whose
+# forward broadcasts buffers on its own communicator. PM_COMMIT_OVERLAP=0 disables the overlap.
 COMMIT_OVERLAP = __import__('os').environ.get('PM_COMMIT_OVERLAP', '1') == '1'
 _commit_streams = {}
 
@@ -67,9 +70,6 @@ def agg_train_step(net, opt, x, gts, aux_gts=None, sched=None, buckets=None, tru
     aux_gts = gts if aux_gts is None else aux_gts
     m = net.module if hasattr(net, 'module') else net
     net.train()
-    # the memory is re-assigned, never written in place (memory.py:253,256; Memory_sup.write here), so holding the tensor is the reference's clone
-    # without a copy kernel at the head of the step (which would wait for an overlapped commit forward)
-    mem_t = m.memory._m_items.detach()
     if x.is_cuda and x.shape[1] == 3:
         # both forward passes of the step read the same batch: lay it out once as the stem's NHWC / 4-channel input
         x = ops.nchw(K.nchw_to_nhwc(x.float(), c_pad=4))
@@ -78,12 +78,16 @@ def agg_train_step(net, opt, x, gts, aux_gts=None, sched=None, buckets=None, tru
     else:
         opt.zero_grad()
     outputs = net(x, gts=gts, aux_gts=aux_gts, memory_writing=True, writing_detach=False)
+    # train.py:312 clones the memory before the forward; it is re-assigned, never written in place (memory.py:253,256; Memory_sup.write here), so the
+    # tensor the read just used IS that clone -- taken after the forward, because with an overlapped commit forward it only becomes final at that read
+    mem_t = m.memory.last_read
     loss = total_loss(outputs)
     loss.backward()
     if buckets is not None:
         buckets.finish()
     opt.step()
-    overlap = COMMIT_OVERLAP and x.is_cuda and buckets is None and not D.is_dist()
+    dist_on = D.is_dist()
+    overlap = COMMIT_OVERLAP and x.is_cuda and (not dist_on or (D.SYNC_MEMORY and not hasattr(net, 'module')))
     main = torch.cuda.current_stream() if x.is_cuda else None
     side = _commit_stream(x.device) if overlap else None
     if overlap:
@@ -93,11 +97,15 @@ def agg_train_step(net, opt, x, gts, aux_gts=None, sched=None, buckets=None, tru
     with torch.no_grad(), (torch.cuda.stream(side) if overlap else contextlib.nullcontext()):
         net.eval()
         m.memory.m_items = mem_t
+        m.memory.defer_sync = overlap and dist_on
         ops.last_prefold_event, ops.fold_misses = None, 0
-        if truncate_second_forward:
-            memory_only_forward(net, x, gts)
-        else:
-            net(x, gts=gts, aux_gts=aux_gts, memory_writing=True)
+        try:
+            if truncate_second_forward:
+                memory_only_forward(net, x, gts)
+            else:
+                net(x, gts=gts, aux_gts=aux_gts, memory_writing=True)
+        finally:
+            m.memory.defer_sync = False
         net.train()
         if overlap:
             done = side.record_event()

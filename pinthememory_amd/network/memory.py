@@ -39,6 +39,10 @@ class Writingnet(nn.Module):
 # forward on its own). Kept OUTSIDE the module: the reference's callers deep-copy networks (train.py:246-277 get_updated_network) and pickle them, and a
 # stream event is neither.
 _PENDING = __import__('weakref').WeakKeyDictionary()
+# Memory_sup -> (memory the write started from, local nominator | denominator) of a write whose cross-rank sum was deferred (Memory_sup.defer_sync): the
+# commit forward of a multi-rank step runs on its own stream and must not issue a collective there; whoever reads m_items next finishes the write on
+# ITS stream -- all-reduce + momentum update, the same two launches write() would have issued -- so every collective of a step stays on one stream.
+_DEFERRED = __import__('weakref').WeakKeyDictionary()
 
 
 class Memory_sup(nn.Module):
@@ -83,11 +87,20 @@ class Memory_sup(nn.Module):
             cur.wait_event(ev)
             if self._m_items.is_cuda:
                 self._m_items.record_stream(cur)
+        d = _DEFERRED.pop(self, None)
+        if d is not None:
+            mem, nomden = d
+            if nomden.is_cuda:
+                cur = torch.cuda.current_stream()
+                nomden.record_stream(cur), mem.record_stream(cur)
+            with torch.no_grad():
+                self._m_items = K.mem_write_update(mem, D.all_reduce_sum(nomden), self.momentum)[0]
         return self._m_items
 
     @m_items.setter
     def m_items(self, value):
         _PENDING.pop(self, None)
+        _DEFERRED.pop(self, None)
         self._m_items = value
 
     def _apply(self, fn, *args, **kwargs):
@@ -126,6 +139,7 @@ class Memory_sup(nn.Module):
         mem = self._mem(query)
         if memory_writing:
             self.m_items = mem = mem.detach()
+        self.last_read = mem.detach()
         g0, g1 = self._gumbel(b * h * w, query.device)
         qr, score, pmem = ops.mem_read(query, mem, g1)
         readloss = ops.upsample_ce(score.permute(0, 3, 1, 2), mask, 1.0 / self.temperature) if mask is not None else 0
@@ -137,6 +151,9 @@ class Memory_sup(nn.Module):
         mem = self._mem(input)
         z = self.writenet(input)
         nomden = ops.mem_write_accum(z, mask, self.memory_size)
+        if self.defer_sync and D.SYNC_MEMORY and D.is_dist() and not torch.is_grad_enabled():
+            _DEFERRED[self] = (mem.detach(), nomden)      # finished by the next reader of m_items, on its stream
+            return [0, 0]
         if D.SYNC_MEMORY:
             nomden = D.all_reduce_sum_autograd(nomden)
         updated_memory = ops.mem_write_update(mem.detach(), nomden, self.momentum)
