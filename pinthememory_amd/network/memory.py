@@ -61,6 +61,8 @@ class Memory_sup(nn.Module):
         self.celoss = nn.CrossEntropyLoss(ignore_index=255)
         self.gumbel_read = gumbel_read
         self.writeTF = lambda x: x.clone()
+        self.defer_sync = False   # harness: leave the cross-rank sum of a no-grad write to the next reader of m_items (see _DEFERRED)
+        self.last_read = None     # the memory tensor the latest read() used (harness: what the commit forward starts from)
         self.m_items = F.normalize(torch.rand((memory_size, feature_dim), dtype=torch.float), dim=1)
         initialize_weights(self)
         self.noise_fn = None      # parity hook: callable(rows, slots, device) -> (noise_dim0, noise_dim1)
