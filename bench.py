@@ -44,9 +44,11 @@ def parse():
     ap.add_argument('--input-edge', action='store_true',
                     help='side measurement (not the metric): every step takes a fresh uint8 [B, D, H, W, 3] batch from pinned host memory, copied and '
                          'converted on a side stream while the previous step computes (pinthememory_amd/input_edge.py)')
-    ap.add_argument('--workload', choices=['train', 'config5'], default='train',
+    ap.add_argument('--workload', choices=['train', 'config5', 'meminit'], default='train',
                     help="train = the metric (default). config5 = side measurement of BASELINE configs[4]: ResNet-101 DeepLabV2 sliding-window "
-                         "evaluation of 1024x2048 images (crop 1024, overlap 1/3 -> 3 tiles x 2 flips, eval.py:148-274), single GPU")
+                         "evaluation of 1024x2048 images (crop 1024, overlap 1/3 -> 3 tiles x 2 flips, eval.py:148-274), single GPU. meminit = side "
+                         "measurement of the caller before training (train.py:1000-1042): class-prototype initialisation of the memory over --steps batches of "
+                         "bs=8 768x768, eval forwards + the write kernel's soft-label accumulation")
     return ap.parse_args()
 
 
@@ -87,6 +89,33 @@ def config5(a):
                       'config': {'workload': 'configs[4]: ResNet-101 DeepLabV2 (network/deepv2.py) 1024x2048 sliding-window inference, side measurement',
                                  'tiles': [list(t) for t in tiles], 'flips': 2, 'conv_tflop_per_image': round(tf, 2),
                                  'direct_equivalent_mfma_frac': round(tf * a.steps / dt / PEAK_TFLOPS_F32_MFMA, 4)},
+                      'roofline': None, 'cpu_baseline': None}), flush=True)
+
+
+def meminit(a):
+    """Side measurement (not the metric): harness.memory_initialize (train.py:1000-1042) at the size it runs at -- `--steps` resident batches of bs x 3 x 768 x 768
+    per epoch, one epoch timed after `--warmup` untimed batches; properties checked: finite unit-norm prototypes, bit-identical repeat."""
+    import torch
+    from pinthememory_amd import harness, synth
+    from pinthememory_amd.network import deepv3plus
+    assert torch.cuda.is_available(), 'bench.py needs a GPU: the HIP path has no CPU fallback'
+    crit = torch.nn.CrossEntropyLoss(reduction='mean', ignore_index=255)
+    net = synth.load_det_weights(deepv3plus.DeepR50V3PlusD(synth.model_args(), 19, crit, crit)).cuda()
+    batches = [tuple(t.cuda() for t in synth.make_batch(a.batch, a.size, seed=304 + i)) for i in range(max(a.steps, 1))]
+    if a.warmup:
+        harness.memory_initialize(net, batches[:max(1, min(a.warmup, len(batches)))], epochs=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    m1 = harness.memory_initialize(net, batches, epochs=1).clone()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    m2 = harness.memory_initialize(net, batches, epochs=1)
+    assert torch.isfinite(m1).all() and (m1.norm(dim=1) - 1).abs().max().item() < 1e-5 and torch.equal(m1, m2)
+    print(json.dumps({'metric': 'memory initialisation imgs/sec 768x768 bs=%d R50-DeepLabV3+ (train.py:1000-1042)' % a.batch, 'value': round(a.batch * len(batches) / dt, 3),
+                      'unit': 'imgs/sec', 'n_gpus': 1, 'steps': len(batches), 'warmup': a.warmup, 'ms_per_step': round(dt / len(batches) * 1e3, 3),
+                      'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                      'config': {'workload': 'memory_initalize (train.py:1000-1042): eval-mode forward of each batch + 4-tap soft-label accumulation of the normalised '
+                                             'bot_aspp features, one epoch over %d resident batches, side measurement' % len(batches)},
                       'roofline': None, 'cpu_baseline': None}), flush=True)
 
 
@@ -306,6 +335,8 @@ def main():
     a = parse()
     if a.workload == 'config5':
         return config5(a)
+    if a.workload == 'meminit':
+        return meminit(a)
     if a.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
     import torch

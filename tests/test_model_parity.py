@@ -251,6 +251,25 @@ def test_memory_initialize_vs_golden(env, golden):
     assert np.abs(m.cpu().numpy() - golden('memory_init_v3plus_128.npz')['m_items']).max() < 2e-5
 
 
+def test_memory_initialize_at_production_size_vs_oracle(env):
+    """train.py:1000-1042 at the size it runs at (VERDICT r2 missing 6): three batches of 2 x 3 x 768 x 768 (48 x 48 prototype maps, 36 864 label pixels behind
+    every feature pixel, top rows ignored), two epochs, against the oracle's one-hot + F.interpolate formulation on the host cores: the class prototypes
+    within 1e-4, unit-norm rows, classes that never occur left at zero; and the full bs=8 batch: finite, normalised, bit-identical repeat."""
+    synth, h, o_h = env['synth'], env['harness'], env['o_harness']
+    args = synth.model_args()
+    ref = synth.load_det_weights(env['o_deeplab'].DeepR50V3PlusD(args, 19, CRIT, CRIT))
+    net = synth.load_det_weights(env['deepv3plus'].DeepR50V3PlusD(args, 19, CRIT, CRIT)).cuda()
+    batches = [synth.make_batch(2, 768, seed=700 + i, classes=15) for i in range(3)]          # classes 15 .. 18 never occur
+    want = o_h.memory_initialize(ref, batches)
+    got = h.memory_initialize(net, [(x.cuda(), y.cuda()) for x, y in batches]).cpu()
+    assert (got - want).abs().max().item() < 1e-4, (got - want).abs().max().item()
+    assert (got[:15].norm(dim=1) - 1).abs().max().item() < 1e-5 and got[15:].abs().max().item() == 0.0 and want[15:].abs().max().item() == 0.0
+    big = [tuple(t.cuda() for t in synth.make_batch(8, 768, seed=800 + i)) for i in range(2)]
+    a = h.memory_initialize(net, big, epochs=1).clone()
+    b = h.memory_initialize(net, big, epochs=1)
+    assert torch.isfinite(a).all() and (a.norm(dim=1) - 1).abs().max().item() < 1e-5 and torch.equal(a, b)
+
+
 def test_memory_module_kat_vs_golden(env, golden):
     """Memory_sup alone (train mode, write detached, then with gradients) against the reference's captured outputs."""
     from pinthememory_amd.network.memory import Memory_sup
