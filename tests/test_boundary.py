@@ -93,3 +93,23 @@ def test_stitching_beyond_64_tiles_takes_the_torch_formulation():
         ref = (torch.flip(full, dims=[2]) if flip else full) + (0 if ref is None else ref)
         acc = h._stitch_torch(lg, tiles, 1024, 2048, flip, acc)
     assert torch.equal(acc, ref)
+
+
+def test_m_items_stays_a_plain_get_set_attribute():
+    """The reference treats Memory_sup.m_items as a plain attribute: read, re-assigned from outside (train.py:312,332,547,558,580,1040; optimizer.py:65),
+    never part of state_dict, and networks are deep-copied with it (train.py:246-277). Here it is a property (it orders a reader behind an overlapped
+    commit forward on the GPU); on the surface nothing changes."""
+    import copy
+    import torch
+    from pinthememory_amd.network.memory import Memory_sup
+    m = Memory_sup(19, 256, 256, 0.8, 1, True)
+    assert tuple(m.m_items.shape) == (19, 256) and 'm_items' not in m.state_dict() and not any('m_items' in k for k in m.state_dict())
+    t = torch.nn.functional.normalize(torch.rand(19, 256), dim=1)
+    m.m_items = t
+    assert m.m_items is t and m.pending is None
+    m2 = copy.deepcopy(m)
+    assert torch.equal(m2.m_items, t) and m2.m_items is not t
+    m2.m_items = t * 2
+    assert torch.equal(m.m_items, t)
+    m.double()                                             # nn.Module._apply follows the attribute (the reference hard-codes .cuda(), memory.py:111,120)
+    assert m.m_items.dtype == torch.float64 and m.mem_cls.dtype == torch.int64
