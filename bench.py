@@ -35,6 +35,7 @@ def parse():
     ap.add_argument('--truncate-second-forward', action='store_true',
                     help='skip the decoder in the memory-commit forward (identical results; NOT the default measurement)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--launch-timeout', type=float, default=3600.0, help='--gpus N self-launch: seconds after which every rank is killed and the run fails')
     ap.add_argument('--cpu-batch', type=int, default=2)
     ap.add_argument('--no-profile', action='store_true', help='do not bracket conv launches with HIP events')
     ap.add_argument('--dtype', choices=['f32', 'bf16', 'bf16_staged'], default='f32',
@@ -189,6 +190,29 @@ def cpu_baseline(batch, size, steps=2):
                       % (len(times), batch, size, size, best, '/'.join(str(k) for k in sweep), phys, dt)}
 
 
+def lib_stamp():
+    """Content fingerprint of the library build (pinthememory_amd/build.py); tools/pmc_bench_summary.py writes the same value into its counter summaries."""
+    try:
+        return open(os.path.join(ROOT, 'pinthememory_amd', 'libpinmem_hip.so.stamp')).read().strip()
+    except OSError:
+        return None
+
+
+def counter_file(pattern):
+    """Latest committed PMC summary matching `pattern` (one tier, one workload: never another tier's file) -> (json, 'profiles/<name>', stale).
+    Counters cannot be read from inside this process, so the committed figure is quoted with its source; `stale` says that the file was produced by
+    ANOTHER build of the library than the one measured here (or predates the stamp field): the figure is then context, not a measurement of this code."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)),
+                   key=lambda f: [int(t) if t.isdigit() else t for t in re.split(r'(\d+)', os.path.basename(f))])
+    if not files:
+        return None, None, None
+    j = json.load(open(files[-1]))
+    stamp = lib_stamp()
+    return j, 'profiles/' + os.path.basename(files[-1]), not (stamp and j.get('lib_stamp') == stamp)
+
+
 PEAK_HBM_GBPS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured with a float4 copy)
 
 
@@ -236,12 +260,12 @@ def memory_path_roofline(batch, size):
         ('main_ce_bwd', 'deepv3plus.py:575-578 (autograd)', B * H * H * 8 + 2 * B * (H // 4) ** 2 * m * 4, lambda: K.upsample_ce_bwd(main, lab, lo_main, None, 1.0)),
     ]
     del z
-    counters = {}
+    counters, src, stale = {}, None, None
     try:
-        pj = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_memory_path_hbm_counters.json')))[-1]
-        counters = json.load(open(pj))['kernels']          # {kernel symbol: {FETCH_SIZE_KB_per_launch, WRITE_SIZE_KB_per_launch, hbm_MB_per_launch}}
-        src = 'profiles/' + os.path.basename(pj) + ': rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of tools/mem_probe.py; read = 2 x FETCH_SIZE (gfx950)'
-    except (OSError, KeyError, ValueError, IndexError):
+        cj, name, stale = counter_file('r*_memory_path_hbm_counters.json')
+        counters = cj['kernels']          # {kernel symbol: {FETCH_SIZE_KB_per_launch, WRITE_SIZE_KB_per_launch, hbm_MB_per_launch}}
+        src = name + ': rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of tools/mem_probe.py; read = 2 x FETCH_SIZE (gfx950)'
+    except (OSError, KeyError, ValueError, IndexError, TypeError):
         src = None
     rows = []
     fill_a = torch.empty(B, H // 4, H // 4, d, device=x.device)      # 302 MB at the flagship size: ~0.12 ms per copy
@@ -267,6 +291,7 @@ def memory_path_roofline(batch, size):
            'achieved': head['achieved'], 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': head['frac'], 'launch_us': head['launch_us'],
            'algorithmic_MB': head['algorithmic_MB'],
            'traffic': next((round(v['hbm_MB_per_launch'] * 1e6) for k, v in counters.items() if k.startswith('mem_read_fwd')), None), 'traffic_source': src,
+           'traffic_stale': stale,
            'measured': 'after the timed region: %d back-to-back launches between one pair of HIP events on the launch stream, queued behind ~1.4 ms of copies so '
                        'that the host is ahead of the GPU (an event pair per launch adds ~5 us of launch latency to a 20 us kernel); average per launch incl. '
                        'the gaps between kernels; one launch may include the second-stage kernels of the op (fixed-order reductions)' % reps,
@@ -281,7 +306,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch_ranks(n, argv, child=None, env=None):
+def launch_ranks(n, argv, child=None, env=None, timeout=None):
     """`python bench.py --gpus N` without a launcher environment: start N fresh rank processes (one per GPU, the reference's
     `torch.distributed.launch --nproc_per_node N` hop, train.py:63-76 reads RANK / WORLD_SIZE / LOCAL_RANK the same way), relay
     rank 0's JSON line and return the worst child exit code. This process has not touched the GPU (no torch import, no HIP call)
@@ -311,7 +336,16 @@ def launch_ranks(n, argv, child=None, env=None):
     import time as _t
     rcs = [None] * n
     failed_at = None
+    t_start = _t.time()
     while any(rc is None for rc in rcs):
+        if timeout is not None and _t.time() - t_start > timeout:      # a rank that hangs without exiting (a collective nobody answers) ends the whole run
+            print('bench.py: ranks still running after %.0f s -- killing them' % timeout, file=sys.stderr)
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    p.kill()
+                    p.wait()
+                    rcs[i] = 124
+            break
         for i, p in enumerate(procs):
             if rcs[i] is None:
                 rcs[i] = p.poll()
@@ -338,7 +372,7 @@ def main():
     if a.workload == 'meminit':
         return meminit(a)
     if a.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
-        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:], timeout=a.launch_timeout))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -473,18 +507,19 @@ def main():
                 ('forward', 'data gradient', 'weight gradient')[mode], bm, bn, ('wave-uniform', 'per-lane', 'per-lane looping')[km],
                 'double-buffered' if nst == 2 else 'single-stage', ('v_mfma_f32_32x32x2_f32', 'v_mfma_f32_32x32x16_bf16 on fp32 tiles rounded per fragment', 'v_mfma_f32_32x32x16_bf16 on bf16 tiles (bf16 operands in HBM)')[kprec])
             traffic, traffic_src = None, None      # HBM bytes per launch of that symbol, from the committed PMC passes of this command
+            traffic_stale = None
             try:
-                import glob
-                pj = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_1gpu_hbm_counters.json')))[-1]      # the latest committed PMC passes
-                for kr in json.load(open(pj))['kernels']:
+                cj, name, traffic_stale = counter_file('r*_bench_1gpu%s_hbm_counters.json' % ('_bf16' if bf16 else ''))      # this tier's latest committed PMC passes
+                for kr in cj['kernels']:
                     if kr['kernel'].replace('void ', '').replace(', false>', '>').strip() == sym:      # the symbol's trailing STATS=false template argument
                         traffic = round((kr['read_MB_per_launch'] + kr['write_MB_per_launch']) * 1e6)
-                        traffic_src = ('profiles/' + os.path.basename(pj) + ': rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of '
+                        traffic_src = (name + ': rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of '
                                        'bench.py --steps 1 --warmup 1; read = 2 x FETCH_SIZE (gfx950), average over all launches of the symbol')
-            except (OSError, KeyError, ValueError, IndexError):
+            except (OSError, KeyError, ValueError, IndexError, TypeError):
                 pass
             roof = {'bound': 'mfma', 'kernel': '%s (%s)' % (sym, what), 'achieved': round(ach, 2),
                     'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_source': traffic_src,
+                    'traffic_stale': traffic_stale,
                     'launches_per_step': n / prof_steps, 'avg_launch_ms': round(ms / n, 5), 'gflop_per_launch': round(fl / n / 1e9, 3),
                     'measured': '%d extra steps after the timed region (event timing costs ~1.7 ms/step, so the timed region runs without it), all launches '
                                 'serialised on one stream (with the weight gradients on their side stream and the commit forward on its own every concurrent kernel\'s duration inflates)' % prof_steps,
@@ -519,16 +554,14 @@ def main():
             # and on the fabric traffic of the committed counter passes -- step_mfma_frac above is a direct-algorithm-equivalent rate, not utilisation
             ex_tf = tot_fl / prof_steps / 1e12
             step = {'executed_tflop': round(ex_tf, 3), 'mfma_frac_executed': round(ex_tf / (dt / a.steps) / peak, 4),
-                    'hbm_GB': None, 'hbm_frac': None, 'hbm_source': None}
+                    'hbm_GB': None, 'hbm_frac': None, 'hbm_source': None, 'hbm_stale': None}
             try:
-                import glob
-                pj = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_1gpu%s_hbm_counters.json' % ('_bf16' if bf16 else ''))))[-1]
-                cj = json.load(open(pj))
+                cj, name, hstale = counter_file('r*_bench_1gpu%s_hbm_counters.json' % ('_bf16' if bf16 else ''))
                 gb = (cj['total_read_GB'] + cj['total_write_GB']) / float(cj.get('steps_counted', 2))
-                step.update(hbm_GB=round(gb, 1), hbm_frac=round(gb / (dt / a.steps) / PEAK_HBM_GBPS, 4),
-                            hbm_source='profiles/' + os.path.basename(pj) + ' (FETCH_SIZE x 2 + WRITE_SIZE over all kernels of the counted steps, separate --pmc passes), '
-                                       'divided by this run\'s step time and the 8 TB/s peak')
-            except (OSError, KeyError, ValueError, IndexError):
+                step.update(hbm_GB=round(gb, 1), hbm_frac=round(gb / (dt / a.steps) / PEAK_HBM_GBPS, 4), hbm_stale=hstale,
+                            hbm_source=name + ' (FETCH_SIZE x 2 + WRITE_SIZE over all kernels of the counted steps, separate --pmc passes), '
+                                       'divided by this run\'s step time and the 8 TB/s peak; hbm_stale = the counter file comes from another build of the library')
+            except (OSError, KeyError, ValueError, IndexError, TypeError):
                 pass
             roof['step'] = step
             try:

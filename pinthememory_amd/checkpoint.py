@@ -9,6 +9,8 @@ def _unwrap(net):
 
 
 def snapshot_dict(net, optimizer=None, scheduler=None, epoch=0, mean_iu=0.0):
+    """No collective in here: the reference saves on rank 0 only (train.py:188-191). With more than one rank and a memory commit still deferred
+    (harness.agg_train_step), `m_items` raises instead of hanging the job -- harness.save_checkpoint finishes the commit on every rank first."""
     m = _unwrap(net)
     sd = {('module.' + k): v for k, v in m.state_dict().items()}      # the reference always saves the DDP-wrapped net
     out = {'state_dict': sd, 'epoch': epoch, 'mean_iu': mean_iu}
@@ -29,6 +31,9 @@ def forgiving_state_restore(net, loaded_dict, verbose=False):
     """optimizer.py:73-89: copy every entry whose name and shape match, skip the rest. Accepts keys with or without the
     'module.' prefix whatever the wrapping of `net`; conv weights keep their channels-last (KRSC) memory."""
     m = _unwrap(net)
+    if any(p.is_cuda for p in m.parameters()):
+        from .hip import ops as _ops
+        _ops.wait_commit()      # load_state_dict writes the weights a commit forward on its own stream may still be reading
     own = m.state_dict()
     new = {}
     for k in own:

@@ -52,9 +52,10 @@ def memory_only_forward(net, x, gts):
 # where it is first read (Memory_sup.pending); (4) transformed filters the commit forward wrote are event-ordered per cache entry (hip/kernels.py);
 # (5) the next SGD is behind (3) on the main stream, so the weights are not written under it. Results are bit-identical to the serial order.
 # With more than one rank every collective of a step stays on the MAIN stream (dist.py: one communicator, program order): the commit forward's only
-# exchange -- the memory-slot sum of its write -- is deferred to the next reader of m_items (Memory_sup.defer_sync: the all-reduce and the momentum
-# update are then issued where the next training forward reads the memory), eval-mode BatchNorm has none. Not under the reference's DDP wrapper, whose
-# forward broadcasts buffers on its own communicator. PM_COMMIT_OVERLAP=0 disables the overlap.
+# exchange -- the memory-slot sum of its write -- is deferred (Memory_sup.defer_sync) to the next point EVERY rank passes: the next training forward's
+# memory read, or an explicit harness.finish_commit(net) -- never to an attribute read (a rank-0-only save would pair it with another rank's
+# collective; `m_items` raises while the sum is owed); eval-mode BatchNorm has no exchange. Under the reference's DDP wrapper the commit forward calls
+# the bare module (see agg_train_step). PM_COMMIT_OVERLAP=0 disables the overlap.
 COMMIT_OVERLAP = __import__('os').environ.get('PM_COMMIT_OVERLAP', '1') == '1'
 _commit_streams = {}
 
@@ -63,6 +64,39 @@ def _commit_stream(device):
     if device.index not in _commit_streams:
         _commit_streams[device.index] = torch.cuda.Stream(device=device)
     return _commit_streams[device.index]
+
+
+def finish_commit(net):
+    """Finish the memory write of the last commit forward where it was left to the next reader (more than one rank, commit forward on its own
+    stream: Memory_sup.defer_sync). COLLECTIVE in that case -- call it on EVERY rank, at the same point of the program, before anything reads
+    `m_items` between steps on a subset of ranks (validation, the rank-0-only save of train.py:188-191). The next training forward does it by
+    itself (Memory_sup.read). A no-op with one rank or when nothing is pending."""
+    m = net.module if hasattr(net, 'module') else net
+    if getattr(m, 'memory', None) is not None:
+        m.memory.finish_commit()
+
+
+def sync_commit(net=None):
+    """Order the CURRENT stream behind the commit forward of the last agg_train_step (it reads every weight on its own stream). Needed before
+    anything WRITES weights outside agg_train_step / mldg_train_step / optim.SGD.step / checkpoint.restore_snapshot, which wait by themselves:
+    a foreign optimizer, an EMA update, in-place edits. No collective, no host synchronisation."""
+    ops.wait_commit()
+
+
+def save_checkpoint(path, net, optimizer=None, scheduler=None, epoch=0, mean_iu=0.0):
+    """utils/misc.py:195-216 for the harness: EVERY rank calls it (it finishes a pending memory commit collectively), rank 0 writes the file."""
+    from . import checkpoint
+    finish_commit(net)
+    if not D.is_dist() or torch.distributed.get_rank() == 0:
+        checkpoint.save_snapshot(path, net, optimizer, scheduler, epoch, mean_iu)
+
+
+def _all_syncbn(m):
+    v = m.__dict__.get('_pm_all_syncbn')
+    if v is None:
+        bns = [b for b in m.modules() if isinstance(b, torch.nn.modules.batchnorm._BatchNorm)]
+        v = m.__dict__['_pm_all_syncbn'] = all(isinstance(b, torch.nn.SyncBatchNorm) for b in bns)
+    return v
 
 
 def agg_train_step(net, opt, x, gts, aux_gts=None, sched=None, buckets=None, truncate_second_forward=False):
@@ -87,7 +121,12 @@ def agg_train_step(net, opt, x, gts, aux_gts=None, sched=None, buckets=None, tru
         buckets.finish()
     opt.step()
     dist_on = D.is_dist()
-    overlap = COMMIT_OVERLAP and x.is_cuda and (not dist_on or (D.SYNC_MEMORY and not hasattr(net, 'module')))
+    # Under the reference's DDP wrapper (network/__init__.py:25-33) the commit forward goes through the bare module: DDP's forward would broadcast the
+    # buffers on its own communicator, from a second stream. With every BatchNorm converted to SyncBatchNorm (train.py:95) the running moments are
+    # already identical on all ranks, so that broadcast changes nothing; with local BatchNorms it does (rank 0's moments win) and the overlap stays off.
+    wrapped = hasattr(net, 'module')
+    overlap = COMMIT_OVERLAP and x.is_cuda and (not dist_on or (D.SYNC_MEMORY and (not wrapped or _all_syncbn(m))))
+    fwd_net = m if (overlap and wrapped) else net
     main = torch.cuda.current_stream() if x.is_cuda else None
     side = _commit_stream(x.device) if overlap else None
     if overlap:
@@ -103,13 +142,14 @@ def agg_train_step(net, opt, x, gts, aux_gts=None, sched=None, buckets=None, tru
             if truncate_second_forward:
                 memory_only_forward(net, x, gts)
             else:
-                net(x, gts=gts, aux_gts=aux_gts, memory_writing=True)
+                fwd_net(x, gts=gts, aux_gts=aux_gts, memory_writing=True)
         finally:
             m.memory.defer_sync = False
         net.train()
         if overlap:
             done = side.record_event()
             m.memory.pending = done
+            ops.commit_done[x.device.index] = done      # whoever writes weights next waits for it (optim.SGD.step, checkpoint restore, sync_commit)
     if overlap:
         # the next training forward rewrites the BatchNorm running moments: wait for the fold launch that read them (or, without one, for everything)
         main.wait_event(ops.last_prefold_event if (ops.last_prefold_event is not None and ops.fold_misses == 0) else done)
@@ -236,6 +276,7 @@ def mldg_train_step(net, updated_net, updated_net2, opt, x_tr, y_tr, x_te, y_te,
     frozen-encoder memory write with the stepped weights, read-only meta-test forward whose loss back-propagates through the
     WRITTEN memory into the write graph (memory.py:323-324 only detaches when writing), outer step, memory commit."""
     net.train()
+    finish_commit(net)          # every rank is here: a memory commit deferred by a preceding agg step is finished before m_items is read
     mem_t = net.memory.m_items.clone().detach()
     opt.zero_grad()
     out_in = net(x_tr, gts=y_tr, aux_gts=y_tr, memory_writing=True, writing_detach=False)

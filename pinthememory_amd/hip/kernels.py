@@ -103,6 +103,17 @@ def _filter_owner(w_krsc):
     return p if (p.data_ptr() == w_krsc.data_ptr() and p.numel() == w_krsc.numel() and p.is_leaf) else None
 
 
+_U_STREAMS = {}     # every stream that ever read or wrote a kept transform (main stream, the harness' commit stream)
+
+
+def _evict(ent):
+    """The buffer goes back to the pool of the stream that allocated it, while a launch on ANOTHER stream (the commit forward) may still be reading it:
+    tell the allocator about every stream that uses the cache, so that the block is not handed out again before their queued work is done."""
+    if ent[2].is_cuda:
+        for s in _U_STREAMS.values():
+            ent[2].record_stream(s)
+
+
 def _wino_u(lib, xd, yd, p, w_krsc):
     if KEEP_WINOGRAD_U is False:
         return None
@@ -120,19 +131,21 @@ def _wino_u(lib, xd, yd, p, w_krsc):
     if ent is None:
         # oldest entries go first (dicts keep insertion order; hits are re-inserted): models that are gone release their buffers here
         for k in [k for k, e in _U_CACHE.items() if isinstance(e[0], weakref.ref) and e[0]() is None]:
-            del _U_CACHE[k]
+            _evict(_U_CACHE.pop(k))
         while _U_CACHE and (len(_U_CACHE) >= _U_CACHE_MAX or sum(e[2].numel() * 4 for e in _U_CACHE.values()) + nbu > _U_CACHE_BYTES):
-            _U_CACHE.pop(next(iter(_U_CACHE)))
+            _evict(_U_CACHE.pop(next(iter(_U_CACHE))))
         ent = [weakref.ref(owner) if owner is not None else w_krsc, -1, torch.empty(nbu // 4, dtype=torch.float32, device=w_krsc.device), None, None]
     version = (owner if owner is not None else w_krsc)._version
     valid = ent[1] == version
-    ent[1] = version
+    if not valid:
+        ent[1] = -1                     # invalid until the launch that fills it has been enqueued (conv_fwd commits the version after check())
     _U_CACHE[key] = ent
     p.wxf, p.wxf_bytes, p.wxf_valid = ent[2].data_ptr(), nbu, 1 if valid else 0
     cur = torch.cuda.current_stream()
+    _U_STREAMS.setdefault(cur.cuda_stream, cur)
     if valid and ent[3] is not None and ent[4] != cur.cuda_stream:
         cur.wait_event(ent[3])          # the transform was written by a launch on another stream (harness: the commit forward runs on its own)
-    return ent if not valid else None
+    return None if valid else (ent, version)
 
 
 def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, residual=None, relu=False, out=None, keep_v=None, bn_partials=None):
@@ -154,9 +167,9 @@ def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, res
         keep_v.append(v)
         if v is not None:
             p.wino_v, p.wino_v_bytes = v.data_ptr(), nbv
-    fresh_u = None
+    u_ent = None
     if (kh == 3 and CONV_PREC == 0) or CONV_PREC == 2:
-        fresh_u = _wino_u(lib, xd, yd, p, w_krsc)      # the cache entry this call is about to (re)write, if any
+        u_ent = _wino_u(lib, xd, yd, p, w_krsc)        # (cache entry this call is about to (re)write, version to commit once the launch is enqueued) or None
     nb = lib.pm_conv_workspace(byref(xd), byref(yd), byref(p), 0)
     ws = workspace(nb, x.device) if nb else None
     part = None
@@ -170,9 +183,11 @@ def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, res
         ep = L.conv_epilogue(ptr(bias), ptr(scale), ptr(shift), rd.ptr if rd else None, rd.pitch if rd else 0, 1 if relu else 0, ptr(part),
                             part.numel() * 4 if part is not None else 0)
     check(lib.pm_conv_fwd(byref(xd), w_krsc.data_ptr(), byref(yd), byref(p), byref(ep) if ep else None, ptr(ws), nb, stream()), 'pm_conv_fwd')
-    if fresh_u is not None:             # later hits from another stream wait for this launch
+    if u_ent is not None:               # the launch is enqueued: only now is the kept transform valid; hits from another stream wait for this event
+        ent, version = u_ent
         cur = torch.cuda.current_stream()
-        fresh_u[3], fresh_u[4] = cur.record_event(), cur.cuda_stream
+        ent[3], ent[4] = cur.record_event(), cur.cuda_stream
+        ent[1] = version
     return y
 
 

@@ -132,6 +132,19 @@ def _wgrad(x, dy, wshape, geom, want_bias=False, deferred=False, wino_v=None):
     return out
 
 
+# harness.agg_train_step runs the memory-commit forward on its own stream; it READS every weight there. device index -> event recorded at its end.
+# Whoever writes weights on another stream waits for it first (optim.SGD.step, checkpoint.restore_snapshot, harness.sync_commit).
+commit_done = {}
+
+
+def wait_commit():
+    if not commit_done or not torch.cuda.is_available():
+        return
+    ev = commit_done.pop(torch.cuda.current_device(), None)
+    if ev is not None:
+        torch.cuda.current_stream().wait_event(ev)
+
+
 BN_FUSED_FINALIZE = _os.environ.get('PM_BN_FUSED', '1') == '1'      # A/B knob: 0 = separate bn_stats / bn_finalize launches
 
 

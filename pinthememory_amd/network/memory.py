@@ -83,27 +83,44 @@ class Memory_sup(nn.Module):
 
     @property
     def m_items(self):
+        if self in _DEFERRED:
+            # A cross-rank sum is still owed to this memory (harness.agg_train_step with more than one rank). An attribute read must never hide a
+            # collective: a rank-0-only reader (the reference saves on rank 0, train.py:188-191 -> utils/misc.py:214) would pair its all-reduce with
+            # whatever the other ranks issue next. The write is finished where EVERY rank passes: the next forward's read(), or harness.finish_commit(net).
+            raise RuntimeError('Memory_sup.m_items: the memory-slot all-reduce of the last commit forward is still pending. Call '
+                               'pinthememory_amd.harness.finish_commit(net) on EVERY rank (harness.save_checkpoint does) before reading m_items between steps.')
         ev = _PENDING.pop(self, None)
         if ev is not None:
             cur = torch.cuda.current_stream()
             cur.wait_event(ev)
             if self._m_items.is_cuda:
                 self._m_items.record_stream(cur)
-        d = _DEFERRED.pop(self, None)
-        if d is not None:
-            mem, nomden = d
-            if nomden.is_cuda:
-                cur = torch.cuda.current_stream()
-                nomden.record_stream(cur), mem.record_stream(cur)
-            with torch.no_grad():
-                self._m_items = K.mem_write_update(mem, D.all_reduce_sum(nomden), self.momentum)[0]
         return self._m_items
 
     @m_items.setter
     def m_items(self, value):
-        _PENDING.pop(self, None)
+        ev = _PENDING.pop(self, None)
+        if ev is not None:      # the tensor being replaced may still be written on another stream: order this stream behind it instead of forgetting the event
+            torch.cuda.current_stream().wait_event(ev)
         _DEFERRED.pop(self, None)
         self._m_items = value
+
+    def finish_commit(self):
+        """COLLECTIVE when a deferred write is pending (Memory_sup.defer_sync): all-reduce of the local nominator | denominator and the momentum update,
+        on the caller's stream -- the two launches write() would have issued. Every rank must call it at the same point of its program: read() does
+        (the next forward, which every rank runs), harness.finish_commit(net) does it explicitly before validation / saving. No-op otherwise."""
+        d = _DEFERRED.pop(self, None)
+        if d is None:
+            return
+        ev = _PENDING.pop(self, None)
+        cur = torch.cuda.current_stream() if d[1].is_cuda else None
+        if ev is not None:
+            cur.wait_event(ev)
+        mem, nomden = d
+        if cur is not None:
+            nomden.record_stream(cur), mem.record_stream(cur)
+        with torch.no_grad():
+            self._m_items = K.mem_write_update(mem, D.all_reduce_sum(nomden), self.momentum)[0]
 
     def _apply(self, fn, *args, **kwargs):
         # m_items / mem_cls are plain attributes in the reference (hard .cuda() at memory.py:111,120); follow the module instead
@@ -138,6 +155,7 @@ class Memory_sup(nn.Module):
 
     def read(self, query, mask, memory_writing):      # memory.py:317-336
         b, d, h, w = query.size()
+        self.finish_commit()      # every rank reads here: the one place a deferred cross-rank sum is finished implicitly
         mem = self._mem(query)
         if memory_writing:
             self.m_items = mem = mem.detach()
@@ -150,6 +168,7 @@ class Memory_sup(nn.Module):
         return updated_query, pq, pmem, readloss
 
     def write(self, input, mask, writing_detach=True):  # memory.py:206-257
+        self.finish_commit()
         mem = self._mem(input)
         z = self.writenet(input)
         nomden = ops.mem_write_accum(z, mask, self.memory_size)

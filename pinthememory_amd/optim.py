@@ -40,6 +40,8 @@ class SGD(torch.optim.SGD):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        from .hip import ops as _ops
+        _ops.wait_commit()      # a memory-commit forward on its own stream (harness.agg_train_step) may still be reading the weights this step writes
         for group in self.param_groups:
             plain = (group['momentum'] != 0 and group['dampening'] == 0 and not group['nesterov'] and not group.get('maximize', False))
             fused, rest = [], []

@@ -113,3 +113,20 @@ def test_m_items_stays_a_plain_get_set_attribute():
     assert torch.equal(m.m_items, t)
     m.double()                                             # nn.Module._apply follows the attribute (the reference hard-codes .cuda(), memory.py:111,120)
     assert m.m_items.dtype == torch.float64 and m.mem_cls.dtype == torch.int64
+
+
+def test_m_items_never_hides_a_collective():
+    """with more than one rank the commit forward leaves the cross-rank sum of its write to a point every rank passes (the next forward's read,
+    harness.finish_commit). An attribute read in between -- the reference saves on rank 0 only, train.py:188-191 -- must fail loudly, not issue an
+    all-reduce that the other ranks answer with a different collective. Assigning the attribute (a restore) drops the owed write."""
+    import pytest
+    import torch
+    from pinthememory_amd.network import memory
+    m = memory.Memory_sup(19, 256, 256, 0.8, 1, True)
+    t = m.m_items
+    memory._DEFERRED[m] = (t, torch.zeros(20 * 257))
+    with pytest.raises(RuntimeError, match='finish_commit'):
+        m.m_items
+    assert m in memory._DEFERRED                    # the failed read consumed nothing
+    m.m_items = t * 1
+    assert m not in memory._DEFERRED and torch.equal(m.m_items, t)

@@ -328,3 +328,67 @@ def test_two_ranks_on_gpu_equal_single_process_big_batch(tmp_path, split):
     print('two-rank vs big-batch gradient errors:', [(round(e, 5), n) for e, n in errs])
     # two fp32 evaluations of a ReLU network differ by the units that flip within round-off: the bounds of tests/test_model_parity.py
     assert errs[-1][0] < 1e-2 and errs[0][0] < 1e-4, errs       # heads behind the last ReLU layers: round-off only; trunk: the ReLU-flip floor (~3e-3)
+
+
+# ---- GPU: two real ranks run the harness' agg step with the commit forward overlapped; the memory commit is never hidden behind an attribute read -----
+_SAVE_PROBE = r'''
+import os, sys, torch
+out_dir = sys.argv[1]
+rank = int(os.environ['RANK'])
+torch.cuda.set_device(0)
+import torch.distributed as dist
+dist.init_process_group('gloo', rank=rank, world_size=2)
+from pinthememory_amd import checkpoint, dist as D, harness, synth
+from pinthememory_amd.network import deepv3plus
+crit = torch.nn.CrossEntropyLoss(reduction='mean', ignore_index=255)
+net = synth.load_det_weights(deepv3plus.DeepR50V3PlusD(synth.model_args(), 19, crit, crit)).cuda()
+net.dsn[3].p = 0.0
+net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
+opt, sched = harness.make_optimizer(net)
+buckets = D.GradBuckets(net.parameters())
+x, y = synth.make_batch(4, 128, seed=5)
+x, y = x[2 * rank:2 * rank + 2].cuda(), y[2 * rank:2 * rank + 2].cuda()
+assert harness.COMMIT_OVERLAP
+for _ in range(2):
+    harness.agg_train_step(net, opt, x, y, sched=sched, buckets=buckets)
+raised = False
+if rank == 0:                      # the reference's save path (train.py:188-191): rank 0 alone reads m_items -> must fail loudly, not issue a collective
+    try:
+        checkpoint.snapshot_dict(net, opt, sched)
+    except RuntimeError as e:
+        raised = 'finish_commit' in str(e)
+    assert raised
+harness.save_checkpoint(os.path.join(out_dir, 'ck.pt'), net, opt, sched, epoch=1)      # every rank: finishes the commit collectively, rank 0 writes
+mem = net.memory.m_items.detach().clone()
+other = mem.clone()
+dist.all_reduce(other)
+assert torch.allclose(other, 2 * mem, rtol=0, atol=1e-6), 'the committed memory differs between the ranks'
+torch.cuda.synchronize()
+if rank == 0:
+    ck = torch.load(os.path.join(out_dir, 'ck.pt'), map_location='cpu')
+    assert torch.equal(ck['memory'], mem.cpu()) and ck['epoch'] == 1
+harness.agg_train_step(net, opt, x, y, sched=sched, buckets=buckets)      # and the loop goes on
+harness.finish_commit(net)
+assert torch.isfinite(net.memory.m_items).all()
+dist.barrier()
+dist.destroy_process_group()
+print('SAVE_PROBE_DONE', rank)
+'''
+
+
+@pytest.mark.gpu
+def test_two_ranks_rank0_only_save_does_not_hide_a_collective(tmp_path):
+    """ADVICE r3 (medium): two real ranks (gloo, one GPU), harness.agg_train_step with the commit forward on its own stream and its memory-slot sum
+    deferred. Rank 0 alone reading `m_items` (checkpoint.snapshot_dict, the reference's rank-0-only save) raises instead of enqueuing an all-reduce
+    nobody answers; harness.save_checkpoint -- called by every rank -- finishes the commit, rank 0 writes the file, both ranks hold the same memory,
+    and training continues."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = str(_free_port())
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=port, RANK=str(rank), WORLD_SIZE='2')
+        procs.append(subprocess.Popen([sys.executable, '-c', _SAVE_PROBE, str(tmp_path)], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all('SAVE_PROBE_DONE' in o[0] for o in outs), ''.join(o[0][-1500:] + o[1][-3000:] for o in outs)

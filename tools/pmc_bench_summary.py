@@ -1,7 +1,11 @@
 """Summarise FETCH_SIZE / WRITE_SIZE passes (rocprofv3 --pmc, separate runs) of bench.py into per-kernel HBM bytes per launch.
 FETCH_SIZE is doubled (gfx950 counts 128-B read requests at 64 B, MI355X_MICROARCH.md section HBM; verified here on a 302 MB copy)."""
-import collections, json, re, sqlite3, sys
+import collections, json, os, re, sqlite3, sys
 fetch_db, write_db, out = sys.argv[1:4]
+try:
+    stamp = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'pinthememory_amd', 'libpinmem_hip.so.stamp')).read().strip()
+except OSError:
+    stamp = None
 res = collections.OrderedDict()
 for path, ctr in ((fetch_db, 'FETCH_SIZE'), (write_db, 'WRITE_SIZE')):
     cur = sqlite3.connect(path).cursor()
@@ -15,7 +19,7 @@ for k, d in res.items():
                      write_MB_per_launch=w.get('total_KB', 0) / max(w.get('launches', 1), 1) / 1e3,
                      read_GB_total=2 * f.get('total_KB', 0) / 1e6, write_GB_total=w.get('total_KB', 0) / 1e6))
 rows.sort(key=lambda r: -(r['read_GB_total'] + r['write_GB_total']))
-json.dump(dict(note='2 steps (1 warm-up + 1 timed); read = 2 x FETCH_SIZE (gfx950 correction), write = WRITE_SIZE; KB = 1000 B units as reported',
+json.dump(dict(lib_stamp=stamp, note='2 steps (1 warm-up + 1 timed); read = 2 x FETCH_SIZE (gfx950 correction), write = WRITE_SIZE; KB = 1000 B units as reported',
                total_read_GB=sum(r['read_GB_total'] for r in rows), total_write_GB=sum(r['write_GB_total'] for r in rows), kernels=rows[:40]), open(out, 'w'), indent=1)
 print('total read %.1f GB write %.1f GB over 2 steps' % (sum(r['read_GB_total'] for r in rows), sum(r['write_GB_total'] for r in rows)))
 for r in rows[:12]:
