@@ -38,10 +38,11 @@ def parse():
     ap.add_argument('--launch-timeout', type=float, default=3600.0, help='--gpus N self-launch: seconds after which every rank is killed and the run fails')
     ap.add_argument('--cpu-batch', type=int, default=2)
     ap.add_argument('--no-profile', action='store_true', help='do not bracket conv launches with HIP events')
-    ap.add_argument('--dtype', choices=['f32', 'bf16', 'bf16_staged'], default='f32',
-                    help='f32 = BASELINE configs[1] (the metric; default). bf16 = configs[2]: every convolution converts its operands to bf16 in HBM, bf16 LDS tiles '
-                         '(64 k per row), bf16 MFMA with fp32 accumulation; activations between layers stay fp32. bf16_staged = the first form of that tier '
-                         '(fp32 tiles in LDS rounded per fragment), kept for A/B')
+    ap.add_argument('--dtype', choices=['f32', 'bf16', 'bf16_operands', 'bf16_staged'], default='f32',
+                    help='f32 = BASELINE configs[1] (the metric; default). bf16 = configs[2], the whole tier (round 4): activations and their gradients are stored as '
+                         'bf16 between layers, bf16 MFMA convolutions with fp32 accumulation, fp32 statistics / losses / memory / parameters. bf16_operands = round 2-3 '
+                         'form (fp32 activations, every convolution converts its operands to bf16 in HBM). bf16_staged = the first form (fp32 tiles in LDS rounded per '
+                         'fragment); both kept for A/B')
     ap.add_argument('--input-edge', action='store_true',
                     help='side measurement (not the metric): every step takes a fresh uint8 [B, D, H, W, 3] batch from pinned host memory, copied and '
                          'converted on a side stream while the previous step computes (pinthememory_amd/input_edge.py)')
@@ -494,7 +495,7 @@ def main():
                 for bn in (128, 64, 32):
                     for km in (0, 1, 2):
                         for nst in (2, 1):
-                            for prec in ((0,) if not bf16 else (2, 1)):
+                            for prec in ((0,) if not bf16 else (2, 4, 3, 1)):
                                 r = K.profile_read(mode=mode, bm=bm, bn=bn, km=km, nst=nst, prec=prec)
                                 if r[2] and (best is None or r[0] > best[0][0]):
                                     best = (r, (mode, bm, bn, km, nst), prec)
@@ -505,7 +506,9 @@ def main():
             sym = 'conv_igemm_kernel<%d, %d, %d, %s, %d, %d, %d>' % (mode, bm, bn, '4, 1' if bn == 32 else '2, 2', km, kprec, nst)
             what = '%s, %dx%dx32 tile, %s K-state, %s LDS, %s; direct convolutions and the batched Winograd F(4x4,3x3) / F(2x2,3x3) GEMMs; FLOPs = 2*M*N*K executed' % (
                 ('forward', 'data gradient', 'weight gradient')[mode], bm, bn, ('wave-uniform', 'per-lane', 'per-lane looping')[km],
-                'double-buffered' if nst == 2 else 'single-stage', ('v_mfma_f32_32x32x2_f32', 'v_mfma_f32_32x32x16_bf16 on fp32 tiles rounded per fragment', 'v_mfma_f32_32x32x16_bf16 on bf16 tiles (bf16 operands in HBM)')[kprec])
+                'double-buffered' if nst == 2 else 'single-stage', ('v_mfma_f32_32x32x2_f32', 'v_mfma_f32_32x32x16_bf16 on fp32 tiles rounded per fragment', 'v_mfma_f32_32x32x16_bf16 on bf16 tiles (bf16 operands in HBM)',
+                                                                    'v_mfma_f32_32x32x16_bf16 on bf16 LDS tiles rounded from gathered fp32 rows, ds_read_b64_tr_b16 fragments',
+                                                                    'v_mfma_f32_32x32x16_bf16 on bf16 LDS tiles gathered from bf16 activations, ds_read_b64_tr_b16 fragments')[kprec])
             traffic, traffic_src = None, None      # HBM bytes per launch of that symbol, from the committed PMC passes of this command
             traffic_stale = None
             try:
@@ -535,7 +538,9 @@ def main():
                'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
                'config': {'workload': '%s: ResNet-50 DeepLabV3+ + memory, bs=%d/GPU %dx%d synthetic, %s reference-faithful agg train step '
                                       '(fwd + bwd + SGD + eval-mode memory-commit fwd%s)' % ('configs[2]' if bf16 else 'configs[1]', a.batch, a.size, a.size,
-                                                                                            'bf16-MFMA convolutions (bf16 operands in HBM and LDS, fp32 accumulation; fp32 activations between layers)' if a.dtype == 'bf16' else ('bf16-MFMA (fp32 tiles staged, rounded per fragment)' if bf16 else 'fp32'),
+                                                                                            {'bf16': 'bf16 tier: bf16 activations and activation gradients between layers, bf16-MFMA convolutions with fp32 accumulation, fp32 statistics / losses / memory / parameters',
+                                                                                             'bf16_operands': 'bf16-MFMA convolutions (bf16 operands in HBM and LDS, fp32 accumulation; fp32 activations between layers)',
+                                                                                             'bf16_staged': 'bf16-MFMA (fp32 tiles staged, rounded per fragment)', 'f32': 'fp32'}[a.dtype],
                                                                                             ', decoder skipped in the commit fwd' if a.truncate_second_forward else ''),
                           'global_batch': a.batch * world, 'crop': a.size, 'parallelism': 'dp%d' % world,
                           'ranks_seen': ranks_seen, 'ranks_seen_source': ('ncclCommCount of the direct RCCL communicator' if multi and backend == 'nccl' and ranks_seen == world and _rccl.get(None) is not None

@@ -23,15 +23,26 @@ extern "C" {
 
 typedef enum pm_status { PM_OK = 0, PM_EINVAL = -1, PM_EWORKSPACE = -2, PM_ELAUNCH = -3, PM_EUNSUPPORTED = -4 } pm_status;
 
-typedef struct pm_tensor {      /* NHWC fp32 activation view */
+/* Element type of an activation tensor. PM_F32: BASELINE configs[1], the parity path (every entry point). PM_BF16: BASELINE configs[2], the bf16 tier --
+ * activations and their gradients are STORED as bf16 between layers (round to nearest even), every reduction / statistic / accumulator stays fp32.
+ * Entry points say which they take; all tensor arguments of one call share the type unless stated otherwise; anything else returns PM_EUNSUPPORTED. */
+typedef enum pm_dtype { PM_F32 = 0, PM_BF16 = 1 } pm_dtype;
+/* pm_tensor.flags */
+#define PM_TF_ZERO_PAD64 1      /* caller's promise: channels c .. roundup(c, 64) - 1 of every pixel lie inside `pitch` and hold zeros (a bf16 convolution
+                                   input whose channel count is not a multiple of 64 is then gathered in place instead of being copied to a padded buffer) */
+
+typedef struct pm_tensor {      /* NHWC activation view */
   void* ptr;
   int32_t n, h, w, c;
-  int64_t pitch;                /* floats between consecutive pixels */
+  int64_t pitch;                /* ELEMENTS between consecutive pixels (>= c) */
+  int32_t dtype;                /* pm_dtype */
+  int32_t flags;                /* PM_TF_* */
 } pm_tensor;
 
 /* ABI version of this header (pm_version() returns the library's). The two structs below carry their own size as first member: an entry point that
- * receives a struct built against another header returns PM_EINVAL instead of reading past the caller's object (they grew in rounds 2 and 3). */
-#define PM_ABI_VERSION 300
+ * receives a struct built against another header returns PM_EINVAL instead of reading past the caller's object (they grew in rounds 2 and 3).
+ * 400 (round 4): pm_tensor carries dtype + flags (bf16 activation tier). */
+#define PM_ABI_VERSION 400
 
 typedef struct pm_conv_params { /* nn.Conv2d geometry (square kernels/strides as used by the reference) */
   int32_t struct_size;          /* = sizeof(pm_conv_params) */
@@ -59,8 +70,8 @@ typedef struct pm_conv_epilogue { /* optional fused epilogue of pm_conv_fwd; all
   const float* bias;            /* [Cout]  conv bias (deepv3plus.py:417,420,424) */
   const float* scale;           /* [Cout]  folded eval-mode BN: y = conv*scale + shift (mynn.py:8-14 in .eval()) */
   const float* shift;           /* [Cout] */
-  const float* residual;        /* NHWC, same n,h,w,c as y; += (Resnet.py:207) */
-  int64_t residual_pitch;
+  const float* residual;        /* NHWC, same n,h,w,c AND dtype as y (a bf16 y takes a bf16 residual: cast the pointer); += (Resnet.py:207) */
+  int64_t residual_pitch;       /* elements */
   int32_t relu;                 /* max(.,0) last (Resnet.py:216) */
   float* bn_partials;           /* optional (NULL: none): train-mode BatchNorm statistics of y produced by the epilogue itself -- per 32-row slab of the
                                    GEMM and per channel (mean, M2), float[ceil(pixels / 32)][Cout][2], two-pass inside the slab -- so that no
@@ -74,7 +85,11 @@ int pm_version(void);
 
 /* ---- K1/K2/K3 convolution, implicit GEMM on v_mfma_f32_32x32x2_f32 -------------------------------------------
  * Replaces nn.Conv2d forward/backward at Resnet.py:145-150,195,404,453-457; deepv3plus.py:72-81,87,398-424;
- * deepv2.py:44-51,138-151; memory.py:75,104.  y: [n,ho,wo,cout], x: [n,h,w,cin], cin % 4 == 0. */
+ * deepv2.py:44-51,138-151; memory.py:75,104.  y: [n,ho,wo,cout], x: [n,h,w,cin], cin % 4 == 0.
+ * dtypes: all PM_F32 = the parity path. The bf16 tier (BASELINE configs[2]) is entered by prec = 2 or by any PM_BF16 tensor: x / y / dy / dx / add may each be
+ * bf16 (c % 8 == 0, pitch % 8 == 0) or fp32 (the image in, the class logits and their gradient out); weights, dw, dbias, bias / scale / shift stay fp32,
+ * every product is accumulated in fp32 and rounded once on the way out. A bf16 input whose channel count is not a multiple of 64 is gathered in place
+ * only with PM_TF_ZERO_PAD64, else it is copied to a zero-padded workspace buffer first. */
 size_t pm_conv_workspace(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p, int which /*0 fwd,1 dgrad,2 wgrad*/);
 size_t pm_conv_winograd_v_bytes(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p);
 size_t pm_conv_wxf_bytes(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p);   /* 0: pm_conv_fwd keeps no transformed filter for this call */
@@ -174,6 +189,10 @@ int pm_add_n(const pm_tensor* const* xs, int n, const pm_tensor* y, void* stream
 int pm_copy(const pm_tensor* src, const pm_tensor* dst, void* stream);
 int pm_scale_shift_act(const pm_tensor* x, const float* scale, const float* shift, const pm_tensor* residual, int relu,
                        const pm_tensor* y, void* stream);
+
+/* dtype conversion between two views of the same shape (PM_F32 <-> PM_BF16, round to nearest even): the edges of the bf16 tier -- the memory module
+ * (memory.py:167-239) and the losses stay fp32. A bf16 destination with c % 8 != 0 must be dense (pitch == roundup(c, 8)); its pad lanes are written as 0. */
+int pm_cast(const pm_tensor* x, const pm_tensor* y, void* stream);
 
 /* ---- K3 pooling (Resnet.py:432 MaxPool2d(3,2,1); deepv3plus.py:85 AdaptiveAvgPool2d(1)) ------------------------- */
 int pm_maxpool3x3s2_fwd(const pm_tensor* x, const pm_tensor* y, uint8_t* argmax, void* stream);

@@ -269,6 +269,7 @@ __global__ void bn_fold_kernel(const float* __restrict__ g, const float* __restr
 }
 
 int check_bn(const pm_tensor* x, const char* who) {
+  PM_REQUIRE_F32(x, who);      // the bf16 forms are dispatched before this check (act16.hip); a mixed-type call ends here
   PM_REQUIRE(x && x->ptr && pm_vec4(x), PM_EINVAL, "%s: tensor must be 16B aligned, pitch %% 4 == 0 and C %% 4 == 0", who);
   return PM_OK;
 }
@@ -276,12 +277,15 @@ int check_bn(const pm_tensor* x, const char* who) {
 }  // namespace
 
 extern "C" size_t pm_bn_workspace(const pm_tensor* x) {
+  if (pm_is_bf16(x)) return pm16_bn_workspace(x);
   const long P = pm_pixels(x);
   const int nb = pm_cdiv(P, chunk_rows(P, x->c));
   return pm_align_up((size_t)nb * x->c * 2 * sizeof(float), 256);
 }
 
 extern "C" int pm_bn_stats(const pm_tensor* x, float* moments, void* ws, size_t ws_bytes, void* stream) {
+  PM_REQUIRE(x && moments, PM_EINVAL, "bn_stats: null");
+  if (pm_is_bf16(x)) return pm16_bn_stats(x, moments, 0.f, nullptr, nullptr, nullptr, nullptr, 0.f, ws, ws_bytes, (hipStream_t)stream);
   if (int e = check_bn(x, "bn_stats")) return e;
   PM_REQUIRE(moments && ws && ws_bytes >= pm_bn_workspace(x), PM_EWORKSPACE, "bn_stats: workspace too small");
   const long P = pm_pixels(x);
@@ -296,8 +300,9 @@ extern "C" int pm_bn_stats(const pm_tensor* x, float* moments, void* ws, size_t 
 
 extern "C" int pm_bn_stats_finalize(const pm_tensor* x, float eps, float* mean, float* invstd, float* running_mean, float* running_var, float momentum,
                                     void* ws, size_t ws_bytes, void* stream) {
+  PM_REQUIRE(x && mean && invstd, PM_EINVAL, "bn_stats_finalize: bad args");
+  if (pm_is_bf16(x)) return pm16_bn_stats(x, nullptr, eps, mean, invstd, running_mean, running_var, momentum, ws, ws_bytes, (hipStream_t)stream);
   if (int e = check_bn(x, "bn_stats_finalize")) return e;
-  PM_REQUIRE(mean && invstd, PM_EINVAL, "bn_stats_finalize: bad args");
   PM_REQUIRE(ws && ws_bytes >= pm_bn_workspace(x), PM_EWORKSPACE, "bn_stats_finalize: workspace too small");
   const long P = pm_pixels(x);
   PM_REQUIRE(P > 0, PM_EINVAL, "bn_stats_finalize: empty tensor");
@@ -369,6 +374,8 @@ extern "C" int pm_bn_apply(const pm_tensor* x, const float* mean, const float* i
 
 extern "C" int pm_bn_apply_mask(const pm_tensor* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const pm_tensor* res,
                                 int relu, const pm_tensor* y, uint8_t* mask, void* stream) {
+  PM_REQUIRE(x && y, PM_EINVAL, "bn_apply: null");
+  if (pm_is_bf16(x)) return pm16_bn_apply_mask(x, mean, invstd, gamma, beta, res, relu, y, mask, (hipStream_t)stream);      // all tensors bf16; mask: one byte per 8 channels
   if (int e = check_bn(x, "bn_apply")) return e;
   if (int e = check_bn(y, "bn_apply")) return e;
   PM_REQUIRE(pm_same_shape(x, y) && mean && invstd && gamma && beta, PM_EINVAL, "bn_apply: bad args");
@@ -395,6 +402,9 @@ extern "C" int pm_bn_apply_mask(const pm_tensor* x, const float* mean, const flo
 
 extern "C" int pm_bn_bwd_reduce(const pm_tensor* dy, const pm_tensor* y, const pm_tensor* x, const float* mean, const float* invstd, const float* gamma,
                                 const float* beta, int relu, const pm_tensor* gmask, float* sums, void* ws, size_t ws_bytes, void* stream) {
+  PM_REQUIRE(dy && x, PM_EINVAL, "bn_bwd_reduce: null");
+  PM_REQUIRE(relu >= 0 && relu <= 2, PM_EINVAL, "bn_bwd_reduce: relu mode %d (0 none, 1 mask from y, 2 mask rebuilt from x)", relu);
+  if (pm_is_bf16(x)) return pm16_bn_bwd_reduce(dy, y, nullptr, x, mean, invstd, gamma, beta, relu, gmask, sums, ws, ws_bytes, (hipStream_t)stream);
   if (int e = check_bn(dy, "bn_bwd_reduce")) return e;
   if (int e = check_bn(x, "bn_bwd_reduce")) return e;
   PM_REQUIRE(pm_same_shape(dy, x) && mean && invstd && sums, PM_EINVAL, "bn_bwd_reduce: bad args");
@@ -428,6 +438,8 @@ extern "C" int pm_bn_bwd_reduce(const pm_tensor* dy, const pm_tensor* y, const p
 // gradient gmask (= the gradient of the residual branch), as pm_bn_bwd_reduce(relu = 1) gives them -- same values, 1 / 16 of the mask bytes.
 extern "C" int pm_bn_bwd_reduce_mask(const pm_tensor* dy, const uint8_t* mask, const pm_tensor* x, const float* mean, const float* invstd,
                                      const pm_tensor* gmask, float* sums, void* ws, size_t ws_bytes, void* stream) {
+  PM_REQUIRE(dy && x && mask, PM_EINVAL, "bn_bwd_reduce_mask: null");
+  if (pm_is_bf16(x)) return pm16_bn_bwd_reduce(dy, nullptr, mask, x, mean, invstd, nullptr, nullptr, 3, gmask, sums, ws, ws_bytes, (hipStream_t)stream);
   if (int e = check_bn(dy, "bn_bwd_reduce_mask")) return e;
   if (int e = check_bn(x, "bn_bwd_reduce_mask")) return e;
   PM_REQUIRE(pm_same_shape(dy, x) && mean && invstd && sums && mask, PM_EINVAL, "bn_bwd_reduce_mask: bad args");
@@ -451,6 +463,8 @@ extern "C" int pm_bn_bwd_reduce_mask(const pm_tensor* dy, const uint8_t* mask, c
 
 extern "C" int pm_bn_bwd_apply(const pm_tensor* dy, const pm_tensor* y, const pm_tensor* x, const float* mean, const float* invstd, const float* gamma,
                                const float* beta, const float* sums, float count, int relu, const pm_tensor* dx, const pm_tensor* dres, void* stream) {
+  PM_REQUIRE(dy && x && dx, PM_EINVAL, "bn_bwd_apply: null");
+  if (pm_is_bf16(x)) return pm16_bn_bwd_apply(dy, y, x, mean, invstd, gamma, beta, sums, count, relu, dx, dres, (hipStream_t)stream);
   if (int e = check_bn(dy, "bn_bwd_apply")) return e;
   if (int e = check_bn(x, "bn_bwd_apply")) return e;
   if (int e = check_bn(dx, "bn_bwd_apply")) return e;

@@ -54,6 +54,7 @@ struct ConvK {
   long res_pitch;
   int relu;
   float* stats;               // train-mode BN statistics of the output: (mean, M2) per 32-row slab and channel, or null
+  int io16;                   // the bf16 tier: C and `residual` are bf16 tensors (pitches in elements); accumulation and the epilogue arithmetic stay fp32
   int stage_ep;               // 1: epilogue staged through LDS (16-byte row stores); 0: per-element stores (PM_STAGE_EP=0, A/B)
 };
 
@@ -100,8 +101,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   // PREC 3 (weight gradient of the bf16 tier): the pixel-major (m-contiguous) tiles are kept in LDS as bf16 [BK][BM + 32] -- rounded once, as the
   // gathered fp32 rows are stored -- and the MFMA fragments (8 consecutive k per lane) come out of them through the hardware transpose read
   // ds_read_b64_tr_b16. The 32-element pad puts the four k-rows one read touches on four disjoint bank quarters (row stride = 64 B mod 256 B).
-  constexpr bool TR = (PREC == 3);
-  static_assert(!TR || MODE == MODE_WGRAD, "PREC 3 is the weight-gradient form");
+  // PREC 4: the same with NATIVE bf16 operands (bf16 activations in HBM, BASELINE configs[2] round 4): a lane gathers 16 bytes = eight channels and stores them
+  // to LDS as they are -- half the gather instructions, no conversion.
+  constexpr bool TR = (PREC == 3 || PREC == 4);
+  constexpr bool NAT16 = (PREC == 4);
+  static_assert(!TR || MODE == MODE_WGRAD, "PREC 3 / 4 are the weight-gradient forms");
   constexpr int LDA_T = BM + 32, LDB_T = BN + 32;   // bf16 elements per k-row
   constexpr int A_FLOATS = A_KC ? BM * LDK : (TR ? BK * LDA_T / 2 : BK * BM);
   constexpr int B_FLOATS = B_KC ? BN * LDK : (TR ? BK * LDB_T / 2 : BK * BN);
@@ -131,7 +135,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   const int by = blockIdx.y;
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A + by * a.a_bs), 0, (int)a.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.B + by * a.b_bs), 0, (int)a.b_bytes, 0x00020000);
-  const int xp4 = (int)a.x_pitch * 4, yp4 = (int)a.y_pitch * 4;
+  const int xp4 = (int)a.x_pitch * (NAT16 ? 2 : 4), yp4 = (int)a.y_pitch * (NAT16 ? 2 : 4);      // bytes between pixels
+  constexpr int A_NL = NAT16 ? (A_N + 1) / 2 : A_N, B_NL = NAT16 ? (B_N + 1) / 2 : B_N;            // 16-byte gathers per thread and tile
+  constexpr int EPL = NAT16 ? 8 : 4;                                                               // elements per 16-byte gather
 
   // ---- gather state ---------------------------------------------------------------------------------------------
   // uniform K-state (FAST) / per-lane K-state (MID, SMALL) of the (tap, channel) decomposition of k
@@ -187,9 +193,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
     }
   } else {
 #pragma unroll
-    for (int j = 0; j < A_N; ++j) {
-      const int col = m0 + (g + 8 * j) * 4;
-      a_col4[j] = col < a.Cout ? col * 4 : OOB;
+    for (int j = 0; j < A_NL; ++j) {
+      const int col = m0 + (g + 8 * j) * EPL;
+      a_col4[j] = col < a.Cout ? col * (NAT16 ? 2 : 4) : OOB;
     }
   }
   if constexpr (MODE == MODE_FWD) {
@@ -211,13 +217,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
     }
   } else {
 #pragma unroll
-    for (int j = 0; j < B_N; ++j) {
-      const int n = n0 + (g + 8 * j) * 4;
+    for (int j = 0; j < B_NL; ++j) {
+      const int n = n0 + (g + 8 * j) * EPL;
       const int tap = n < a.Nn ? n / a.Cin : 0;
       const int ky = tap / a.kw, kx = tap - ky * a.kw;
       b_dy[j] = ky * a.dil - a.pad;
       b_dx[j] = kx * a.dil - a.pad;
-      b_base[j] = n < a.Nn ? (b_dy[j] * a.W + b_dx[j]) * xp4 + (n - tap * a.Cin) * 4 : OOB;
+      b_base[j] = n < a.Nn ? (b_dy[j] * a.W + b_dx[j]) * xp4 + (n - tap * a.Cin) * (NAT16 ? 2 : 4) : OOB;
     }
     const int p = k_begin + r;
     p_img = p / (a.Ho * a.Wo);
@@ -289,14 +295,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
       const bool pok = p < k_end;
       const int poff = p * yp4;
 #pragma unroll
-      for (int j = 0; j < A_N; ++j) {
+      for (int j = 0; j < A_NL; ++j) {
         const int off = poff + a_col4[j];
         ra[j] = bload(rA, (pok & (a_col4[j] != OOB)) ? off : OOB);
       }
       const int by = p_oy * a.stride, bx = p_ox * a.stride;
       const int rowbase = ((p_img * a.H + by) * a.W + bx) * xp4;
 #pragma unroll
-      for (int j = 0; j < B_N; ++j) {
+      for (int j = 0; j < B_NL; ++j) {
         const bool ok = pok & (b_base[j] != OOB) & ((unsigned)(by + b_dy[j]) < (unsigned)a.H) & ((unsigned)(bx + b_dx[j]) < (unsigned)a.W);
         const int off = rowbase + b_base[j];
         rb[j] = bload(rB, ok ? off : OOB);
@@ -368,14 +374,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
     float* As = smem + buf * STAGE;
     float* Bs = As + A_FLOATS;
 #pragma unroll
-    for (int i = 0; i < A_N; ++i) {
+    for (int i = 0; i < A_NL; ++i) {
       if constexpr (A_KC) *reinterpret_cast<float4*>(As + (r + 32 * i) * LDK + g * 4) = ra[i];
+      else if constexpr (NAT16) *reinterpret_cast<float4*>(reinterpret_cast<char*>(As) + (r * LDA_T + (g + 8 * i) * 8) * 2) = ra[i];
       else if constexpr (TR) *reinterpret_cast<float2*>(reinterpret_cast<char*>(As) + (r * LDA_T + (g + 8 * i) * 4) * 2) = pack4(ra[i]);
       else *reinterpret_cast<float4*>(As + r * BM + (g + 8 * i) * 4) = ra[i];
     }
 #pragma unroll
-    for (int i = 0; i < B_N; ++i) {
+    for (int i = 0; i < B_NL; ++i) {
       if constexpr (B_KC) *reinterpret_cast<float4*>(Bs + (r + 32 * i) * LDK + g * 4) = rb[i];
+      else if constexpr (NAT16) *reinterpret_cast<float4*>(reinterpret_cast<char*>(Bs) + (r * LDB_T + (g + 8 * i) * 8) * 2) = rb[i];
       else if constexpr (TR) *reinterpret_cast<float2*>(reinterpret_cast<char*>(Bs) + (r * LDB_T + (g + 8 * i) * 4) * 2) = pack4(rb[i]);
       else *reinterpret_cast<float4*>(Bs + r * BN + (g + 8 * i) * 4) = rb[i];
     }
@@ -542,7 +550,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
       advance();
       __builtin_amdgcn_sched_group_barrier(0x100, TM + TN + (A_KC ? 0 : 3 * TM) + (B_KC ? 0 : 3 * TN), 0);  // fragment DS reads
 #define PM_SG(I)                                                                   \
-      if constexpr (A_N + B_N > I) {                                                \
+      if constexpr (A_NL + B_NL > I) {                                                \
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  /* 2 MFMA            */ \
         __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);  /* <= 8 VALU / SALU  */ \
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  /* 1 buffer load     */ \
@@ -570,6 +578,91 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   // per MFMA tile and lane. A finished tile is bound by the ISSUE of its stores, not by bandwidth: 64 -> 16 store instructions per
   // lane and 128 x 128 tile (tools/micro/gemm_lab.hip: +4 ... +18 % on the store-heavy shapes, never slower). The fused epilogue
   // operands are read as 16-byte vectors of the same row segments; values and their evaluation order are unchanged.
+  // The bf16 tier (a.io16, split-K slabs excepted: they stay fp32): the same staging, a lane owns EIGHT columns of a row -- two 16-byte LDS reads, the fused
+  // epilogue in fp32, one 16-byte store of eight bf16 (round to nearest even); the residual / skip-gradient operand is bf16 as well.
+  const bool out16 = a.io16 && a.ksplit == 1;
+  if (out16 && ((a.c_pitch | a.Nn | (a.residual ? a.res_pitch : 0)) & 7) == 0 &&
+      ((reinterpret_cast<uintptr_t>(a.C) | reinterpret_cast<uintptr_t>(a.residual)) & 15) == 0) {
+    constexpr int WC = BN / WN, LDC = WC + 4, LPR = WC / 8, RPI = 64 / LPR;
+    static_assert(32 % RPI == 0, "row segments must tile the 32-row slab");
+    __syncthreads();
+    float* Ws = smem + wave * 32 * LDC;
+    const int rr0 = lane / LPR, cc = (lane % LPR) * 8;
+    const int col = n0 + wn * WC + cc;
+    const bool cok = col < a.Nn;                      // Nn % 8 == 0: the group is all in or all out
+    const bool aff = a.bias || a.scale, res = a.residual != nullptr, relu = a.relu != 0;
+    float bi[8], sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bi[e] = 0.f, sc[e] = 1.f, sh[e] = 0.f;
+    if (aff && cok) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (a.bias) bi[e] = a.bias[col + e];
+        if (a.scale) sc[e] = a.scale[col + e], sh[e] = a.shift[col + e];
+      }
+    }
+    pm_bf16* C16 = reinterpret_cast<pm_bf16*>(a.C) + by * a.c_bs;
+    const pm_bf16* R16 = reinterpret_cast<const pm_bf16*>(a.residual);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Ws[((q & 3) + 8 * (q >> 2) + 4 * half) * LDC + n * 32 + l31] = acc[i][n][q];
+#pragma unroll
+      for (int r0 = 0; r0 < 32; r0 += RPI) {
+        const int rr = r0 + rr0;
+        const long row = m0 + wm * (BM / WM) + i * 32 + rr;
+        const float4 v0 = *reinterpret_cast<const float4*>(Ws + rr * LDC + cc), v1 = *reinterpret_cast<const float4*>(Ws + rr * LDC + cc + 4);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        if (row < a.M && cok) {
+          if (aff) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (v[e] + bi[e]) * sc[e] + sh[e];
+          }
+          if (res) {
+            float q[8];
+            pm_ld8(R16 + row * a.res_pitch + col, q);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += q[e];
+          }
+          if (relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          pm_st8(C16 + row * a.c_pitch + col, v);
+        }
+      }
+    }
+    return;
+  }
+  if (out16) {      // unaligned / narrow bf16 outputs: per-element form
+    pm_bf16* C16 = reinterpret_cast<pm_bf16*>(a.C) + by * a.c_bs;
+    const pm_bf16* R16 = reinterpret_cast<const pm_bf16*>(a.residual);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int n = 0; n < TN; ++n) {
+        const int col = cbase + n * 32;
+        const bool cok = col < a.Nn;
+        float bi = 0.f, sc = 1.f, sh = 0.f;
+        if (cok) {
+          if (a.bias) bi = a.bias[col];
+          if (a.scale) sc = a.scale[col], sh = a.shift[col];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = rbase + i * 32 + (q & 3) + 8 * (q >> 2);
+          if (row < a.M && cok) {
+            float v = (acc[i][n][q] + bi) * sc + sh;
+            if (R16) v += pm_bf16_to_f32(R16[(long)row * a.res_pitch + col]);
+            if (a.relu) v = fmaxf(v, 0.f);
+            C16[(long)row * a.c_pitch + col] = pm_f32_to_bf16(v);
+          }
+        }
+      }
+    return;
+  }
   const bool vec = a.stage_ep && ((a.c_pitch | a.Nn | (a.residual ? a.res_pitch : 0)) & 3) == 0 &&
                    ((reinterpret_cast<uintptr_t>(Cb) | reinterpret_cast<uintptr_t>(a.residual)) & 15) == 0;
   if (vec) {
@@ -724,7 +817,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
 // Vectorised split-K reduce: thread -> 4 consecutive outputs, ZL lanes share the slabs of one output group (lane l sums
 // z = l, l + ZL, ...; the ZL partial sums are combined in lane order through LDS), so that a 256-way split over a small dw is not
 // a 256-long serial chain of dependent loads. Fixed association order -> deterministic.
-template <int ZL>
+template <int ZL, bool O16 = false>
 __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const float* __restrict__ ws, int ksplit, long slab, int M, int Nn,
                                                                 float* __restrict__ C, long c_pitch, const float* bias,
                                                                 const float* scale, const float* shift, const float* residual,
@@ -765,11 +858,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const float* __r
         v.x = v.x * sc.x + sh.x, v.y = v.y * sc.y + sh.y, v.z = v.z * sc.z + sh.z, v.w = v.w * sc.w + sh.w;
       }
       if (residual) {
-        const float4 r = PM_LD4(residual + (long)row * res_pitch + col);
-        v.x += r.x, v.y += r.y, v.z += r.z, v.w += r.w;
+        if constexpr (O16) {      // bf16 tier: residual and output are bf16 tensors (pitches in elements), 8-byte accesses
+          const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const pm_bf16*>(residual) + (long)row * res_pitch + col);
+          v.x += __uint_as_float(q.x << 16), v.y += __uint_as_float(q.x & 0xffff0000u), v.z += __uint_as_float(q.y << 16), v.w += __uint_as_float(q.y & 0xffff0000u);
+        } else {
+          const float4 r = PM_LD4(residual + (long)row * res_pitch + col);
+          v.x += r.x, v.y += r.y, v.z += r.z, v.w += r.w;
+        }
       }
       if (relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
-      PM_ST4(C + (long)row * c_pitch + col, v);
+      if constexpr (O16) *reinterpret_cast<uint2*>(reinterpret_cast<pm_bf16*>(C) + (long)row * c_pitch + col) = make_uint2(pm_pack_bf16(v.x, v.y), pm_pack_bf16(v.z, v.w));
+      else PM_ST4(C + (long)row * c_pitch + col, v);
     }
     if constexpr (ZL > 1) __syncthreads();
   }
@@ -793,8 +892,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 int splitk_reduce(const float* ws, int ksplit, long M, long Nn, float* C, long c_pitch, const float* bias, const float* scale, const float* shift,
-                  const float* residual, long res_pitch, int relu, hipStream_t st) {
+                  const float* residual, long res_pitch, int relu, hipStream_t st, bool out16 = false) {
   const long total = M * Nn;
+  if (out16) {      // bf16 tier: bf16 output / residual, four outputs = 8 bytes per thread
+    PM_REQUIRE((Nn % 4 == 0) && (c_pitch % 4 == 0) && (res_pitch % 4 == 0) && pm_aligned16(ws) && (reinterpret_cast<uintptr_t>(C) & 7) == 0 &&
+                   (reinterpret_cast<uintptr_t>(residual) & 7) == 0 && (!bias || pm_aligned16(bias)) && (!scale || (pm_aligned16(scale) && pm_aligned16(shift))),
+               PM_EUNSUPPORTED, "splitk_reduce(bf16): unaligned output");
+    const long groups = total / 4;
+    const int zl = (ksplit >= 32 && groups < (1 << 18)) ? 16 : (ksplit >= 8 && groups < (1 << 20) ? 4 : 1);
+    const int nb = (int)std::min<long>((groups + 256 / zl - 1) / (256 / zl), 8192);
+    if (zl == 16)
+      hipLaunchKernelGGL((splitk_reduce_vec_kernel<16, true>), dim3(nb), dim3(256), 0, st, ws, ksplit, total, (int)M, (int)Nn, C, c_pitch, bias, scale, shift, residual, res_pitch, relu);
+    else if (zl == 4)
+      hipLaunchKernelGGL((splitk_reduce_vec_kernel<4, true>), dim3(nb), dim3(256), 0, st, ws, ksplit, total, (int)M, (int)Nn, C, c_pitch, bias, scale, shift, residual, res_pitch, relu);
+    else
+      hipLaunchKernelGGL((splitk_reduce_vec_kernel<1, true>), dim3(nb), dim3(256), 0, st, ws, ksplit, total, (int)M, (int)Nn, C, c_pitch, bias, scale, shift, residual, res_pitch, relu);
+    return pm_check_launch("splitk_reduce(bf16)");
+  }
   const bool vec = (Nn % 4 == 0) && (c_pitch % 4 == 0) && (res_pitch % 4 == 0) && pm_aligned16(ws) && pm_aligned16(C) &&
                    (!bias || pm_aligned16(bias)) && (!scale || (pm_aligned16(scale) && pm_aligned16(shift))) && (!residual || pm_aligned16(residual));
   if (!vec) {
@@ -883,6 +997,7 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restr
 }
 
 // stride-2 dgrad: scatter the four per-class results (compact [class][n*Hc*Wc][Cin]) back to dx and fuse the optional add.
+template <bool O16>
 __global__ __launch_bounds__(256) void dgrad_s2_interleave_kernel(const float* __restrict__ tmp, long class_stride, int valid_mask,
                                                                   float* __restrict__ dx, long xp, int N, int H, int W, int C, const float* __restrict__ add,
                                                                   long add_pitch) {
@@ -896,11 +1011,19 @@ __global__ __launch_bounds__(256) void dgrad_s2_interleave_kernel(const float* _
     const int Hc = (H - cy + 1) >> 1, Wc = (W - cx + 1) >> 1;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if ((valid_mask >> cls) & 1) v = PM_LD4(tmp + cls * class_stride + ((long)(n * Hc + (iy >> 1)) * Wc + (ix >> 1)) * C + c);
-    if (add) {
-      const float4 q = PM_LD4(add + pix * add_pitch + c);
-      v.x += q.x, v.y += q.y, v.z += q.z, v.w += q.w;
+    if constexpr (O16) {      // bf16 tier: dx and the fused skip gradient are bf16 tensors (pitches in elements)
+      if (add) {
+        const uint2 q = *reinterpret_cast<const uint2*>(reinterpret_cast<const pm_bf16*>(add) + pix * add_pitch + c);
+        v.x += __uint_as_float(q.x << 16), v.y += __uint_as_float(q.x & 0xffff0000u), v.z += __uint_as_float(q.y << 16), v.w += __uint_as_float(q.y & 0xffff0000u);
+      }
+      *reinterpret_cast<uint2*>(reinterpret_cast<pm_bf16*>(dx) + pix * xp + c) = make_uint2(pm_pack_bf16(v.x, v.y), pm_pack_bf16(v.z, v.w));
+    } else {
+      if (add) {
+        const float4 q = PM_LD4(add + pix * add_pitch + c);
+        v.x += q.x, v.y += q.y, v.z += q.z, v.w += q.w;
+      }
+      PM_ST4(dx + pix * xp + c, v);
     }
-    PM_ST4(dx + pix * xp + c, v);
   }
 }
 
@@ -945,7 +1068,7 @@ Plan make_plan(int mode, long M, long Nn, long K, bool bf16 = false) {
   // 18 KB single-stage LDS -> 7-8 resident per CU): -1.4 ms/step of kernel time against 64 x 128 in the per-shape A/B
   // (tools/conv_compare.py), within +-3 % on the few N >= 1024 shapes that preferred the wider tile. PM_WIDE_BN=1 restores 128.
   static const int wide_bn = getenv("PM_WIDE_BN") ? atoi(getenv("PM_WIDE_BN")) : 0;
-  int bn = Nn > 64 ? 128 : (Nn > 32 ? 64 : 32);
+  int bn = Nn > 64 ? 128 : ((Nn > 32 || bf16) ? 64 : 32);      // no bf16-operand instantiation of the 128 x 32 tile: narrow outputs (19 classes) pad to 64
   // bf16 operands (configs[2], direct algorithm everywhere): the MFMA phase is 16x shorter, the kernel is bound by staging its
   // operands through L2 / LDS, so the 128 x 128 tile (half the operand traffic per FLOP of 64 x 64) wins: 73.1 -> see DESIGN
   if (mode != MODE_WGRAD && !wide_bn && !bf16 && bn == 128) bn = 64;
@@ -1033,6 +1156,7 @@ void launch_inst(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
   }
   if constexpr (MODE == MODE_WGRAD && BN >= 64) {
     if (k.prec == 3) return launch_prec<MODE, BM, BN, WM, WN, KM, 3>(k, grid, smem, st);
+    if (k.prec == 4) return launch_prec<MODE, BM, BN, WM, WN, KM, 4>(k, grid, smem, st);
   }
   if (k.prec != 0) launch_prec<MODE, BM, BN, WM, WN, KM, 1>(k, grid, smem, st);
   else launch_prec<MODE, BM, BN, WM, WN, KM, 0>(k, grid, smem, st);
@@ -1072,7 +1196,7 @@ int launch(const ConvK& k0, const Plan& p, hipStream_t st, int batch = 1, double
     (void)hipEventRecord(rec.a, st);
   }
   constexpr bool akc = MODE != MODE_WGRAD, bkc = MODE == MODE_FWD;
-  const bool tr = MODE == MODE_WGRAD && k.prec == 3 && p.bn >= 64;      // bf16 [k][m + 32] tiles: 2 bytes per element
+  const bool tr = MODE == MODE_WGRAD && (k.prec == 3 || k.prec == 4) && p.bn >= 64;      // bf16 [k][m + 32] tiles: 2 bytes per element
   auto smem = [&](int bm, int bn) {
     if (tr) return (size_t)2 * (BK * (bm + 32) + BK * (bn + 32)) * 2;
     return (size_t)2 * ((akc ? bm * LDK : BK * bm) + (bkc ? bn * LDK : BK * bn)) * sizeof(float);
@@ -1103,7 +1227,11 @@ int check_common(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p
   const int ho = (x->h + 2 * p->pad - p->dil * (p->kh - 1) - 1) / p->stride + 1;
   const int wo = (x->w + 2 * p->pad - p->dil * (p->kw - 1) - 1) / p->stride + 1;
   PM_REQUIRE(ho == y->h && wo == y->w && x->n == y->n, PM_EINVAL, "conv: output %dx%d does not match geometry (%dx%d)", y->h, y->w, ho, wo);
-  PM_REQUIRE(pm_vec_ok(x) && pm_vec_ok(y), PM_EINVAL, "conv: tensors must be 16B aligned with pitch %% 4 == 0");
+  PM_REQUIRE((x->dtype == PM_F32 || x->dtype == PM_BF16) && (y->dtype == PM_F32 || y->dtype == PM_BF16), PM_EUNSUPPORTED, "conv: dtype %d / %d", x->dtype, y->dtype);
+  for (const pm_tensor* t : {x, y}) {
+    if (pm_is_bf16(t)) PM_REQUIRE(pm_vec8(t), PM_EINVAL, "conv: bf16 tensors must be 16B aligned with pitch %% 8 == 0 and channels %% 8 == 0");
+    else PM_REQUIRE(pm_vec_ok(t), PM_EINVAL, "conv: tensors must be 16B aligned with pitch %% 4 == 0");
+  }
   PM_REQUIRE(x->c % 4 == 0, PM_EUNSUPPORTED, "conv: Cin %% 4 != 0 unsupported (pad the input channels)");
   PM_REQUIRE((y->c % 4 == 0) || (p->kh * p->kw == 1), PM_EUNSUPPORTED, "conv: Cout %% 4 != 0 only for 1x1");
   PM_REQUIRE(x->pitch >= x->c && y->pitch >= y->c, PM_EINVAL, "conv: pitch < channels");
@@ -1121,7 +1249,7 @@ void fill_geom(ConvK& k, const pm_tensor* x, const pm_tensor* y, const pm_conv_p
   k.T_eff = p->kh * p->kw, k.tk_w = p->kw, k.ky0 = k.kx0 = 0, k.ksy = k.ksx = 1;
   k.sub = k.sub_cy = k.sub_cx = 0, k.Hc = x->h, k.Wc = x->w;
   k.bias = k.scale = k.shift = k.residual = nullptr;
-  k.res_pitch = 0, k.relu = 0, k.stats = nullptr;
+  k.res_pitch = 0, k.relu = 0, k.stats = nullptr, k.io16 = 0;
   static const int stage_ep = getenv("PM_STAGE_EP") ? atoi(getenv("PM_STAGE_EP")) : 1;
   k.stage_ep = stage_ep;
   k.a_bs = k.b_bs = k.c_bs = 0;
@@ -1276,6 +1404,7 @@ int wino_wgrad(const pm_tensor* x, const pm_tensor* dy, float* dw, const WinoPla
 // so that a slab never straddles a tap and the wave-uniform K-state (K_FAST) applies to every layer.
 struct Bf16Plan {
   bool use;
+  bool inplace;              // the gathered operand already is a bf16 tensor whose rows can be gathered where they lie (no cast / pad pass)
   int Cp;                    // padded input channels (bf16 elements)
   long M, Nn, Kf;            // GEMM extents, K in float units (= taps * Cp / 2)
   size_t xb_bytes, wb_bytes;
@@ -1283,13 +1412,16 @@ struct Bf16Plan {
 };
 Bf16Plan bf16_plan(const pm_tensor* xin, const pm_tensor* yout, const pm_conv_params* p) {
   Bf16Plan b{};
-  if (p->prec != 2 || xin->c < 32) return b;                      // the 3(4)-channel stem would be padded 16x
+  if ((p->prec != 2 && !pm_is_bf16(xin) && !pm_is_bf16(yout)) || xin->c < 32) return b;      // the 3(4)-channel stem would be padded 16x
   b.Cp = (xin->c + 63) / 64 * 64;
   const long T = (long)p->kh * p->kw;
   b.M = pm_pixels(yout), b.Nn = yout->c, b.Kf = T * b.Cp / 2;
-  const size_t xb = (size_t)pm_pixels(xin) * b.Cp * 2, wb = (size_t)yout->c * T * b.Cp * 2;
+  // round 4, bf16 activations: a bf16 tensor is gathered in place when a K-slab of 64 channels never straddles a tap, i.e. its channel count is a multiple of 64,
+  // or the caller vouches for zero-filled pad channels inside the pitch (PM_TF_ZERO_PAD64: the decoder's 304-channel concat buffer)
+  b.inplace = pm_is_bf16(xin) && (xin->c % 64 == 0 || ((xin->flags & PM_TF_ZERO_PAD64) && xin->pitch >= b.Cp));
+  const size_t xb = b.inplace ? (size_t)pm_pixels(xin) * xin->pitch * 2 : (size_t)pm_pixels(xin) * b.Cp * 2, wb = (size_t)yout->c * T * b.Cp * 2;
   if (xb >= (1ull << 31) || wb >= (1ull << 31)) return b;         // 32-bit byte offsets
-  b.xb_bytes = pm_align_up(xb, 256), b.wb_bytes = pm_align_up(wb, 256);
+  b.xb_bytes = b.inplace ? 0 : pm_align_up(xb, 256), b.wb_bytes = pm_align_up(wb, 256);
   b.pl = make_plan(MODE_FWD, b.M, b.Nn, b.Kf, true);
   if (b.pl.bn < 64) return b;                                     // no bf16 instantiation of the 128 x 32 tile
   b.use = true;
@@ -1302,26 +1434,32 @@ inline size_t bf16_ws(const Bf16Plan& b) { return b.xb_bytes + b.wb_bytes + pm_a
 // convolution of dy with pad' = dil (k - 1) - pad).
 int conv_bf16(const pm_tensor* xin, const float* w, int w_cout, int w_cin, bool rotate, const pm_tensor* yout, const pm_conv_params* pe, const Bf16Plan& b,
               const pm_conv_epilogue& e0, void* ws, hipStream_t st, char* wb_ext = nullptr, bool wb_valid = false) {
-  char* xb = (char*)ws;
-  char* wb = wb_ext ? wb_ext : xb + b.xb_bytes;          // caller-owned: survives the call (weight-cast cache)
-  float* slab = (float*)(xb + b.xb_bytes + b.wb_bytes);
+  char* xb = b.inplace ? (char*)xin->ptr : (char*)ws;
+  char* wb = wb_ext ? wb_ext : (char*)ws + b.xb_bytes;   // caller-owned: survives the call (weight-cast cache)
+  float* slab = (float*)((char*)ws + b.xb_bytes + b.wb_bytes);
   const int T = pe->kh * pe->kw;
-  if (int e = pm_bf16_cast_rows((const float*)xin->ptr, xin->pitch, xin->c, b.Cp, pm_pixels(xin), xb, st)) return e;
+  if (!b.inplace) {
+    if (pm_is_bf16(xin)) {      // bf16 rows whose channel count is not a multiple of 64 (48): copied once with zero pad channels
+      if (int e = pm16_pad_rows((const pm_bf16*)xin->ptr, xin->pitch, xin->c, b.Cp, pm_pixels(xin), (pm_bf16*)xb, st)) return e;
+    } else if (int e = pm_bf16_cast_rows((const float*)xin->ptr, xin->pitch, xin->c, b.Cp, pm_pixels(xin), xb, st)) return e;
+  }
   if (!(wb_ext && wb_valid))
     if (int e = pm_bf16_cast_weights(w, w_cout, T, w_cin, b.Cp, rotate, wb, st)) return e;
-  const pm_tensor xv = {xb, xin->n, xin->h, xin->w, b.Cp / 2, b.Cp / 2};     // fp32-typed view: one float = two bf16 channels
+  const long xpitch16 = b.inplace ? xin->pitch : b.Cp;                       // bf16 elements between pixels
+  const pm_tensor xv = {xb, xin->n, xin->h, xin->w, b.Cp / 2, xpitch16 / 2};   // fp32-typed view: one float = two bf16 channels
   ConvK k;
   fill_geom(k, &xv, yout, pe);
   k.prec = 2;
   k.A = (const float*)xb, k.B = (const float*)wb;
   k.M = (int)b.M, k.Nn = (int)b.Nn, k.K = (int)b.Kf;
-  k.a_bytes = (unsigned)((size_t)pm_pixels(xin) * b.Cp * 2), k.b_bytes = (unsigned)((size_t)yout->c * T * b.Cp * 2), k.kmode = K_FAST;
+  k.a_bytes = (unsigned)((size_t)pm_pixels(xin) * xpitch16 * 2), k.b_bytes = (unsigned)((size_t)yout->c * T * b.Cp * 2), k.kmode = K_FAST;
   const double flops = 2.0 * (double)b.M * (double)b.Nn * (double)T * (double)xin->c;
+  k.io16 = pm_is_bf16(yout) ? 1 : 0;      // bf16 output (and bf16 residual / skip gradient: the caller checked the types)
   if (b.pl.ksplit > 1) {
     k.C = slab, k.c_pitch = b.Nn, k.c_split = b.M * b.Nn;
     if (int e = launch<MODE_FWD>(k, b.pl, st, 1, flops)) return e;
     return splitk_reduce(slab, b.pl.ksplit, b.M, b.Nn, (float*)yout->ptr, (long)yout->pitch, e0.bias, e0.scale, e0.shift, e0.residual, (long)e0.residual_pitch,
-                         e0.relu, st);
+                         e0.relu, st, k.io16 != 0);
   }
   k.C = (float*)yout->ptr, k.c_pitch = yout->pitch, k.c_split = 0;
   k.bias = e0.bias, k.scale = e0.scale, k.shift = e0.shift, k.residual = e0.residual, k.res_pitch = e0.residual_pitch, k.relu = e0.relu;
@@ -1334,6 +1472,20 @@ inline pm_conv_params dgrad_as_fwd(const pm_conv_params* p) {
   return q;
 }
 inline bool dgrad_bf16_ok(const pm_conv_params* p) { return p->prec == 2 && p->stride == 1 && p->kh == p->kw && p->dil * (p->kh - 1) - p->pad >= 0; }
+// the bf16 tier is entered by tensor type as well as by pm_conv_params.prec: a call with a bf16 tensor always runs the bf16-MFMA forms
+inline pm_conv_params tier_params(const pm_conv_params* p, const pm_tensor* a, const pm_tensor* b) {
+  pm_conv_params q = *p;
+  if (pm_is_bf16(a) || pm_is_bf16(b)) q.prec = 2;
+  return q;
+}
+// dense fp32 copy of a bf16 tensor in the workspace (the few mixed-type call sites: stride-2 data gradients, stem / class-head weight gradients, bias gradients)
+inline size_t upcast_bytes(const pm_tensor* t) { return pm_is_bf16(t) ? pm_align_up((size_t)pm_pixels(t) * t->c * sizeof(float), 256) : 0; }
+inline int upcast(const pm_tensor* t, void* dst, pm_tensor* out, hipStream_t st) {
+  *out = *t;
+  if (!pm_is_bf16(t)) return PM_OK;
+  out->ptr = dst, out->pitch = t->c, out->dtype = PM_F32, out->flags = 0;
+  return pm16_to_f32((const pm_bf16*)t->ptr, t->pitch, t->c, pm_pixels(t), (float*)dst, t->c, st);
+}
 
 // prec = 2 weight gradient: dw[co][(t, ci)] = sum_p dyt[co][p] * xt[t][ci][p] over the output pixels p -- with both operands transposed to
 // pixel-contiguous bf16 (pm_bf16_transpose_taps: per tap the input pixel each output pixel sees, zero outside the image) this is the same
@@ -1460,14 +1612,18 @@ extern "C" int pm_profile_dump(const char* path) {
   return PM_OK;
 }
 
-extern "C" size_t pm_conv_winograd_v_bytes(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p) {
-  if (!x || !y || !p) return 0;
+extern "C" size_t pm_conv_winograd_v_bytes(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p0) {
+  if (!x || !y || !p0) return 0;
+  const pm_conv_params tp = tier_params(p0, x, y);
+  const pm_conv_params* p = &tp;
   const WinoPlan f = wino_plan(x, y->c, p), g = wino_plan(x, y->c, p, true);   // forward and weight gradient both on the route
   return (f.use && g.use && f.g.m == g.g.m) ? f.v_bytes : 0;
 }
 
-extern "C" size_t pm_conv_wxf_bytes(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p) {
-  if (!x || !y || !p) return 0;
+extern "C" size_t pm_conv_wxf_bytes(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p0) {
+  if (!x || !y || !p0) return 0;
+  const pm_conv_params tp = tier_params(p0, x, y);
+  const pm_conv_params* p = &tp;
   const WinoPlan f = wino_plan(x, y->c, p);
   if (f.use) return f.u_bytes;
   if (p->prec == 2) {
@@ -1481,6 +1637,7 @@ extern "C" size_t pm_conv_wxf_bytes(const pm_tensor* x, const pm_tensor* y, cons
 // split and a 16-byte-aligned output takes the staged epilogue; everything else (Winograd route, split-K, the 19-class heads) answers 0.
 static bool bn_partials_route(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p) {
   if (!x || !y || !p || check_common(x, y, p) != PM_OK) return false;
+  if (pm_is_bf16(x) || pm_is_bf16(y)) return false;      // the statistics epilogue exists for fp32 outputs only
   if ((y->c & 3) || (y->pitch & 3) || !pm_aligned16(y->ptr)) return false;
   static const int on = getenv("PM_BN_EPILOGUE") ? atoi(getenv("PM_BN_EPILOGUE")) : 1;
   static const int stage_ep = getenv("PM_STAGE_EP") ? atoi(getenv("PM_STAGE_EP")) : 1;
@@ -1501,15 +1658,17 @@ extern "C" size_t pm_conv_bn_partials_bytes(const pm_tensor* x, const pm_tensor*
   return pm_align_up((size_t)pm_cdiv(pm_pixels(y), 32) * y->c * 2 * sizeof(float), 256);
 }
 
-extern "C" size_t pm_conv_workspace(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p, int which) {
+extern "C" size_t pm_conv_workspace(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p0, int which) {
+  const pm_conv_params tp = tier_params(p0, x, y);
+  const pm_conv_params* p = &tp;
   if (which == MODE_DGRAD && p->stride == 2) {   // four parity classes: compact results + the largest split-K slab set
-    size_t slab = 0, tmp = 0;
+    size_t slab = 0, tmp = 0;      // (+ the fp32 copy of a bf16 dy below: on the bf16 tier the stride-2 data gradient still gathers fp32 rows)
     for (int cls = 0; cls < 4; ++cls) {
       const S2Class c = s2_class(cls, x, p);
       tmp = std::max(tmp, (size_t)c.M * x->c * sizeof(float));
       if (c.M > 0 && c.nky * c.nkx > 0) slab = std::max(slab, make_plan(MODE_DGRAD, c.M, x->c, (long)c.nky * c.nkx * y->c, p->prec != 0).ws_bytes);
     }
-    return pm_align_up(4 * pm_align_up(tmp, 256) + slab + 256, 256);
+    return pm_align_up(4 * pm_align_up(tmp, 256) + slab + 256, 256) + upcast_bytes(y);
   }
   if (which == MODE_FWD && p->prec == 2) {
     const Bf16Plan b = bf16_plan(x, y, p);
@@ -1525,6 +1684,11 @@ extern "C" size_t pm_conv_workspace(const pm_tensor* x, const pm_tensor* y, cons
     if (wp.use) return wino_ws(wp);
   }
   const size_t bias_part = pm_align_up((size_t)pm_cdiv(pm_pixels(y), colsum_rows(pm_pixels(y), y->c)) * y->c * sizeof(float), 256);
+  if (which == MODE_WGRAD && (pm_is_bf16(x) || pm_is_bf16(y))) {      // bf16 tier: split-K slabs + bias partials + the fp32 copies of the mixed-type call sites
+    long M, Nn, K;
+    gemm_dims(which, x, y, p, M, Nn, K);
+    return pm_align_up(make_plan(which, M, Nn, K, true).ws_bytes, 256) + bias_part + upcast_bytes(x) + upcast_bytes(y);
+  }
   if (which == MODE_WGRAD && p->prec == 2) {
     const Bf16WgradPlan b = bf16_wgrad_plan(x, y, p);
     if (b.use) return pm_align_up(bf16_wgrad_ws(b), 256) + bias_part;
@@ -1540,9 +1704,11 @@ extern "C" size_t pm_conv_workspace(const pm_tensor* x, const pm_tensor* y, cons
   return pm_align_up(b, 256);
 }
 
-extern "C" int pm_conv_fwd(const pm_tensor* x, const float* w, const pm_tensor* y, const pm_conv_params* p,
+extern "C" int pm_conv_fwd(const pm_tensor* x, const float* w, const pm_tensor* y, const pm_conv_params* p0,
                            const pm_conv_epilogue* ep, void* ws, size_t ws_bytes, void* stream) {
-  if (int e = check_common(x, y, p)) return e;
+  if (int e = check_common(x, y, p0)) return e;
+  const pm_conv_params tp = tier_params(p0, x, y);      // a bf16 tensor puts the call on the bf16 tier whatever prec says
+  const pm_conv_params* p = &tp;
   PM_REQUIRE(!ep || ep->struct_size == (int64_t)sizeof(pm_conv_epilogue), PM_EINVAL,
              "conv_fwd: pm_conv_epilogue.struct_size %ld != %zu -- caller built against another pinmem_hip.h (library ABI %d)", ep ? (long)ep->struct_size : 0l,
              sizeof(pm_conv_epilogue), PM_ABI_VERSION);
@@ -1575,12 +1741,15 @@ extern "C" int pm_conv_fwd(const pm_tensor* x, const float* w, const pm_tensor* 
       return conv_bf16(x, w, y->c, x->c, false, y, p, b, e2, ws, (hipStream_t)stream, wext, p->wxf_valid != 0);
     }
   }
+  // what is left gathers fp32 rows: fp32 convolutions, and on the bf16 tier the 4-channel stem (fp32 image in, bf16 out)
+  PM_REQUIRE(pm_is_f32(x), PM_EUNSUPPORTED, "conv_fwd: a bf16 input needs at least 32 channels (got %d)", x->c);
   long M, Nn, K;
   gemm_dims(MODE_FWD, x, y, p, M, Nn, K);
   Plan pl = make_plan(MODE_FWD, M, Nn, K, p->prec != 0);
   PM_REQUIRE(pl.ws_bytes <= ws_bytes && (pl.ws_bytes == 0 || ws), PM_EWORKSPACE, "conv_fwd: workspace %zu < %zu", ws_bytes, pl.ws_bytes);
   ConvK k;
   fill_geom(k, x, y, p);
+  k.io16 = pm_is_bf16(y) ? 1 : 0;
   k.A = (const float*)x->ptr, k.B = w;
   k.M = (int)M, k.Nn = (int)Nn, k.K = (int)K;
   k.a_bytes = (unsigned)(pm_pixels(x) * x->pitch * 4), k.b_bytes = (unsigned)((long)y->c * K * 4), k.kmode = x->c % BK == 0 ? 0 : (x->c >= BK ? 1 : 2);
@@ -1592,7 +1761,7 @@ extern "C" int pm_conv_fwd(const pm_tensor* x, const float* w, const pm_tensor* 
     k.C = (float*)ws, k.c_pitch = Nn, k.c_split = M * Nn;
     if (int e = launch<MODE_FWD>(k, pl, st)) return e;
     return splitk_reduce((const float*)ws, pl.ksplit, M, Nn, (float*)y->ptr, (long)y->pitch, e0.bias, e0.scale, e0.shift, e0.residual,
-                         (long)e0.residual_pitch, e0.relu, st);
+                         (long)e0.residual_pitch, e0.relu, st, k.io16 != 0);
   }
   k.C = (float*)y->ptr, k.c_pitch = y->pitch, k.c_split = 0;
   k.bias = e0.bias, k.scale = e0.scale, k.shift = e0.shift, k.residual = e0.residual, k.res_pitch = e0.residual_pitch, k.relu = e0.relu;
@@ -1600,10 +1769,15 @@ extern "C" int pm_conv_fwd(const pm_tensor* x, const float* w, const pm_tensor* 
   return launch<MODE_FWD>(k, pl, st);
 }
 
-extern "C" int pm_conv_bwd_data(const pm_tensor* dy, const float* w, const pm_tensor* dx, const pm_conv_params* p, const pm_tensor* add,
+extern "C" int pm_conv_bwd_data(const pm_tensor* dy0, const float* w, const pm_tensor* dx, const pm_conv_params* p0, const pm_tensor* add,
                                 void* ws, size_t ws_bytes, void* stream) {
-  if (int e = check_common(dx, dy, p)) return e;
-  PM_REQUIRE(!add || (add->ptr && pm_same_shape(add, dx)), PM_EINVAL, "conv_bwd_data: `add` must match dx");
+  if (int e = check_common(dx, dy0, p0)) return e;
+  const pm_conv_params tp = tier_params(p0, dy0, dx);
+  const pm_conv_params* p = &tp;
+  const pm_tensor* dy = dy0;
+  pm_tensor dy32;
+  PM_REQUIRE(!add || (add->ptr && pm_same_shape(add, dx) && add->dtype == dx->dtype), PM_EINVAL, "conv_bwd_data: `add` must match dx (shape and dtype)");
+  PM_REQUIRE(!add || !pm_is_bf16(add) || pm_vec8(add), PM_EINVAL, "conv_bwd_data: bf16 `add` must be 16B aligned with pitch %% 8 == 0");
   const float* addp = add ? (const float*)add->ptr : nullptr;
   const long add_pitch = add ? add->pitch : 0;
   PM_REQUIRE(w && pm_aligned16(w), PM_EINVAL, "conv_bwd_data: weight null or unaligned");
@@ -1615,6 +1789,10 @@ extern "C" int pm_conv_bwd_data(const pm_tensor* dy, const float* w, const pm_te
     const size_t need = pm_conv_workspace(dx, dy, p, MODE_DGRAD);
     PM_REQUIRE(ws && ws_bytes >= need, PM_EWORKSPACE, "conv_bwd_data(stride 2): workspace %zu < %zu", ws_bytes, need);
     PM_REQUIRE(dx->c % 4 == 0, PM_EUNSUPPORTED, "conv_bwd_data(stride 2): Cin %% 4 != 0");
+    if (pm_is_bf16(dy)) {      // bf16 tier: the parity-class gather reads fp32 rows -- dy (a quarter of dx's pixels) is widened once, at the end of the workspace
+      if (int e = upcast(dy0, (char*)ws + need - upcast_bytes(dy0), &dy32, st0)) return e;
+      dy = &dy32;
+    }
     size_t tmp_bytes = 0;
     for (int cls = 0; cls < 4; ++cls) tmp_bytes = std::max(tmp_bytes, (size_t)s2_class(cls, dx, p).M * dx->c * sizeof(float));
     tmp_bytes = pm_align_up(tmp_bytes, 256);
@@ -1647,9 +1825,12 @@ extern "C" int pm_conv_bwd_data(const pm_tensor* dy, const float* w, const pm_te
     }
     const int valid_mask = valid[0] | (valid[1] << 1) | (valid[2] << 2) | (valid[3] << 3);
     const long total = pm_pixels(dx) * (dx->c / 4);
-    hipLaunchKernelGGL(dgrad_s2_interleave_kernel, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, st0, (const float*)tmp,
-                       (long)(tmp_bytes / sizeof(float)), valid_mask, (float*)dx->ptr, (long)dx->pitch, dx->n, dx->h, dx->w, dx->c, addp,
-                       add_pitch);
+    if (pm_is_bf16(dx))
+      hipLaunchKernelGGL(dgrad_s2_interleave_kernel<true>, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, st0, (const float*)tmp,
+                         (long)(tmp_bytes / sizeof(float)), valid_mask, (float*)dx->ptr, (long)dx->pitch, dx->n, dx->h, dx->w, dx->c, addp, add_pitch);
+    else
+      hipLaunchKernelGGL(dgrad_s2_interleave_kernel<false>, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, st0, (const float*)tmp,
+                         (long)(tmp_bytes / sizeof(float)), valid_mask, (float*)dx->ptr, (long)dx->pitch, dx->n, dx->h, dx->w, dx->c, addp, add_pitch);
     return pm_check_launch("dgrad_s2_interleave");
   }
   if (dgrad_bf16_ok(p)) {      // data gradient of a stride-1 convolution = forward convolution of dy with the rotated / transposed filter
@@ -1669,12 +1850,14 @@ extern "C" int pm_conv_bwd_data(const pm_tensor* dy, const float* w, const pm_te
       return wino_conv(dy, w, dy->c, dx->c, true, dx, wp, e1, ws, st0);
     }
   }
+  PM_REQUIRE(pm_is_f32(dy), PM_EUNSUPPORTED, "conv_bwd_data: a bf16 dy needs at least 32 channels and a stride-1 geometry the forward form covers");
   long M, Nn, K;
   gemm_dims(MODE_DGRAD, dx, dy, p, M, Nn, K);
   Plan pl = make_plan(MODE_DGRAD, M, Nn, K, p->prec != 0);
   PM_REQUIRE(pl.ws_bytes <= ws_bytes && (pl.ws_bytes == 0 || ws), PM_EWORKSPACE, "conv_bwd_data: workspace %zu < %zu", ws_bytes, pl.ws_bytes);
   ConvK k;
   fill_geom(k, dx, dy, p);
+  k.io16 = pm_is_bf16(dx) ? 1 : 0;
   k.A = (const float*)dy->ptr, k.B = w;
   k.M = (int)M, k.Nn = (int)Nn, k.K = (int)K;
   k.a_bytes = (unsigned)(pm_pixels(dy) * dy->pitch * 4), k.b_bytes = (unsigned)((long)dy->c * p->kh * p->kw * dx->c * 4), k.kmode = (dy->c % BK == 0 && p->stride == 1) ? 0 : (dy->c >= BK ? 1 : 2);
@@ -1682,32 +1865,55 @@ extern "C" int pm_conv_bwd_data(const pm_tensor* dy, const float* w, const pm_te
   if (pl.ksplit > 1) {
     k.C = (float*)ws, k.c_pitch = Nn, k.c_split = M * Nn;
     if (int e = launch<MODE_DGRAD>(k, pl, st)) return e;
-    return splitk_reduce((const float*)ws, pl.ksplit, M, Nn, (float*)dx->ptr, (long)dx->pitch, nullptr, nullptr, nullptr, addp, add_pitch, 0, st);
+    return splitk_reduce((const float*)ws, pl.ksplit, M, Nn, (float*)dx->ptr, (long)dx->pitch, nullptr, nullptr, nullptr, addp, add_pitch, 0, st, k.io16 != 0);
   }
   k.C = (float*)dx->ptr, k.c_pitch = dx->pitch, k.c_split = 0;
   k.residual = addp, k.res_pitch = add_pitch;
   return launch<MODE_DGRAD>(k, pl, st);
 }
 
-extern "C" int pm_conv_bwd_weight(const pm_tensor* x, const pm_tensor* dy, float* dw, float* dbias, const pm_conv_params* p, void* ws,
+extern "C" int pm_conv_bwd_weight(const pm_tensor* x0, const pm_tensor* dy0, float* dw, float* dbias, const pm_conv_params* p0, void* ws,
                                   size_t ws_bytes, void* stream) {
-  if (int e = check_common(x, dy, p)) return e;
+  if (int e = check_common(x0, dy0, p0)) return e;
+  const pm_conv_params tp = tier_params(p0, x0, dy0);
+  const pm_conv_params* p = &tp;
   PM_REQUIRE(dw && pm_aligned16(dw), PM_EINVAL, "conv_bwd_weight: dw null or unaligned");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t need = pm_conv_workspace(x0, dy0, p, MODE_WGRAD);
+  PM_REQUIRE(need <= ws_bytes && ws, PM_EWORKSPACE, "conv_bwd_weight: workspace %zu < %zu", ws_bytes, need);
+  const pm_tensor *x = x0, *dy = dy0;
+  pm_tensor x32, dy32;
+  // bf16 tier. Both operands bf16: the gather moves 16 bytes = eight channels per lane straight into the bf16 LDS tiles of the transpose-read form (PREC 4).
+  // Mixed types (fp32 image x bf16 dy: the stem; bf16 x x fp32 dy: the 19-class heads) and a bias gradient over a bf16 dy: the bf16 side is widened to a
+  // dense fp32 copy at the end of the workspace and the call proceeds as the fp32-gather form (PREC 3) -- small tensors, once per step.
+  const bool tier = pm_is_bf16(x0) || pm_is_bf16(dy0);
+  const bool native16 = pm_is_bf16(x0) && pm_is_bf16(dy0) && dy0->c >= 32;
+  if (tier) {
+    char* tail = (char*)ws + need;
+    if (!native16 && pm_is_bf16(x0)) {
+      tail -= upcast_bytes(x0);
+      if (int e = upcast(x0, tail, &x32, st)) return e;
+      x = &x32;
+    }
+    if (pm_is_bf16(dy0) && (!native16 || dbias)) {
+      tail -= upcast_bytes(dy0);
+      if (int e = upcast(dy0, tail, &dy32, st)) return e;
+      if (!native16) dy = &dy32;
+    }
+  }
   long M, Nn, K;
   gemm_dims(MODE_WGRAD, x, dy, p, M, Nn, K);
   Plan pl = make_plan(MODE_WGRAD, M, Nn, K, p->prec != 0);
-  const size_t need = pm_conv_workspace(x, dy, p, MODE_WGRAD);
-  PM_REQUIRE(need <= ws_bytes && ws, PM_EWORKSPACE, "conv_bwd_weight: workspace %zu < %zu", ws_bytes, need);
-  const Bf16WgradPlan bw = bf16_wgrad_plan(x, dy, p);
+  const Bf16WgradPlan bw = tier ? Bf16WgradPlan{} : bf16_wgrad_plan(x, dy, p);
   if (bw.use) {
-    if (int e = conv_wgrad_bf16(x, dy, dw, p, bw, ws, (hipStream_t)stream)) return e;
+    if (int e = conv_wgrad_bf16(x, dy, dw, p, bw, ws, st)) return e;
     pl.ws_bytes = bf16_wgrad_ws(bw);       // the bias partials follow the bf16 buffers
   }
   const WinoPlan wp = wino_plan(x, dy->c, p, true);
   if (wp.use) {
     const WinoWgradPlan q = wino_wgrad_plan(wp, dy->c);
     float* kept = (p->wino_v && (size_t)p->wino_v_bytes >= wp.v_bytes) ? (float*)p->wino_v : nullptr;
-    if (int e = wino_wgrad(x, dy, dw, wp, q, ws, (hipStream_t)stream, kept)) return e;
+    if (int e = wino_wgrad(x, dy, dw, wp, q, ws, st, kept)) return e;
     pl.ws_bytes = wino_wgrad_ws(wp, q);     // the bias partials follow the Winograd buffers
   }
   ConvK k;
@@ -1716,10 +1922,14 @@ extern "C" int pm_conv_bwd_weight(const pm_tensor* x, const pm_tensor* dy, float
   // transpose read (PREC 3): no transposed / per-tap copies of x in HBM. PM_BF16_WGRAD_TR=0 keeps the staged-fp32 form (A/B runs).
   static const int tr_on = getenv("PM_BF16_WGRAD_TR") ? atoi(getenv("PM_BF16_WGRAD_TR")) : 1;
   if (p->prec == 2 && tr_on) k.prec = 3;
+  if (native16) {
+    PM_REQUIRE(x->c % 8 == 0 && dy->c % 8 == 0 && pl.bn >= 64, PM_EUNSUPPORTED, "conv_bwd_weight(bf16): channels %% 8 != 0 or a tile narrower than 64");
+    k.prec = 4;
+  }
+  const int esz = native16 ? 2 : 4;
   k.A = (const float*)dy->ptr, k.B = (const float*)x->ptr;
   k.M = (int)M, k.Nn = (int)Nn, k.K = (int)K;
-  k.a_bytes = (unsigned)(pm_pixels(dy) * dy->pitch * 4), k.b_bytes = (unsigned)(pm_pixels(x) * x->pitch * 4), k.kmode = dy->w >= BK ? 1 : 2;
-  hipStream_t st = (hipStream_t)stream;
+  k.a_bytes = (unsigned)(pm_pixels(dy) * dy->pitch * esz), k.b_bytes = (unsigned)(pm_pixels(x) * x->pitch * esz), k.kmode = dy->w >= BK ? 1 : 2;
   if (wp.use || bw.use) {
   } else if (pl.ksplit > 1) {
     k.C = (float*)ws, k.c_pitch = Nn, k.c_split = M * Nn;
@@ -1730,14 +1940,15 @@ extern "C" int pm_conv_bwd_weight(const pm_tensor* x, const pm_tensor* dy, float
     if (int e = launch<MODE_WGRAD>(k, pl, st)) return e;
   }
   if (dbias) {
-    const long P = pm_pixels(dy);
-    const int rpb = colsum_rows(P, dy->c), nb = pm_cdiv(P, rpb);
+    const pm_tensor* dyb = pm_is_bf16(dy0) ? &dy32 : dy0;      // the bias gradient sums fp32 rows
+    const long P = pm_pixels(dyb);
+    const int rpb = colsum_rows(P, dyb->c), nb = pm_cdiv(P, rpb);
     float* part = (float*)((char*)ws + pm_align_up(pl.ws_bytes, 256));
-    if (dy->pitch == ((dy->c + 3) & ~3) && dy->pitch <= 64 && pm_aligned16(dy->ptr))   // the tensor's own (pad-to-4) rows, not a channel slice
-      hipLaunchKernelGGL(colsum_partial_narrow_kernel, dim3(nb), dim3(256), 0, st, (const float*)dy->ptr, (int)(dy->pitch / 4), P, dy->c, rpb, part);
+    if (dyb->pitch == ((dyb->c + 3) & ~3) && dyb->pitch <= 64 && pm_aligned16(dyb->ptr))   // the tensor's own (pad-to-4) rows, not a channel slice
+      hipLaunchKernelGGL(colsum_partial_narrow_kernel, dim3(nb), dim3(256), 0, st, (const float*)dyb->ptr, (int)(dyb->pitch / 4), P, dyb->c, rpb, part);
     else
-      hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb, pm_cdiv(dy->c, 64)), dim3(256), 0, st, (const float*)dy->ptr, (long)dy->pitch, P, dy->c, rpb, part);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(pm_cdiv(dy->c, 64)), dim3(1024), 0, st, (const float*)part, nb, dy->c, dbias);
+      hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb, pm_cdiv(dyb->c, 64)), dim3(256), 0, st, (const float*)dyb->ptr, (long)dyb->pitch, P, dyb->c, rpb, part);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(pm_cdiv(dyb->c, 64)), dim3(1024), 0, st, (const float*)part, nb, dyb->c, dbias);
     return pm_check_launch("conv_bias_grad");
   }
   return PM_OK;

@@ -342,6 +342,7 @@ extern "C" size_t pm_upsample_ce_workspace(int n, int H, int W) {   // one (sum,
 
 extern "C" int pm_upsample_ce_fwd(const pm_tensor* logits, float inv_temp, const int64_t* labels, int H, int W, float* loss_out, void* ws, size_t ws_bytes,
                                   void* stream) {
+  PM_REQUIRE_F32(logits, "upsample_ce_fwd");
   CEGeom g;
   if (int e = fill(g, logits, inv_temp, labels, H, W, "upsample_ce_fwd")) return e;
   PM_REQUIRE(loss_out && ws && ws_bytes >= pm_upsample_ce_workspace(g.n, H, W), PM_EWORKSPACE, "upsample_ce_fwd: workspace too small");
@@ -410,12 +411,14 @@ int fused_launch(const CEGeom& g, const FusedPlan& p, float* part, float* T, hip
 }  // namespace
 
 extern "C" size_t pm_upsample_ce_field_bytes(const pm_tensor* logits, int H, int W) {
+  if ((logits && !pm_is_f32(logits))) return 0;      // fp32 tensors only
   (void)W;
   return (size_t)logits->n * H * logits->w * logits->c * sizeof(float);
 }
 
 extern "C" int pm_upsample_ce_fwd_field(const pm_tensor* logits, float inv_temp, const int64_t* labels, int H, int W, float* loss_out, float* field,
                                         void* ws, size_t ws_bytes, void* stream) {
+  PM_REQUIRE_F32(logits, "upsample_ce_fwd_field");
   CEGeom g;
   if (int e = fill(g, logits, inv_temp, labels, H, W, "upsample_ce_fwd_field")) return e;
   PM_REQUIRE(loss_out && field && ws && ws_bytes >= pm_upsample_ce_workspace(g.n, H, W), PM_EWORKSPACE, "upsample_ce_fwd_field: workspace too small / null field");
@@ -429,6 +432,8 @@ extern "C" int pm_upsample_ce_fwd_field(const pm_tensor* logits, float inv_temp,
 
 extern "C" int pm_upsample_ce_bwd_field(const pm_tensor* logits, float inv_temp, int H, int W, const float* loss_out, const float* gscale, const float* field,
                                         const pm_tensor* dlogits, void* stream) {
+  PM_REQUIRE_F32(logits, "upsample_ce_bwd_field");
+  PM_REQUIRE_F32(dlogits, "upsample_ce_bwd_field");
   CEGeom g;
   static const int64_t dummy = 0;
   if (int e = fill(g, logits, inv_temp, &dummy, H, W, "upsample_ce_bwd_field")) return e;      // the row pass reads neither labels nor logits
@@ -442,11 +447,14 @@ extern "C" int pm_upsample_ce_bwd_field(const pm_tensor* logits, float inv_temp,
 // Backward without a field from the forward (the caller ran pm_upsample_ce_fwd): the field is rebuilt into the workspace by the same fused sweep
 // (its loss partials are discarded), then the row pass. Same results as pm_upsample_ce_fwd_field + pm_upsample_ce_bwd_field.
 extern "C" size_t pm_upsample_ce_bwd_workspace(const pm_tensor* logits, int H, int W) {
+  if ((logits && !pm_is_f32(logits))) return 0;      // fp32 tensors only
   return pm_align_up(pm_upsample_ce_field_bytes(logits, H, W), 256) + pm_upsample_ce_workspace(logits->n, H, W);
 }
 
 extern "C" int pm_upsample_ce_bwd(const pm_tensor* logits, float inv_temp, const int64_t* labels, int H, int W, const float* loss_out, const float* gscale,
                                   const pm_tensor* dlogits, void* ws, size_t ws_bytes, void* stream) {
+  PM_REQUIRE_F32(logits, "upsample_ce_bwd");
+  PM_REQUIRE_F32(dlogits, "upsample_ce_bwd");
   CEGeom g;
   if (int e = fill(g, logits, inv_temp, labels, H, W, "upsample_ce_bwd")) return e;
   PM_REQUIRE(loss_out && dlogits && dlogits->ptr && pm_same_shape(logits, dlogits), PM_EINVAL, "upsample_ce_bwd: bad args");

@@ -584,6 +584,8 @@ inline int accum_blocks(long rows) { return (int)std::min<long>((rows + 15) / 16
 
 extern "C" int pm_mem_read_fwd(const pm_tensor* x, const float* mem, int m, const float* noise, const pm_tensor* qr, float* score, float* p_mem,
                                void* stream) {
+  PM_REQUIRE_F32(x, "mem_read_fwd");
+  PM_REQUIRE_F32(qr, "mem_read_fwd");
   PM_REQUIRE(x && qr && mem && score && p_mem && x->ptr && qr->ptr, PM_EINVAL, "mem_read_fwd: null");
   PM_REQUIRE(x->c == D && qr->c == 2 * D && pm_vec_ok(x) && pm_vec_ok(qr) && pm_aligned16(mem), PM_EUNSUPPORTED, "mem_read_fwd: needs d == %d, aligned views", D);
   PM_REQUIRE(m >= 1 && m <= MAXM && pm_pixels(x) == pm_pixels(qr), PM_EINVAL, "mem_read_fwd: bad slots/rows");
@@ -613,6 +615,9 @@ extern "C" int pm_mem_colsoftmax(const float* score, const float* noise, int64_t
 extern "C" size_t pm_mem_read_bwd_workspace(int64_t rows, int m, int d) { return pm_align_up((size_t)row_blocks(rows) * m * d * sizeof(float), 256); }
 extern "C" int pm_mem_read_bwd(const pm_tensor* x, const float* mem, int m, const float* p_mem, const pm_tensor* dqr, const float* dsx,
                                const pm_tensor* dx, float* dmem, void* ws, size_t ws_bytes, void* stream) {
+  PM_REQUIRE_F32(x, "mem_read_bwd");
+  PM_REQUIRE_F32(dqr, "mem_read_bwd");
+  PM_REQUIRE_F32(dx, "mem_read_bwd");
   PM_REQUIRE(x && dqr && dx && mem && p_mem && x->ptr && dqr->ptr && dx->ptr, PM_EINVAL, "mem_read_bwd: null");
   PM_REQUIRE(x->c == D && dqr->c == 2 * D && dx->c == D && pm_vec_ok(x) && pm_vec_ok(dqr) && pm_vec_ok(dx) && pm_aligned16(mem), PM_EUNSUPPORTED,
              "mem_read_bwd: needs d == %d, aligned views", D);
@@ -651,10 +656,12 @@ extern "C" int pm_mem_read_bwd(const pm_tensor* x, const float* mem, int m, cons
 }
 
 extern "C" size_t pm_mem_write_accum_workspace(const pm_tensor* z, int m) {
+  if ((z && !pm_is_f32(z))) return 0;      // fp32 tensors only
   return pm_align_up((size_t)accum_blocks(pm_pixels(z)) * ((m + 1) * (D + 1)) * sizeof(float), 256);
 }
 extern "C" int pm_mem_write_accum(const pm_tensor* z, const int64_t* labels, int H, int W, int m, int normalize, float* nomden, void* ws, size_t ws_bytes,
                                   void* stream) {
+  PM_REQUIRE_F32(z, "mem_write_accum");
   PM_REQUIRE(z && z->ptr && labels && nomden, PM_EINVAL, "mem_write_accum: null");
   PM_REQUIRE(z->c == D && pm_vec_ok(z) && m >= 1 && m + 1 <= MAXM, PM_EUNSUPPORTED, "mem_write_accum: needs d == %d and <= %d slots", D, MAXM - 1);
   PM_REQUIRE(ws && ws_bytes >= pm_mem_write_accum_workspace(z, m), PM_EWORKSPACE, "mem_write_accum: workspace too small");
@@ -676,6 +683,8 @@ extern "C" int pm_mem_write_accum(const pm_tensor* z, const int64_t* labels, int
 
 extern "C" int pm_mem_write_accum_bwd(const pm_tensor* z, const int64_t* labels, int H, int W, int m, int normalize, const float* dnom,
                                       const pm_tensor* dz, void* stream) {
+  PM_REQUIRE_F32(z, "mem_write_accum_bwd");
+  PM_REQUIRE_F32(dz, "mem_write_accum_bwd");
   PM_REQUIRE(z && dz && z->ptr && dz->ptr && labels && dnom && pm_aligned16(dnom), PM_EINVAL, "mem_write_accum_bwd: null/unaligned");
   PM_REQUIRE(z->c == D && dz->c == D && pm_vec_ok(z) && pm_vec_ok(dz) && m >= 1 && m + 1 <= MAXM, PM_EUNSUPPORTED, "mem_write_accum_bwd: needs d == %d", D);
   const long rows = pm_pixels(z);

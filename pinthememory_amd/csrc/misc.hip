@@ -22,6 +22,7 @@ extern "C" int pm_version(void) { return PM_ABI_VERSION; }
 
 extern "C" int pm_relu_bwd(const pm_tensor* dy, const pm_tensor* y, const pm_tensor* dx, void* stream) {
   PM_REQUIRE(dy && y && dx && same_shape(dy, y) && same_shape(dy, dx), PM_EINVAL, "relu_bwd: shape mismatch");
+  PM_REQUIRE_F32(dy, "relu_bwd"); PM_REQUIRE_F32(y, "relu_bwd"); PM_REQUIRE_F32(dx, "relu_bwd");
   const float *pdy = (const float*)dy->ptr, *py = (const float*)y->ptr;
   float* pdx = (float*)dx->ptr;
   const long a = dy->pitch, b = y->pitch, c = dx->pitch;
@@ -38,6 +39,11 @@ extern "C" int pm_relu_bwd(const pm_tensor* dy, const pm_tensor* y, const pm_ten
 
 extern "C" int pm_add(const pm_tensor* x, const pm_tensor* y, const pm_tensor* o, void* stream) {
   PM_REQUIRE(x && y && o && same_shape(x, y) && same_shape(x, o), PM_EINVAL, "add: shape mismatch");
+  if (pm_is_bf16(o)) {
+    const pm_tensor* two[2] = {x, y};
+    return pm16_add_n(two, 2, o, (hipStream_t)stream);
+  }
+  PM_REQUIRE_F32(x, "add"); PM_REQUIRE_F32(y, "add");
   const float *px = (const float*)x->ptr, *py = (const float*)y->ptr;
   float* po = (float*)o->ptr;
   const long a = x->pitch, b = y->pitch, c = o->pitch;
@@ -58,8 +64,10 @@ struct AddN {
 };
 extern "C" int pm_add_n(const pm_tensor* const* xs, int n, const pm_tensor* o, void* stream) {
   PM_REQUIRE(xs && o && n >= 2 && n <= 8, PM_EINVAL, "add_n: 2..8 operands");
+  if (pm_is_bf16(o)) return pm16_add_n(xs, n, o, (hipStream_t)stream);
   AddN a;
   for (int i = 0; i < n; ++i) {
+    PM_REQUIRE_F32(xs[i], "add_n");
     PM_REQUIRE(xs[i] && same_shape(xs[i], o) && vec4(xs[i]), PM_EINVAL, "add_n: operand %d: shape / float4 view mismatch", i);
     a.p[i] = (const float*)xs[i]->ptr, a.pitch[i] = xs[i]->pitch;
   }
@@ -78,6 +86,8 @@ extern "C" int pm_add_n(const pm_tensor* const* xs, int n, const pm_tensor* o, v
 
 extern "C" int pm_copy(const pm_tensor* x, const pm_tensor* o, void* stream) {
   PM_REQUIRE(x && o && same_shape(x, o), PM_EINVAL, "copy: shape mismatch");
+  if (pm_is_bf16(x) && pm_is_bf16(o)) return pm16_copy(x, o, (hipStream_t)stream);
+  PM_REQUIRE_F32(x, "copy"); PM_REQUIRE_F32(o, "copy");
   const float* px = (const float*)x->ptr;
   float* po = (float*)o->ptr;
   const long a = x->pitch, c = o->pitch;
@@ -91,6 +101,7 @@ extern "C" int pm_copy(const pm_tensor* x, const pm_tensor* o, void* stream) {
 extern "C" int pm_scale_shift_act(const pm_tensor* x, const float* scale, const float* shift, const pm_tensor* res, int relu,
                                   const pm_tensor* o, void* stream) {
   PM_REQUIRE(x && o && scale && shift && same_shape(x, o) && (!res || same_shape(x, res)), PM_EINVAL, "scale_shift_act: bad args");
+  PM_REQUIRE_F32(x, "scale_shift_act"); PM_REQUIRE_F32(o, "scale_shift_act"); PM_REQUIRE_F32(res, "scale_shift_act");
   const float *px = (const float*)x->ptr, *pr = res ? (const float*)res->ptr : nullptr;
   float* po = (float*)o->ptr;
   const long a = x->pitch, b = res ? res->pitch : 0, c = o->pitch;
@@ -153,6 +164,7 @@ __global__ void label_nearest_kernel(const int64_t* __restrict__ lab, int n, int
 
 extern "C" int pm_nchw_to_nhwc(const float* x, int c_src, const pm_tensor* y, void* stream) {
   PM_REQUIRE(x && y && y->ptr && c_src <= y->c, PM_EINVAL, "nchw_to_nhwc: bad args");
+  PM_REQUIRE_F32(y, "nchw_to_nhwc");
   const long P = (long)y->h * y->w;
   dim3 grid(pm_cdiv(P, 32), pm_cdiv(y->c, 32), y->n);
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, c_src, P, (float*)y->ptr, y->c, (long)y->pitch);
@@ -160,6 +172,7 @@ extern "C" int pm_nchw_to_nhwc(const float* x, int c_src, const pm_tensor* y, vo
 }
 extern "C" int pm_nhwc_to_nchw(const pm_tensor* x, float* y, void* stream) {
   PM_REQUIRE(x && y && x->ptr, PM_EINVAL, "nhwc_to_nchw: bad args");
+  PM_REQUIRE_F32(x, "nhwc_to_nchw");
   const long P = (long)x->h * x->w;
   dim3 grid(pm_cdiv(P, 32), pm_cdiv(x->c, 32), x->n);
   hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr, x->c, (long)x->pitch, P, y);

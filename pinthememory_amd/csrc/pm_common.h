@@ -34,6 +34,12 @@ static inline size_t pm_align_up(size_t v, size_t a) { return (v + a - 1) / a * 
 
 // Vectorisable NHWC view: base 16B-aligned, pitch % 4 == 0.
 static inline bool pm_vec_ok(const pm_tensor* t) { return pm_aligned16(t->ptr) && (t->pitch % 4) == 0; }
+static inline bool pm_is_f32(const pm_tensor* t) { return t->dtype == PM_F32; }
+static inline bool pm_is_bf16(const pm_tensor* t) { return t->dtype == PM_BF16; }
+// every fp32-only entry point starts with this: a bf16 tensor handed to a kernel that would read it as floats must fail loudly
+#define PM_REQUIRE_F32(t, who) PM_REQUIRE(!(t) || pm_is_f32(t), PM_EUNSUPPORTED, "%s: fp32 tensors only (got dtype %d)", who, (t)->dtype)
+// bf16 views move 16 bytes = 8 channels per lane: base 16B-aligned, pitch % 8 == 0, c % 8 == 0
+static inline bool pm_vec8(const pm_tensor* t) { return pm_is_bf16(t) && pm_aligned16(t->ptr) && (t->pitch % 8) == 0 && (t->c % 8) == 0; }
 
 // ---- Winograd F(m x m, 3x3) transforms, m = 2 / 4 (winograd.hip), driven by the conv entry points in conv_igemm.hip ------------
 struct pm_wino_geom {
@@ -56,7 +62,52 @@ int pm_bf16_cast_weights(const float* w, int Cout, int T, int Cin, int Cp, bool 
 int pm_bf16_transpose_taps(const float* x, long pitch, int C, int N, int H, int W, int Ho, int Wo, int kh, int kw, int stride, int pad, int dil, void* out,
                            hipStream_t st);
 
+// ---- bf16 activation tier (act16.hip): the bf16 forms of the elementwise / reduction entry points; the extern "C" functions dispatch on dtype ------
+typedef unsigned short pm_bf16;
+int pm16_bn_stats(const pm_tensor* x, float* moments, float eps, float* mean, float* invstd, float* running_mean, float* running_var, float momentum, void* ws,
+                  size_t ws_bytes, hipStream_t st);      // moments != NULL: mean | M2 | count ; else finalise
+size_t pm16_bn_workspace(const pm_tensor* x);
+int pm16_bn_apply_mask(const pm_tensor* x, const float* mean, const float* invstd, const float* gamma, const float* beta, const pm_tensor* res, int relu,
+                       const pm_tensor* y, uint8_t* mask, hipStream_t st);
+int pm16_bn_bwd_reduce(const pm_tensor* dy, const pm_tensor* y, const uint8_t* mask, const pm_tensor* x, const float* mean, const float* invstd, const float* gamma,
+                       const float* beta, int relu, const pm_tensor* gmask, float* sums, void* ws, size_t ws_bytes, hipStream_t st);
+int pm16_bn_bwd_apply(const pm_tensor* dy, const pm_tensor* y, const pm_tensor* x, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                      const float* sums, float count, int relu, const pm_tensor* dx, const pm_tensor* dres, hipStream_t st);
+int pm16_add_n(const pm_tensor* const* xs, int n, const pm_tensor* y, hipStream_t st);
+int pm16_copy(const pm_tensor* x, const pm_tensor* y, hipStream_t st);
+int pm16_maxpool_fwd(const pm_tensor* x, const pm_tensor* y, uint8_t* argmax, hipStream_t st);
+int pm16_maxpool_bwd(const pm_tensor* dy, const uint8_t* argmax, const pm_tensor* dx, hipStream_t st);
+int pm16_gap_fwd(const pm_tensor* x, const pm_tensor* y, hipStream_t st);
+int pm16_gap_bwd(const pm_tensor* dy, const pm_tensor* dx, int accumulate, hipStream_t st);
+int pm16_resize_fwd(const pm_tensor* x, const pm_tensor* y, hipStream_t st);
+int pm16_resize_bwd(const pm_tensor* dy, const pm_tensor* dx, int accumulate, hipStream_t st);
+size_t pm16_resize_bwd_workspace(const pm_tensor* dy, const pm_tensor* dx);
+int pm16_resize_bwd_separable(const pm_tensor* dy, const pm_tensor* dx, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+// dense conversions used by the convolution entry points for the few mixed-type call sites of the tier (fp32 logits / image next to bf16 activations)
+int pm16_to_f32(const pm_bf16* x, long pitch, int C, long P, float* out, long out_pitch, hipStream_t st);
+int pm16_pad_rows(const pm_bf16* x, long pitch, int C, int Cp, long P, pm_bf16* out, hipStream_t st);
+
 // ---- device helpers -------------------------------------------------------------------------------------------
+// eight bf16 channels (16 bytes) <-> eight floats. Round to nearest even on the way out (v_cvt_pk_bf16_f32).
+__device__ __forceinline__ void pm_ld8(const pm_bf16* p, float* v) {
+  const uint4 q = *reinterpret_cast<const uint4*>(p);
+  v[0] = __uint_as_float(q.x << 16), v[1] = __uint_as_float(q.x & 0xffff0000u), v[2] = __uint_as_float(q.y << 16), v[3] = __uint_as_float(q.y & 0xffff0000u);
+  v[4] = __uint_as_float(q.z << 16), v[5] = __uint_as_float(q.z & 0xffff0000u), v[6] = __uint_as_float(q.w << 16), v[7] = __uint_as_float(q.w & 0xffff0000u);
+}
+__device__ __forceinline__ unsigned pm_pack_bf16(float a, float b) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  bf16x2_t o;
+  o[0] = (__bf16)a, o[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, o);
+}
+__device__ __forceinline__ void pm_st8(pm_bf16* p, const float* v) {
+  uint4 q;
+  q.x = pm_pack_bf16(v[0], v[1]), q.y = pm_pack_bf16(v[2], v[3]), q.z = pm_pack_bf16(v[4], v[5]), q.w = pm_pack_bf16(v[6], v[7]);
+  *reinterpret_cast<uint4*>(p) = q;
+}
+__device__ __forceinline__ float pm_bf16_to_f32(pm_bf16 h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ pm_bf16 pm_f32_to_bf16(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+
 __device__ __forceinline__ float pm_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

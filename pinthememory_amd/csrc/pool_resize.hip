@@ -364,6 +364,8 @@ __global__ __launch_bounds__(256) void resize_bwd_rows_kernel(const float* __res
 extern "C" int pm_maxpool3x3s2_fwd(const pm_tensor* x, const pm_tensor* y, uint8_t* argmax, void* stream) {
   PM_REQUIRE(x && y && argmax && x->ptr && y->ptr, PM_EINVAL, "maxpool_fwd: null");
   PM_REQUIRE(y->h == (x->h + 2 - 3) / 2 + 1 && y->w == (x->w + 2 - 3) / 2 + 1 && x->n == y->n && x->c == y->c, PM_EINVAL, "maxpool_fwd: shape mismatch");
+  if (pm_is_bf16(x) && pm_is_bf16(y)) return pm16_maxpool_fwd(x, y, argmax, (hipStream_t)stream);
+  PM_REQUIRE_F32(x, "maxpool_fwd"); PM_REQUIRE_F32(y, "maxpool_fwd");
   const bool v = pm_vec4(x) && pm_vec4(y);
   const long total = pm_pixels(y) * (v ? y->c / 4 : y->c);
   if (v)
@@ -377,6 +379,8 @@ extern "C" int pm_maxpool3x3s2_fwd(const pm_tensor* x, const pm_tensor* y, uint8
 
 extern "C" int pm_maxpool3x3s2_bwd(const pm_tensor* dy, const uint8_t* argmax, const pm_tensor* dx, void* stream) {
   PM_REQUIRE(dy && dx && argmax && dy->ptr && dx->ptr && dy->n == dx->n && dy->c == dx->c, PM_EINVAL, "maxpool_bwd: bad args");
+  if (pm_is_bf16(dy) && pm_is_bf16(dx)) return pm16_maxpool_bwd(dy, argmax, dx, (hipStream_t)stream);
+  PM_REQUIRE_F32(dy, "maxpool_bwd"); PM_REQUIRE_F32(dx, "maxpool_bwd");
   const long total = pm_pixels(dx) * dx->c;
   if (pm_vec4(dy) && pm_vec4(dx) && (reinterpret_cast<uintptr_t>(argmax) & 3u) == 0)
     hipLaunchKernelGGL(maxpool_bwd_vec_kernel, dim3(grid_for(total / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)dy->ptr, (long)dy->pitch, dy->h, dy->w,
@@ -388,14 +392,20 @@ extern "C" int pm_maxpool3x3s2_bwd(const pm_tensor* dy, const uint8_t* argmax, c
 }
 
 extern "C" int pm_global_avgpool_fwd(const pm_tensor* x, const pm_tensor* y, void* stream) {
-  PM_REQUIRE(x && y && pm_vec4(x) && y->ptr && y->h == 1 && y->w == 1 && y->n == x->n && y->c == x->c, PM_EINVAL, "global_avgpool_fwd: bad args");
+  PM_REQUIRE(x && y && y->ptr && y->h == 1 && y->w == 1 && y->n == x->n && y->c == x->c, PM_EINVAL, "global_avgpool_fwd: bad args");
+  if (pm_is_bf16(x) && pm_is_bf16(y)) return pm16_gap_fwd(x, y, (hipStream_t)stream);
+  PM_REQUIRE_F32(x, "global_avgpool_fwd"); PM_REQUIRE_F32(y, "global_avgpool_fwd");
+  PM_REQUIRE(pm_vec4(x), PM_EINVAL, "global_avgpool_fwd: bad args");
   hipLaunchKernelGGL(gap_fwd_kernel, dim3(x->n, pm_cdiv(x->c, 64)), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr, (long)x->pitch,
                      (long)x->h * x->w, x->c, (float*)y->ptr, (long)y->pitch, 1.f / (float)((long)x->h * x->w), 0);
   return pm_check_launch("global_avgpool_fwd");
 }
 
 extern "C" int pm_global_avgpool_bwd(const pm_tensor* dy, const pm_tensor* dx, int accumulate, void* stream) {
-  PM_REQUIRE(dy && dx && dy->ptr && pm_vec4(dx) && dy->h == 1 && dy->w == 1 && dy->n == dx->n && dy->c == dx->c, PM_EINVAL, "global_avgpool_bwd: bad args");
+  PM_REQUIRE(dy && dx && dy->ptr && dy->h == 1 && dy->w == 1 && dy->n == dx->n && dy->c == dx->c, PM_EINVAL, "global_avgpool_bwd: bad args");
+  if (pm_is_bf16(dy) && pm_is_bf16(dx)) return pm16_gap_bwd(dy, dx, accumulate, (hipStream_t)stream);
+  PM_REQUIRE_F32(dy, "global_avgpool_bwd"); PM_REQUIRE_F32(dx, "global_avgpool_bwd");
+  PM_REQUIRE(pm_vec4(dx), PM_EINVAL, "global_avgpool_bwd: bad args");
   const float* pd = (const float*)dy->ptr;
   float* px = (float*)dx->ptr;
   const long dp = dy->pitch, xp = dx->pitch, HW = (long)dx->h * dx->w;
@@ -410,6 +420,8 @@ extern "C" int pm_global_avgpool_bwd(const pm_tensor* dy, const pm_tensor* dx, i
 
 extern "C" int pm_resize_bilinear_fwd(const pm_tensor* x, const pm_tensor* y, void* stream) {
   PM_REQUIRE(x && y && x->ptr && y->ptr && x->n == y->n && x->c == y->c, PM_EINVAL, "resize_fwd: bad args");
+  if (pm_is_bf16(x) && pm_is_bf16(y)) return pm16_resize_fwd(x, y, (hipStream_t)stream);
+  PM_REQUIRE_F32(x, "resize_fwd"); PM_REQUIRE_F32(y, "resize_fwd");
   // channel counts that are not a multiple of 4 (the 19 class logits) on pitch-padded views: run the float4 path over the padded
   // width -- the pad lanes of the input are zero (kernels.new), so the pad lanes of the output are written as zero
   const int cv = (x->c + 3) & ~3;
@@ -428,6 +440,8 @@ extern "C" int pm_resize_bilinear_fwd(const pm_tensor* x, const pm_tensor* y, vo
 
 extern "C" int pm_resize_bilinear_bwd(const pm_tensor* dy, const pm_tensor* dx, int accumulate, void* stream) {
   PM_REQUIRE(dy && dx && dy->ptr && dx->ptr && dy->n == dx->n && dy->c == dx->c, PM_EINVAL, "resize_bwd: bad args");
+  if (pm_is_bf16(dy) && pm_is_bf16(dx)) return pm16_resize_bwd(dy, dx, accumulate, (hipStream_t)stream);
+  PM_REQUIRE_F32(dy, "resize_bwd"); PM_REQUIRE_F32(dx, "resize_bwd");
   const bool v = pm_vec4(dy) && pm_vec4(dx);
   if (dx->h == 1 && dx->w == 1 && v) {  // 1x1 source (ASPP image feature): every output pixel has weight 1 -> a plain column sum
     hipLaunchKernelGGL(gap_fwd_kernel, dim3(dy->n, pm_cdiv(dy->c, 64)), dim3(256), 0, (hipStream_t)stream, (const float*)dy->ptr, (long)dy->pitch,
@@ -447,11 +461,14 @@ extern "C" int pm_resize_bilinear_bwd(const pm_tensor* dy, const pm_tensor* dx, 
 
 // workspace of the separable backward (0: shape not eligible -> use pm_resize_bilinear_bwd)
 extern "C" size_t pm_resize_bilinear_bwd_workspace(const pm_tensor* dy, const pm_tensor* dx) {
-  if (!dy || !dx || !pm_vec4(dy) || !pm_vec4(dx) || dx->h < 2 || dx->w < 2 || dy->h < 2 * dx->h || dy->w < 2 * dx->w) return 0;
+  if (dy && dx && pm_is_bf16(dy) && pm_is_bf16(dx)) return pm16_resize_bwd_workspace(dy, dx);
+  if (!dy || !dx || !pm_is_f32(dy) || !pm_is_f32(dx) || !pm_vec4(dy) || !pm_vec4(dx) || dx->h < 2 || dx->w < 2 || dy->h < 2 * dx->h || dy->w < 2 * dx->w) return 0;
   return pm_align_up((size_t)dy->n * dy->h * dx->w * dy->c * sizeof(float), 256);
 }
 extern "C" int pm_resize_bilinear_bwd_separable(const pm_tensor* dy, const pm_tensor* dx, int accumulate, void* ws, size_t ws_bytes, void* stream) {
   PM_REQUIRE(dy && dx && dy->ptr && dx->ptr && dy->n == dx->n && dy->c == dx->c, PM_EINVAL, "resize_bwd_separable: bad args");
+  if (pm_is_bf16(dy) && pm_is_bf16(dx)) return pm16_resize_bwd_separable(dy, dx, accumulate, ws, ws_bytes, (hipStream_t)stream);
+  PM_REQUIRE_F32(dy, "resize_bwd_separable"); PM_REQUIRE_F32(dx, "resize_bwd_separable");
   const size_t need = pm_resize_bilinear_bwd_workspace(dy, dx);
   PM_REQUIRE(need > 0, PM_EUNSUPPORTED, "resize_bwd_separable: needs 16-byte channel vectors and an up-sampling ratio >= 2 in both directions");
   PM_REQUIRE(ws && ws_bytes >= need, PM_EWORKSPACE, "resize_bwd_separable: workspace %zu < %zu", ws_bytes, need);
@@ -466,6 +483,7 @@ extern "C" int pm_resize_bilinear_bwd_separable(const pm_tensor* dy, const pm_te
 
 extern "C" int pm_resize_bilinear_hp_fwd(const pm_tensor* x, const pm_tensor* y, int flip_w, void* stream) {
   PM_REQUIRE(x && y && x->ptr && y->ptr && x->n == y->n && x->c == y->c, PM_EINVAL, "resize_hp_fwd: bad args");
+  PM_REQUIRE_F32(x, "resize_hp_fwd"); PM_REQUIRE_F32(y, "resize_hp_fwd");
   const long total = pm_pixels(y) * y->c;
   hipLaunchKernelGGL(resize_hp_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x->ptr, (long)x->pitch, x->h, x->w,
                      (float*)y->ptr, (long)y->pitch, y->h, y->w, y->c, total, (float)x->h / (float)y->h, (float)x->w / (float)y->w, flip_w);
@@ -473,6 +491,7 @@ extern "C" int pm_resize_bilinear_hp_fwd(const pm_tensor* x, const pm_tensor* y,
 }
 extern "C" int pm_softmax_mean_update(const pm_tensor* logits, double* buffer, int counter, void* stream) {
   PM_REQUIRE(logits && logits->ptr && buffer && counter >= 1 && logits->c >= 1 && logits->c <= 32, PM_EINVAL, "softmax_mean_update: bad args");
+  PM_REQUIRE_F32(logits, "softmax_mean_update");
   const long pixels = pm_pixels(logits);
   hipLaunchKernelGGL(softmax_mean_kernel, dim3(grid_for(pixels)), dim3(256), 0, (hipStream_t)stream, (const float*)logits->ptr, (long)logits->pitch, pixels,
                      logits->c, buffer, 1.0 / (double)counter);
@@ -513,6 +532,7 @@ extern "C" int pm_sliding_stitch(const pm_tensor* logits, const int32_t* tiles_x
                                  void* stream) {
   PM_REQUIRE(logits && logits->ptr && tiles_xyxy && acc && ntiles >= 1 && ntiles <= STITCH_MAX_TILES && logits->n == ntiles, PM_EINVAL,
              "sliding_stitch: bad args (1..%d tiles, logits->n == ntiles)", STITCH_MAX_TILES);
+  PM_REQUIRE_F32(logits, "sliding_stitch");
   StitchTiles t;
   t.n = ntiles;
   for (int i = 0; i < ntiles; ++i) {

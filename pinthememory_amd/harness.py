@@ -171,7 +171,7 @@ def memory_initialize(net, batches, epochs=2):
         for _ in range(epochs):
             for x, gt in batches:
                 feat = net(x, gts=gt, aux_gts=gt)[-1]
-                nomden = K.mem_write_accum(ops.nhwc(feat), gt.contiguous(), mem.memory_size, normalize=True)
+                nomden = K.mem_write_accum(K.cast(ops.nhwc(feat), torch.float32), gt.contiguous(), mem.memory_size, normalize=True)
                 acc = nomden if acc is None else acc + nomden
         acc = D.all_reduce_sum(acc)
         s, d = mem.memory_size, mem.feature_dim

@@ -19,22 +19,49 @@ def _lib():
 # layers, BatchNorm, losses and the memory stay fp32. 1: the first form of that tier (fp32 tiles staged in LDS, rounded per fragment), which
 # prec 2 falls back to for the call sites it does not cover (3-channel stem, 19-class heads, stride-2 data gradients).
 CONV_PREC = 0
+# Element type of the activations BETWEEN layers. 'bf16' (round 4) = the whole tier: convolutions write bf16, every elementwise / reduction kernel between them
+# (BatchNorm, pooling, resize, adds: csrc/act16.hip) reads and writes bf16 with fp32 arithmetic; the image, the class logits, the losses, the memory module,
+# every statistic and every parameter / parameter gradient stay fp32. 'bf16_operands' = round 2-3's form (fp32 activations, operands cast per convolution).
+ACT_DTYPE = torch.float32
 
 
 def set_conv_precision(name):
-    global CONV_PREC
-    CONV_PREC = {'f32': 0, 'fp32': 0, 'bf16': 2, 'bf16_staged': 1}[name]
+    global CONV_PREC, ACT_DTYPE
+    CONV_PREC = {'f32': 0, 'fp32': 0, 'bf16': 2, 'bf16_operands': 2, 'bf16_staged': 1}[name]
+    ACT_DTYPE = torch.bfloat16 if name == 'bf16' else torch.float32
 
 
-def new(shape, like, pitch_pad=False, zero_pad=True):
-    """Fresh NHWC tensor. Channel counts that are not a multiple of 4 (the 19 logits) get a padded pitch so rows stay 16B aligned;
-    the pad lanes are zero unless the producer writes them itself (zero_pad=False)."""
+def _act_dtype(like):
+    return like.dtype if like.dtype in (torch.float32, torch.bfloat16) else torch.float32
+
+
+def new(shape, like, pitch_pad=False, zero_pad=True, dtype=None):
+    """Fresh NHWC tensor of `dtype` (default: like.dtype). fp32: channel counts that are not a multiple of 4 (the 19 logits) get a padded pitch so rows
+    stay 16B aligned; the pad lanes are zero unless the producer writes them itself (zero_pad=False). bf16: a channel count that is not a multiple of 64
+    (the 48-channel skip branch, the 304-channel decoder gradient) is allocated with zero pad channels up to the next multiple and registered, so that a
+    convolution gathers it in place (lib.register_zero_pad)."""
     n, h, w, c = shape
+    dtype = _act_dtype(like) if dtype is None else dtype
+    if dtype == torch.bfloat16:
+        if c % 64:
+            base = torch.zeros((n, h, w, (c + 63) // 64 * 64), dtype=dtype, device=like.device)
+            L.register_zero_pad(base, c, base.shape[3])
+            return base[..., :c]
+        return torch.empty((n, h, w, c), dtype=dtype, device=like.device)
     if c % 4 and pitch_pad:
         cp = (c + 3) // 4 * 4
         alloc = torch.zeros if zero_pad else torch.empty
         return alloc((n, h, w, cp), dtype=torch.float32, device=like.device)[..., :c]
     return torch.empty((n, h, w, c), dtype=torch.float32, device=like.device)
+
+
+def cast(x, dtype):
+    """NHWC tensor -> the same values as `dtype` (fp32 <-> bf16, round to nearest even): the edges of the bf16 tier."""
+    if x.dtype == dtype:
+        return x
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    check(_lib().pm_cast(byref(tdesc(x)), byref(tdesc(y)), stream()), 'pm_cast')
+    return y
 
 
 def conv_out_hw(h, w, k, stride, pad, dil):
@@ -148,7 +175,7 @@ def _wino_u(lib, xd, yd, p, w_krsc):
     return None if valid else (ent, version)
 
 
-def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, residual=None, relu=False, out=None, keep_v=None, bn_partials=None):
+def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, residual=None, relu=False, out=None, keep_v=None, bn_partials=None, out_dtype=None):
     """keep_v: a list; if this convolution and its weight gradient both take the Winograd route, the transformed input V is written
     to a fresh tensor that is appended to the list (else None is appended) -- pass it to conv_bwd_weight(wino_v=...).
     bn_partials: a list; if this call can hand the train-mode BatchNorm statistics of its output out of its own epilogue ((mean, M2) per
@@ -157,7 +184,8 @@ def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, res
     n, h, w_, c = x.shape
     assert c == cin, 'conv: Cin mismatch %d vs %d' % (c, cin)
     ho, wo = conv_out_hw(h, w_, kh, stride, pad, dil)
-    y = out if out is not None else new((n, ho, wo, cout), x, pitch_pad=True)
+    y = out if out is not None else new((n, ho, wo, cout), x, pitch_pad=True, dtype=out_dtype if out_dtype is not None else ACT_DTYPE)
+    assert residual is None or residual.dtype == y.dtype, 'conv_fwd: the fused residual has the dtype of the output'
     xd, yd = tdesc(x), tdesc(y)
     p = L.conv_params(kh, kw, stride, pad, dil, CONV_PREC)
     lib = _lib()
@@ -191,9 +219,10 @@ def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, res
     return y
 
 
-def conv_bwd_data(dy, w_krsc, x_shape, stride, pad, dil, add=None):
+def conv_bwd_data(dy, w_krsc, x_shape, stride, pad, dil, add=None, dtype=None):
+    """dtype: element type of dx = the type of the tensor it is the gradient of (default: dy's)."""
     cout, kh, kw, cin = w_krsc.shape
-    dx = new(x_shape, dy)
+    dx = new(x_shape, dy, dtype=dtype)
     dyd, dxd = tdesc(dy), tdesc(dx)
     p = L.conv_params(kh, kw, stride, pad, dil, CONV_PREC)
     lib = _lib()
@@ -306,7 +335,8 @@ def bn_apply(x, mean, invstd, gamma, beta, residual=None, relu=False, out=None, 
     """want_mask: also -> uint8 [pixels, C / 4], bit e of a byte = output e of that float4 group is positive (the ReLU mask for bn_bwd_reduce_mask)."""
     y = out if out is not None else torch.empty_like(x, memory_format=torch.contiguous_format)
     rd = tdesc(residual) if residual is not None else None
-    mask = torch.empty((x.shape[0] * x.shape[1] * x.shape[2], x.shape[3] // 4), dtype=torch.uint8, device=x.device) if want_mask else None
+    grp = 8 if x.dtype == torch.bfloat16 else 4      # channels per mask byte = channels per 16-byte lane access
+    mask = torch.empty((x.shape[0] * x.shape[1] * x.shape[2], x.shape[3] // grp), dtype=torch.uint8, device=x.device) if want_mask else None
     check(_lib().pm_bn_apply_mask(byref(tdesc(x)), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), byref(rd) if rd else None,
                                   1 if relu else 0, byref(tdesc(y)), ptr(mask), stream()), 'pm_bn_apply_mask')
     return (y, mask) if want_mask else y
@@ -322,7 +352,7 @@ def bn_bwd_reduce_mask(dy, mask, x, mean, invstd, want_gmask=True, with_count=Fa
     lib = _lib()
     nb = lib.pm_bn_workspace(byref(xd))
     ws = workspace(nb, x.device)
-    gm = torch.empty(x.shape, dtype=torch.float32, device=x.device) if want_gmask else None
+    gm = torch.empty(x.shape, dtype=x.dtype, device=x.device) if want_gmask else None
     gd = tdesc(gm) if want_gmask else None
     check(lib.pm_bn_bwd_reduce_mask(byref(tdesc(dy)), mask.data_ptr(), byref(xd), mean.data_ptr(), invstd.data_ptr(), byref(gd) if gd else None,
                                     sums.data_ptr(), ptr(ws), nb, stream()), 'pm_bn_bwd_reduce_mask')
@@ -351,7 +381,7 @@ def bn_bwd_reduce(dy, y, x, mean, invstd, relu, gamma=None, beta=None, want_gmas
     nb = lib.pm_bn_workspace(byref(xd))
     ws = workspace(nb, x.device)
     yd = tdesc(y) if relu == 1 else None
-    gm = torch.empty(x.shape, dtype=torch.float32, device=x.device) if want_gmask else None
+    gm = torch.empty(x.shape, dtype=x.dtype, device=x.device) if want_gmask else None
     gd = tdesc(gm) if want_gmask else None
     check(lib.pm_bn_bwd_reduce(byref(tdesc(dy)), byref(yd) if yd else None, byref(xd), mean.data_ptr(), invstd.data_ptr(), ptr(gamma), ptr(beta), relu,
                                byref(gd) if gd else None, sums.data_ptr(), ptr(ws), nb, stream()), 'pm_bn_bwd_reduce')
@@ -360,8 +390,8 @@ def bn_bwd_reduce(dy, y, x, mean, invstd, relu, gamma=None, beta=None, want_gmas
 
 def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, count, relu, want_dres, beta=None):
     relu = int(relu)
-    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-    dres = torch.empty(x.shape, dtype=torch.float32, device=x.device) if want_dres else None
+    dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    dres = torch.empty(x.shape, dtype=x.dtype, device=x.device) if want_dres else None
     yd = tdesc(y) if relu == 1 else None
     dr = tdesc(dres) if want_dres else None
     check(_lib().pm_bn_bwd_apply(byref(tdesc(dy)), byref(yd) if yd else None, byref(tdesc(x)), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
@@ -381,13 +411,13 @@ def add_n(xs):
     from ctypes import POINTER, pointer
     descs = [tdesc(x) for x in xs]
     arr = (POINTER(PmTensor) * len(xs))(*[pointer(d) for d in descs])
-    y = torch.empty(xs[0].shape, dtype=torch.float32, device=xs[0].device)
+    y = torch.empty(xs[0].shape, dtype=xs[0].dtype, device=xs[0].device)
     check(_lib().pm_add_n(arr, len(xs), byref(tdesc(y)), stream()), 'pm_add_n')
     return y
 
 
 def add(a, b, out=None):
-    y = out if out is not None else torch.empty(a.shape, dtype=torch.float32, device=a.device)
+    y = out if out is not None else torch.empty(a.shape, dtype=a.dtype, device=a.device)
     check(_lib().pm_add(byref(tdesc(a)), byref(tdesc(b)), byref(tdesc(y)), stream()), 'pm_add')
     return y
 
@@ -400,27 +430,27 @@ def copy(src, dst):
 # ---- pooling / resize / layout -------------------------------------------------------------------------------------
 def maxpool_fwd(x):
     n, h, w, c = x.shape
-    y = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), dtype=torch.float32, device=x.device)
+    y = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), dtype=x.dtype, device=x.device)
     arg = torch.empty(y.shape, dtype=torch.uint8, device=x.device)
     check(_lib().pm_maxpool3x3s2_fwd(byref(tdesc(x)), byref(tdesc(y)), arg.data_ptr(), stream()), 'pm_maxpool3x3s2_fwd')
     return y, arg
 
 
 def maxpool_bwd(dy, arg, x_shape):
-    dx = torch.empty(x_shape, dtype=torch.float32, device=dy.device)
+    dx = torch.empty(x_shape, dtype=dy.dtype, device=dy.device)
     check(_lib().pm_maxpool3x3s2_bwd(byref(tdesc(dy)), arg.data_ptr(), byref(tdesc(dx)), stream()), 'pm_maxpool3x3s2_bwd')
     return dx
 
 
 def global_avgpool_fwd(x):
     n, h, w, c = x.shape
-    y = torch.empty((n, 1, 1, c), dtype=torch.float32, device=x.device)
+    y = torch.empty((n, 1, 1, c), dtype=x.dtype, device=x.device)
     check(_lib().pm_global_avgpool_fwd(byref(tdesc(x)), byref(tdesc(y)), stream()), 'pm_global_avgpool_fwd')
     return y
 
 
 def global_avgpool_bwd(dy, x_shape):
-    dx = torch.empty(x_shape, dtype=torch.float32, device=dy.device)
+    dx = torch.empty(x_shape, dtype=dy.dtype, device=dy.device)
     check(_lib().pm_global_avgpool_bwd(byref(tdesc(dy)), byref(tdesc(dx)), 0, stream()), 'pm_global_avgpool_bwd')
     return dx
 

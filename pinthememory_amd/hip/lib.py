@@ -11,7 +11,11 @@ LIB_PATH = os.environ.get('PM_LIB') or os.path.join(_HERE, 'libpinmem_hip.so')  
 
 
 class PmTensor(ctypes.Structure):
-    _fields_ = [('ptr', c_void_p), ('n', c_int32), ('h', c_int32), ('w', c_int32), ('c', c_int32), ('pitch', c_int64)]
+    _fields_ = [('ptr', c_void_p), ('n', c_int32), ('h', c_int32), ('w', c_int32), ('c', c_int32), ('pitch', c_int64), ('dtype', c_int32), ('flags', c_int32)]
+
+
+PM_F32, PM_BF16 = 0, 1          # include/pinmem_hip.h pm_dtype
+PM_TF_ZERO_PAD64 = 1            # pm_tensor.flags
 
 
 class PmSgdEntry(ctypes.Structure):
@@ -37,7 +41,7 @@ def conv_epilogue(*fields):
     return PmConvEpilogue(ctypes.sizeof(PmConvEpilogue), *fields)
 
 
-ABI_VERSION = 300          # include/pinmem_hip.h PM_ABI_VERSION this binding was written against
+ABI_VERSION = 400          # include/pinmem_hip.h PM_ABI_VERSION this binding was written against
 
 
 class PinmemError(RuntimeError):
@@ -120,6 +124,7 @@ SIGNATURES = {
     'pm_conv_bn_partials_bytes': (_sz, [_T, _T, POINTER(PmConvParams)]),
     'pm_bn_partials_finalize': (_i, [_vp, _i64, _i, _f, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
     'pm_sgd_momentum_multi': (_i, [_vp, _i, _f, _f, _f, _vp]),
+    'pm_cast': (_i, [_T, _T, _vp]),
 }
 
 _lib = None
@@ -152,9 +157,23 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# bf16 tensors allocated with zero-filled pad channels up to a multiple of 64 (kernels.new / ops.concat_buffer): base pointer -> (weakref(base), c, pitch).
+# A convolution then gathers such an input in place (PM_TF_ZERO_PAD64) instead of copying it to a padded buffer. A view keeps its base alive (`_base`),
+# so a dead weak reference means the memory may belong to somebody else: the promise is withdrawn.
+_ZERO_PAD = {}
+
+
+def register_zero_pad(base, c, pitch):
+    import weakref
+    if len(_ZERO_PAD) > 64:
+        for k in [k for k, v in _ZERO_PAD.items() if v[0]() is None]:
+            del _ZERO_PAD[k]
+    _ZERO_PAD[base.data_ptr()] = (weakref.ref(base), c, pitch)
+
+
 def tdesc(t):
-    """pm_tensor view of a torch tensor shaped [N,H,W,C] (channels innermost; may be a channel slice of a wider buffer)."""
-    assert t.dim() == 4 and t.dtype == torch.float32 and t.is_cuda, 'expected a CUDA fp32 NHWC tensor, got %s %s' % (tuple(t.shape), t.dtype)
+    """pm_tensor view of a torch tensor shaped [N,H,W,C] (channels innermost; may be a channel slice of a wider buffer); fp32 or bf16."""
+    assert t.dim() == 4 and t.dtype in (torch.float32, torch.bfloat16) and t.is_cuda, 'expected a CUDA fp32 / bf16 NHWC tensor, got %s %s' % (tuple(t.shape), t.dtype)
     n, h, w, c = t.shape
     sn, sh, sw, sc = t.stride()
     # size-1 dims carry arbitrary strides in torch: take the pixel pitch from the innermost spatial dim that is > 1
@@ -162,7 +181,14 @@ def tdesc(t):
     assert (sc == 1 or c == 1) and pitch >= c, 'channels must be innermost: shape %s stride %s' % (tuple(t.shape), t.stride())
     assert (h == 1 or w == 1 or sh == w * pitch) and (n == 1 or h * w == 1 or sn == h * w * pitch), \
         'not an NHWC view: shape %s stride %s' % (tuple(t.shape), t.stride())
-    return PmTensor(t.data_ptr(), n, h, w, c, pitch)
+    if t.dtype == torch.float32:
+        return PmTensor(t.data_ptr(), n, h, w, c, pitch, PM_F32, 0)
+    flags = 0
+    if c % 64:
+        z = _ZERO_PAD.get(t.data_ptr())
+        if z is not None and z[0]() is not None and z[1] == c and z[2] == pitch:
+            flags = PM_TF_ZERO_PAD64
+    return PmTensor(t.data_ptr(), n, h, w, c, pitch, PM_BF16, flags)
 
 
 _ws = {}

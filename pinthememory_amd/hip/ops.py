@@ -20,6 +20,10 @@ def nhwc(t):
     ok = (sc == 1 or c == 1) and pitch >= c and (h == 1 or w == 1 or sh == w * pitch) and (n == 1 or h * w == 1 or sn == h * w * pitch)
     if ok and v.dtype == torch.float32:
         return v
+    if v.dtype == torch.bfloat16:      # the bf16 tier's activations (K.ACT_DTYPE): 16-byte rows of eight channels
+        if ok and pitch % 8 == 0 and c % 8 == 0 and v.data_ptr() % 16 == 0:
+            return v
+        return v.contiguous()
     if h * w == 1:
         return v.contiguous().float()
     return K.nchw_to_nhwc(t.float())
@@ -32,7 +36,7 @@ def nchw(v):
 def _grad_view(g):
     """Incoming gradient (logical NCHW, arbitrary strides) -> NHWC view with 16B-aligned rows."""
     v = nhwc(g)
-    if v.stride(2) % 4 or v.data_ptr() % 16:
+    if v.stride(2) % (8 if v.dtype == torch.bfloat16 else 4) or v.data_ptr() % 16:
         v = v.contiguous()
     return v
 
@@ -361,7 +365,7 @@ class _ConvBnAct(torch.autograd.Function):
             g = dv if g is None else g
             dy = K.scale_shift_act(g, gamma * invstd, torch.zeros_like(gamma))
             dres, dgamma, dbeta = (g if want_dres else None), sums[c:], sums[:c]
-        dx = nchw(K.conv_bwd_data(dy, wk, tuple(xv.shape), stride, pad, dil)) if ctx.needs_input_grad[0] else None
+        dx = nchw(K.conv_bwd_data(dy, wk, tuple(xv.shape), stride, pad, dil, dtype=xv.dtype)) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dwk, db = _wgrad(xv, dy, tuple(wk.shape), (stride, pad, dil), want_bias=ctx.has_bias, deferred=ctx.deferred, wino_v=vk)
@@ -376,7 +380,7 @@ class _Conv(torch.autograd.Function):
     def forward(ctx, x, w, bias, geom):
         stride, pad, dil = geom
         xv, wk = nhwc(x), K.krsc(w)
-        y = K.conv_fwd(xv, wk, stride, pad, dil, bias=bias)
+        y = K.conv_fwd(xv, wk, stride, pad, dil, bias=bias, out_dtype=torch.float32)      # the class logits (and every other un-normalised head) stay fp32 on the bf16 tier
         ctx.geom, ctx.has_bias = geom, bias is not None
         ctx.save_for_backward(xv, wk)
         return nchw(y)
@@ -386,7 +390,7 @@ class _Conv(torch.autograd.Function):
         xv, wk = ctx.saved_tensors
         stride, pad, dil = ctx.geom
         dv = _grad_view(dout)
-        dx = nchw(K.conv_bwd_data(dv, wk, tuple(xv.shape), stride, pad, dil)) if ctx.needs_input_grad[0] else None
+        dx = nchw(K.conv_bwd_data(dv, wk, tuple(xv.shape), stride, pad, dil, dtype=xv.dtype)) if ctx.needs_input_grad[0] else None
         dwk, db = _wgrad(xv, dv, tuple(wk.shape), (stride, pad, dil), want_bias=ctx.has_bias)
         return dx, dwk.permute(0, 3, 1, 2), db, None
 
@@ -620,9 +624,9 @@ def resize(x, size, out=None):
 
 
 def concat_buffer(like, channels, hw):
-    """Logical-NCHW [B, sum(channels), h, w] buffer (NHWC memory) for branches to write into."""
-    buf = torch.empty((like.shape[0], hw[0], hw[1], sum(channels)), dtype=torch.float32, device=like.device)
-    return nchw(buf)
+    """Logical-NCHW [B, sum(channels), h, w] buffer (NHWC memory) for branches to write into, of the dtype of `like` (bf16 on the bf16 tier: a channel
+    total that is not a multiple of 64 -- the decoder's 48 + 256 -- comes with zero pad channels, K.new)."""
+    return nchw(K.new((like.shape[0], hw[0], hw[1], sum(channels)), like, dtype=like.dtype if like.dtype == torch.bfloat16 else torch.float32))
 
 
 def concat(buf, parts):
@@ -631,6 +635,23 @@ def concat(buf, parts):
 
 def add(a, b):
     return _Add.apply(a, b)
+
+
+class _Cast(torch.autograd.Function):
+    """fp32 <-> bf16 at the edges of the bf16 tier (the memory module and the losses stay fp32): one conversion kernel each way."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return nchw(K.cast(nhwc(x), dtype))
+
+    @staticmethod
+    def backward(ctx, g):
+        return nchw(K.cast(_grad_view(g), ctx.src)), None
+
+
+def cast(x, dtype):
+    return x if x.dtype == dtype else _Cast.apply(x, dtype)
 
 
 def upsample_ce(logits, labels, inv_temp=1.0):

@@ -148,7 +148,7 @@ class Memory_sup(nn.Module):
     def get_score(self, query, mask, mem):            # memory.py:167-189; query NHWC, normalised by the caller
         bs, h, w, d = query.size()
         g0, g1 = self._gumbel(bs * h * w, query.device)
-        _, score, pmem = ops.mem_read(query.permute(0, 3, 1, 2), mem, g1)
+        _, score, pmem = ops.mem_read(ops.cast(query.permute(0, 3, 1, 2), torch.float32), mem, g1)
         readloss = ops.upsample_ce(score.permute(0, 3, 1, 2), mask, 1.0 / self.temperature) if mask is not None else 0
         pq = K.mem_colsoftmax(score.detach().reshape(bs * h * w, -1), g0)
         return pq, pmem.reshape(bs * h * w, -1), readloss
@@ -161,7 +161,7 @@ class Memory_sup(nn.Module):
             self.m_items = mem = mem.detach()
         self.last_read = mem.detach()
         g0, g1 = self._gumbel(b * h * w, query.device)
-        qr, score, pmem = ops.mem_read(query, mem, g1)
+        qr, score, pmem = ops.mem_read(ops.cast(query, torch.float32), mem, g1)      # the memory works in fp32 (a no-op off the bf16 tier)
         readloss = ops.upsample_ce(score.permute(0, 3, 1, 2), mask, 1.0 / self.temperature) if mask is not None else 0
         pq = K.mem_colsoftmax(score.detach().reshape(b * h * w, -1), g0).view(b, h, w, self.memory_size)
         updated_query = ops.conv_bn_act(qr, self.output[0], self.output[1], relu=True)
@@ -171,7 +171,7 @@ class Memory_sup(nn.Module):
         self.finish_commit()
         mem = self._mem(input)
         z = self.writenet(input)
-        nomden = ops.mem_write_accum(z, mask, self.memory_size)
+        nomden = ops.mem_write_accum(ops.cast(z, torch.float32), mask, self.memory_size)
         if self.defer_sync and D.SYNC_MEMORY and D.is_dist() and not torch.is_grad_enabled():
             _DEFERRED[self] = (mem.detach(), nomden)      # finished by the next reader of m_items, on its stream
             return [0, 0]

@@ -640,7 +640,7 @@ BF16_CASES = [CONV_CASES[1], CONV_CASES[3], CONV_CASES[5], CONV_CASES[8], CONV_C
               (1, 512, 12, 12, 512, 3, 1, 2, 2, False)]
 
 
-@pytest.mark.parametrize('form', ['bf16', 'bf16_staged', 'bf16+wgrad'])
+@pytest.mark.parametrize('form', ['bf16_operands', 'bf16_staged', 'bf16_operands+wgrad'])
 @pytest.mark.parametrize('case', BF16_CASES)
 def test_conv_bf16_operands(K, case, form):
     """BASELINE configs[2]: operands rounded to bf16 (RNE) feeding v_mfma_f32_32x32x16_bf16, fp32 accumulation -- the bf16-operand form
@@ -674,6 +674,218 @@ def test_conv_bf16_operands(K, case, form):
     w2 = wt.clone().requires_grad_(True)
     F.conv2d(r16(x), w2, None, stride=s, padding=p, dilation=d).backward(r16(dy))
     assert rel(dw.permute(0, 3, 1, 2), w2.grad) < 2e-4
+
+
+# ---- BASELINE configs[2], round 4: bf16 ACTIVATIONS (pm_tensor.dtype == PM_BF16) ------------------------------------------------------------------
+def b16(t):
+    """logical NCHW fp32 (CPU) -> NHWC bf16 on the GPU"""
+    return t.permute(0, 2, 3, 1).contiguous().cuda().bfloat16()
+
+
+def close16(got, want, ulps=1.0):
+    """bf16 result vs an fp32 reference of the same formula on the same (bf16) inputs: equal up to `ulps` bf16 roundings of the reference (2^-8 relative:
+    the reference may sit on a rounding boundary), plus the same slack relative to the tensor's scale for values that cancel to ~0."""
+    g, w = got.float().cpu().double(), want.float().cpu().double()
+    tol = ulps * 2.0 ** -8 * w.abs() + ulps * 2.0 ** -9 * w.abs().max() * 1e-2 + 1e-30
+    bad = (g - w).abs() > tol
+    assert not bad.any(), 'max |err| %.3e at ref %.3e (scale %.3e), %d of %d off' % ((g - w).abs().max().item(), w[bad][0].item(), w.abs().max().item(), int(bad.sum()), bad.numel())
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 24, 20), (3, 48, 9, 11), (2, 256, 12, 12), (1, 1280, 6, 6), (2, 128, 1, 1)])
+def test_act16_batchnorm(K, shape):
+    """csrc/act16.hip: train-mode BatchNorm forward / backward on bf16 activations (fp32 statistics) against the fp32 formulas evaluated on the same bf16
+    values: statistics to fp32 round-off, bf16 outputs to one rounding; ReLU masks from the forward output, rebuilt from x, and from the mask bytes."""
+    n, c, h, w = shape
+    x = rnd(n, c, h, w, seed=1).bfloat16().float() * 2 + 0.5
+    res = rnd(n, c, h, w, seed=2).bfloat16().float()
+    dy = rnd(n, c, h, w, seed=3).bfloat16().float()
+    gamma, beta = rnd(c, seed=4) * 0.2 + 1.0, rnd(c, seed=5) * 0.1
+    x16, res16, dy16 = b16(x), b16(res), b16(dy)
+    rm, rv = torch.zeros(c, device='cuda'), torch.ones(c, device='cuda')
+    mean, invstd = K.bn_stats_finalize(x16, 1e-5, rm, rv, 0.1)
+    xd = x.double()
+    m_ref, v_ref = xd.mean((0, 2, 3)), xd.var((0, 2, 3), unbiased=False)
+    assert rel(mean, m_ref) < 1e-6 and rel(invstd, 1.0 / torch.sqrt(v_ref + 1e-5)) < 1e-5
+    assert rel(rm, 0.1 * m_ref) < 1e-5
+    mom = K.bn_stats(x16)
+    assert rel(mom[:c], m_ref) < 1e-6 and rel(mom[c:2 * c], v_ref * (n * h * w)) < 1e-5 and (mom[2 * c:] == n * h * w).all()
+    mu, isd = mean.cpu(), invstd.cpu()
+    bc = lambda t: t[None, :, None, None]
+    aff = (x - bc(mu)) * bc(isd) * bc(gamma) + bc(beta)
+    # forward: plain, ReLU, residual + ReLU (+ mask bytes)
+    o0 = K.bn_apply(x16, mean, invstd, gamma.cuda(), beta.cuda())
+    close16(nchw(o0.float()), aff)
+    o2 = K.bn_apply(x16, mean, invstd, gamma.cuda(), beta.cuda(), relu=True)
+    close16(nchw(o2.float()), aff.clamp_min(0))
+    o1, mask = K.bn_apply(x16, mean, invstd, gamma.cuda(), beta.cuda(), residual=res16, relu=True, want_mask=True)
+    pre = aff + res
+    close16(nchw(o1.float()), pre.clamp_min(0))
+    assert tuple(mask.shape) == (n * h * w, c // 8)
+    # backward reduce: the three mask sources agree with the fp32 formula wherever the pre-activation is not within rounding of zero
+    xhat = (x - bc(mu)) * bc(isd)
+    for mode, fwd_out, m in ((0, None, None), (2, None, None), (1, o1, None), (3, None, mask)):
+        if mode == 3:
+            sums, gm = K.bn_bwd_reduce_mask(dy16, m, x16, mean, invstd, want_gmask=True)
+            keep = pre > 0
+        else:
+            sums, gm = K.bn_bwd_reduce(dy16, fwd_out, x16, mean, invstd, mode, gamma.cuda(), beta.cuda(), want_gmask=mode != 0)
+            keep = torch.ones_like(dy, dtype=torch.bool) if mode == 0 else (aff > 0 if mode == 2 else nchw(o1.float()) > 0)
+        g = dy * keep
+        ref_s = torch.cat([g.sum((0, 2, 3)), (g * xhat).sum((0, 2, 3))])
+        edge = (aff.abs() < 1e-2) | (pre.abs() < 1e-2)                       # units whose sign the two evaluations may see differently
+        slack = (dy.abs() * edge).sum((0, 2, 3))
+        slack = torch.cat([slack, slack * xhat.abs().amax((0, 2, 3))]) + 1e-4 * ref_s.abs().max()
+        assert ((sums.cpu() - ref_s).abs() <= slack + 1e-5 * ref_s.abs()).all(), mode
+        if gm is not None:
+            ok = ~edge
+            assert torch.equal(nchw(gm.float())[ok], g[ok]), mode
+    # backward apply (relu 0, the masked gradient as input): dx = gamma invstd (g - s1 / n - xhat s2 / n)
+    sums, _ = K.bn_bwd_reduce(dy16, None, x16, mean, invstd, 0)
+    cnt = float(n * h * w)
+    dx, _ = K.bn_bwd_apply(dy16, None, x16, mean, invstd, gamma.cuda(), sums, cnt, 0, False)
+    s1, s2 = sums[:c].cpu(), sums[c:].cpu()
+    ref_dx = (dy - bc(s1) / cnt - xhat * bc(s2) / cnt) * bc(isd * gamma)
+    close16(nchw(dx.float()), ref_dx, ulps=2.0)
+    dx2, dres = K.bn_bwd_apply(dy16, o1, x16, mean, invstd, gamma.cuda(), sums, cnt, 1, True)
+    assert dres.dtype == torch.bfloat16 and torch.equal(nchw(dres.float()), dy * (nchw(o1.float()) > 0))
+
+
+def test_act16_pool_resize_add_cast(K):
+    """csrc/act16.hip against the fp32 kernels of the library (themselves tested against torch above) on the widened inputs: identical arithmetic, so
+    the bf16 outputs are the fp32 results rounded once."""
+    x = rnd(2, 64, 23, 19, seed=1).bfloat16().float()
+    x16, x32 = b16(x), nhwc(x)
+    assert torch.equal(K.cast(x16, torch.float32), x32) and torch.equal(K.cast(x32, torch.bfloat16), x16)
+    odd = nhwc(rnd(2, 19, 5, 7, seed=9))
+    assert torch.equal(K.cast(odd, torch.bfloat16).float(), odd.bfloat16().float())
+    # max pool
+    y16, a16 = K.maxpool_fwd(x16)
+    y32, a32 = K.maxpool_fwd(x32)
+    assert torch.equal(y16.float(), y32) and torch.equal(a16, a32)
+    dy = rnd(*nchw(y32).shape, seed=2).bfloat16().float()
+    close16(K.maxpool_bwd(b16(dy), a16, tuple(x16.shape)).float(), K.maxpool_bwd(nhwc(dy), a32, tuple(x32.shape)))
+    # global average pool (+ backward), 1x1-source resize backward (a column sum)
+    close16(K.global_avgpool_fwd(x16).float(), K.global_avgpool_fwd(x32))
+    g = rnd(2, 64, 1, 1, seed=3).bfloat16().float()
+    close16(K.global_avgpool_bwd(b16(g), tuple(x16.shape)).float(), K.global_avgpool_bwd(nhwc(g), tuple(x32.shape)))
+    close16(K.resize_bwd(x16, (2, 1, 1, 64)).float(), K.resize_bwd(x32, (2, 1, 1, 64)), ulps=2.0)
+    # bilinear resize forward, backward (gather and separable), into a channel slice of a wider buffer
+    up16, up32 = K.resize_fwd(x16, (47, 41)), K.resize_fwd(x32, (47, 41))
+    close16(up16.float(), up32)
+    buf = torch.zeros(2, 47, 41, 128, device='cuda', dtype=torch.bfloat16)
+    K.resize_fwd(x16, (47, 41), out=buf[..., 64:])
+    assert torch.equal(buf[..., 64:], up16) and buf[..., :64].abs().max().item() == 0
+    du = rnd(2, 64, 47, 41, seed=4).bfloat16().float()
+    for sep in (False, True):
+        close16(K.resize_bwd(b16(du), tuple(x16.shape), separable=sep).float(), K.resize_bwd(nhwc(du), tuple(x32.shape), separable=sep), ulps=2.0)
+    # n-ary add, copy
+    ts = [rnd(2, 64, 23, 19, seed=10 + i).bfloat16().float() for i in range(5)]
+    close16(K.add_n([b16(t) for t in ts]).float(), K.add_n([nhwc(t) for t in ts]))
+    close16(K.add(b16(ts[0]), b16(ts[1])).float(), K.add(nhwc(ts[0]), nhwc(ts[1])))
+    dst = torch.zeros_like(buf)
+    K.copy(x16, dst[:, :23, :19, 32:96])
+    assert torch.equal(dst[:, :23, :19, 32:96], x16)
+
+
+ACT16_CASES = [CONV_CASES[0], CONV_CASES[1], CONV_CASES[3], CONV_CASES[4], CONV_CASES[5], CONV_CASES[10], CONV_CASES[11], CONV_CASES[12],
+               (2, 256, 24, 24, 128, 3, 1, 6, 6, False),        # dilated 3x3
+               (1, 1280, 16, 16, 256, 1, 1, 0, 1, False),       # bot_aspp: long K
+               (2, 256, 20, 20, 48, 1, 1, 0, 1, False),         # bot_fine: 48 output channels (weight-gradient rows beyond Cout, dgrad of a 48-channel dy)
+               (1, 1024, 12, 12, 512, 3, 1, 1, 1, True),        # dsn.0: bias + bias gradient over a bf16 dy
+               (1, 512, 12, 12, 512, 3, 1, 2, 2, False)]
+
+
+@pytest.mark.parametrize('case', ACT16_CASES)
+def test_conv_bf16_activations(K, case):
+    """BASELINE configs[2], round 4: bf16 tensors in, bf16 tensors out (x, y, dy, dx), fp32 weights / dw, fp32 accumulation. Oracle: the fp32 convolution of
+    the bf16-rounded operands; outputs agree to one bf16 rounding, dw to fp32 accumulation order."""
+    n, cin, h, w, cout, k, s, p, d, has_bias = case
+    r16 = lambda t: t.bfloat16().float()
+    x, wt = r16(rnd(n, cin, h, w, seed=1)), rnd(cout, cin, k, k, seed=2, scale=(2.0 / (cin * k * k)) ** 0.5)
+    b = rnd(cout, seed=3) if has_bias else None
+    y_ref = F.conv2d(x, r16(wt), b, stride=s, padding=p, dilation=d)
+    dy = r16(rnd(*y_ref.shape, seed=4))
+    skip = r16(rnd(n, cin, h, w, seed=5))
+    K.set_conv_precision('bf16')
+    try:
+        wg = wt.permute(0, 2, 3, 1).contiguous().cuda()
+        xg = K.new((n, h, w, cin), wg, dtype=torch.bfloat16)      # zero-padded + registered when cin % 64 != 0 (304): gathered in place
+        xg.copy_(b16(x))
+        y = K.conv_fwd(xg, wg, s, p, d, bias=b.cuda() if has_bias else None)
+        assert y.dtype == torch.bfloat16
+        close16(nchw(y.float()), y_ref, ulps=1.5)
+        dyg = K.new(tuple(y.shape), y)
+        dyg.copy_(b16(dy))
+        dx = K.conv_bwd_data(dyg, wg, tuple(xg.shape), s, p, d, add=b16(skip))
+        dw, db = K.conv_bwd_weight(xg, dyg, tuple(wg.shape), s, p, d, want_bias=has_bias)
+        # the same through tensors WITHOUT the zero-pad promise (dense 48 / 304-channel rows: copied to a padded buffer by the library)
+        if cin % 64 or cout % 64:
+            y2 = K.conv_fwd(b16(x), wg, s, p, d, bias=b.cuda() if has_bias else None)
+            dx2 = K.conv_bwd_data(b16(dy), wg, tuple(xg.shape), s, p, d, add=b16(skip))
+            assert torch.equal(y2, y) and torch.equal(dx2, dx)
+    finally:
+        K.set_conv_precision('f32')
+    x2 = x.clone().requires_grad_(True)
+    F.conv2d(x2, r16(wt), None, stride=s, padding=p, dilation=d).backward(dy)
+    assert dx.dtype == torch.bfloat16
+    close16(nchw(dx.float()), x2.grad + skip, ulps=1.5)
+    w2 = wt.clone().requires_grad_(True)
+    b2 = b.clone().requires_grad_(True) if has_bias else None
+    F.conv2d(x, w2, b2, stride=s, padding=p, dilation=d).backward(dy)
+    assert dw.dtype == torch.float32 and rel(dw.permute(0, 3, 1, 2), w2.grad) < 2e-4
+    if has_bias:
+        assert rel(db, b2.grad) < 2e-5
+
+
+def test_conv_bf16_tier_mixed_edges(K):
+    """The mixed-type call sites of the tier: the stem (fp32 NHWC4 image -> bf16, weight gradient from a bf16 dy), a 19-class head (bf16 -> fp32 logits with
+    bias, fp32 dy -> bf16 dx, weight / bias gradient), a stride-2 3x3 and a stride-2 1x1 data gradient (bf16 dy -> bf16 dx + bf16 skip)."""
+    r16 = lambda t: t.bfloat16().float()
+    K.set_conv_precision('bf16')
+    try:
+        # stem
+        x, wt = rnd(2, 4, 40, 36, seed=1), rnd(64, 4, 7, 7, seed=2, scale=0.1)
+        x[:, 3] = 0
+        wg = wt.permute(0, 2, 3, 1).contiguous().cuda()
+        y = K.conv_fwd(nhwc(x), wg, 2, 3, 1)
+        y_ref = F.conv2d(r16(x), r16(wt), None, stride=2, padding=3)
+        assert y.dtype == torch.bfloat16
+        close16(nchw(y.float()), y_ref, ulps=1.5)
+        dy = r16(rnd(*y_ref.shape, seed=3))
+        dw, _ = K.conv_bwd_weight(nhwc(x), b16(dy), tuple(wg.shape), 2, 3, 1)
+        w2 = wt.clone().requires_grad_(True)
+        F.conv2d(r16(x), w2, None, stride=2, padding=3).backward(dy)
+        assert rel(dw.permute(0, 3, 1, 2), w2.grad) < 2e-4
+        # class head
+        x, wt, b = r16(rnd(2, 256, 16, 16, seed=4)), rnd(19, 256, 1, 1, seed=5, scale=0.06), rnd(19, seed=6)
+        wg = wt.permute(0, 2, 3, 1).contiguous().cuda()
+        y = K.conv_fwd(b16(x), wg, 1, 0, 1, bias=b.cuda(), out_dtype=torch.float32)
+        assert y.dtype == torch.float32 and rel(nchw(y), F.conv2d(x, r16(wt), b)) < 1e-4
+        dy = rnd(2, 19, 16, 16, seed=7)
+        dyg = K.new(tuple(y.shape), y, pitch_pad=True)
+        dyg.copy_(nhwc(dy))
+        dx = K.conv_bwd_data(dyg, wg, (2, 16, 16, 256), 1, 0, 1, dtype=torch.bfloat16)
+        x2 = x.clone().requires_grad_(True)
+        F.conv2d(x2, r16(wt), None).backward(r16(dy))
+        assert dx.dtype == torch.bfloat16
+        close16(nchw(dx.float()), x2.grad, ulps=1.5)
+        dw, db = K.conv_bwd_weight(b16(x), dyg, tuple(wg.shape), 1, 0, 1, want_bias=True)
+        w2, b2 = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        F.conv2d(x, w2, b2).backward(r16(dy))
+        assert rel(dw.permute(0, 3, 1, 2), w2.grad) < 2e-4 and rel(db, dy.sum((0, 2, 3))) < 2e-5
+        # stride-2 data gradients
+        for cin, cout, k, p in ((128, 128, 3, 1), (256, 512, 1, 0)):
+            wt = rnd(cout, cin, k, k, seed=8, scale=(2.0 / (cin * k * k)) ** 0.5)
+            wg = wt.permute(0, 2, 3, 1).contiguous().cuda()
+            x2 = torch.zeros(2, cin, 24, 24, requires_grad=True)
+            yr = F.conv2d(x2, r16(wt), None, stride=2, padding=p)
+            dy, skip = r16(rnd(*yr.shape, seed=9)), r16(rnd(2, cin, 24, 24, seed=10))
+            yr.backward(dy)
+            dx = K.conv_bwd_data(b16(dy), wg, (2, 24, 24, cin), 2, p, 1, add=b16(skip))
+            assert dx.dtype == torch.bfloat16
+            close16(nchw(dx.float()), x2.grad + skip, ulps=1.5)
+    finally:
+        K.set_conv_precision('f32')
 
 
 def test_input_edge_u8(K):

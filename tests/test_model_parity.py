@@ -431,11 +431,11 @@ def test_batched_bn_fold_is_bit_identical(env):
         assert torch.equal(lg, out[False][0][0]) and torch.equal(mem, out[False][0][1])
 
 
-@pytest.mark.parametrize('form', ['bf16', 'bf16_staged'])
+@pytest.mark.parametrize('form', ['bf16', 'bf16_operands', 'bf16_staged'])
 def test_config3_bf16_mfma_forward_and_step(env, form, capsys):
-    """BASELINE configs[2]: the same network with bf16-MFMA convolutions -- `bf16`: every convolution converts its operands to bf16 in HBM
-    (csrc/bf16.hip), bf16 LDS tiles, fp32 accumulation; `bf16_staged`: fp32 tiles rounded per fragment (the fall-back form). Activations between
-    layers, BatchNorm, losses and the memory stay fp32. Gate (looser than fp32 by the operand precision, 2^-9 per operand, through 53 layers):
+    """BASELINE configs[2]: the same network with bf16-MFMA convolutions -- `bf16` (round 4): the whole tier, activations and their gradients stored as bf16
+    between layers (csrc/act16.hip), fp32 statistics / losses / memory / parameters; `bf16_operands`: fp32 activations, every convolution converts its
+    operands to bf16 in HBM (csrc/bf16.hip), bf16 LDS tiles, fp32 accumulation; `bf16_staged`: fp32 tiles rounded per fragment (the fall-back form). Gate (looser than fp32 by the operand precision, 2^-9 per operand, through 53 layers):
     eval logits within 1 % of their range of the fp32 oracle and argmax identical wherever the oracle's top-2 margin exceeds 0.1; a train step
     reproduces the fp32 HIP step's losses to 1 %."""
     from pinthememory_amd.hip import kernels as K
