@@ -93,6 +93,9 @@ int pm_version(void);
 size_t pm_conv_workspace(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p, int which /*0 fwd,1 dgrad,2 wgrad*/);
 size_t pm_conv_winograd_v_bytes(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p);
 size_t pm_conv_wxf_bytes(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p);   /* 0: pm_conv_fwd keeps no transformed filter for this call */
+/* the same for pm_conv_bwd_data on the bf16 tier: bytes of the rotated / transposed bf16 filter a stride-1 data gradient derives from w (0: none). The caller
+ * passes the buffer in pm_conv_params.wxf / wxf_bytes / wxf_valid exactly as for pm_conv_fwd. */
+size_t pm_conv_wxf_bytes_dgrad(const pm_tensor* dy, const pm_tensor* dx, const pm_conv_params* p);
 /* bytes of pm_conv_epilogue.bn_partials for this forward call, 0 if the call cannot emit them (then run pm_bn_stats* on y as before) */
 size_t pm_conv_bn_partials_bytes(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p);
 int pm_conv_fwd(const pm_tensor* x, const float* w_krsc, const pm_tensor* y, const pm_conv_params* p,
@@ -115,6 +118,9 @@ int pm_set_winograd(int mode);
  * 32 channels x all 36 points). Same results to fp32 round-off; measured slower than GEMM + output-transform pass on every flagship layer
  * (DESIGN.md section 7), hence off by default: 0 off, 1 on. Process-wide like pm_set_winograd. */
 int pm_set_winograd_fused(int on);
+/* bf16 tier, forward and stride-1 data gradient: 1 (default) = the LDS-DMA kernel (csrc/conv16.hip: global_load_lds staging, swizzled LDS image), 0 = the
+ * register-staged kernel of rounds 2-3 with bf16 rows (A/B runs and tests). Process-wide like pm_set_winograd. */
+int pm_set_conv16(int on);
 /* prec = 2 weight gradients on pixel-contiguous bf16 copies of x (one per tap) and dy instead of the staged-fp32 form: 0 off (default: the
  * copies cost more HBM time than the GEMM saves), 1 on. Process-wide like pm_set_winograd. */
 int pm_set_bf16_wgrad(int on);
@@ -191,7 +197,7 @@ int pm_scale_shift_act(const pm_tensor* x, const float* scale, const float* shif
                        const pm_tensor* y, void* stream);
 
 /* dtype conversion between two views of the same shape (PM_F32 <-> PM_BF16, round to nearest even): the edges of the bf16 tier -- the memory module
- * (memory.py:167-239) and the losses stay fp32. A bf16 destination with c % 8 != 0 must be dense (pitch == roundup(c, 8)); its pad lanes are written as 0. */
+ * (memory.py:167-239) and the losses stay fp32. Only the c channels of a pixel are written (pad lanes of a wider pitch are left alone). */
 int pm_cast(const pm_tensor* x, const pm_tensor* y, void* stream);
 
 /* ---- K3 pooling (Resnet.py:432 MaxPool2d(3,2,1); deepv3plus.py:85 AdaptiveAvgPool2d(1)) ------------------------- */

@@ -768,19 +768,17 @@ extern "C" int pm_cast(const pm_tensor* x, const pm_tensor* y, void* stream) {
   const long P = pm_pixels(x);
   if (pm_is_bf16(x) && pm_is_f32(y)) return pm16_to_f32((const pm_bf16*)x->ptr, x->pitch, x->c, P, (float*)y->ptr, y->pitch, st);
   if (pm_is_f32(x) && pm_is_bf16(y)) {
-    PM_REQUIRE(y->pitch % 8 == 0 && pm_aligned16(y->ptr) && pm_vec_ok(x), PM_EINVAL, "cast: fp32 -> bf16 needs 16-byte aligned rows on both sides");
-    const int cp = (x->c + 7) / 8 * 8;
-    PM_REQUIRE(y->pitch == cp || x->c % 8 == 0, PM_EINVAL, "cast: a bf16 destination with c %% 8 != 0 must be dense (pitch == roundup(c, 8)): the pad lanes are written");
-    if (y->pitch == cp) return pm_bf16_cast_rows((const float*)x->ptr, x->pitch, x->c, cp, P, y->ptr, st);
-    // channel slice of a wider buffer (c % 8 == 0): row by row through the generic driver
     const float* px = (const float*)x->ptr;
     pm_bf16* py = (pm_bf16*)y->ptr;
     const long a = x->pitch, c = y->pitch;
-    return ew16_launch(P, x->c, st, "cast", [=] __device__(long p, int ch) {
-      float v[V];
-      ld8f(px + p * a + ch, v);
-      pm_st8(py + p * c + ch, v);
-    });
+    const int C = x->c;
+    if (C % 8 == 0 && pm_vec_ok(x) && y->pitch % 8 == 0 && pm_aligned16(y->ptr))      // 16-byte rows on both sides (any pitches: channel slices of wider buffers)
+      return ew16_launch(P, C, st, "cast", [=] __device__(long p, int ch) {
+        float v[V];
+        ld8f(px + p * a + ch, v);
+        pm_st8(py + p * c + ch, v);
+      });
+    return pm_ew_launch(false, P, C, st, "cast", [=] __device__(long p, int ch) { py[p * c + ch] = pm_f32_to_bf16(px[p * a + ch]); });      // odd shapes: element by element
   }
   PM_REQUIRE(false, PM_EUNSUPPORTED, "cast: dtype %d -> %d", x->dtype, y->dtype);
   return PM_OK;

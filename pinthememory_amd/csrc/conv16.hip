@@ -1,0 +1,298 @@
+// BASELINE configs[2], round 4: the bf16 implicit-GEMM convolution built around LDS-DMA (the core of tools/micro/bf16_glds_lab.hip moved into the library and
+// given the convolution gather). Forward and stride-1 data gradient (= forward convolution of dy with the rotated filter) of nn.Conv2d on bf16 activations:
+//   C[M][N] = sum_k A[m][k] B[n][k],  M = output pixels, N = output channels, k = (tap, channel), channels padded to a multiple of 64 per tap
+//   A = bf16 NHWC activations gathered per (row, tap): one K-step = one tap x 64 channels = 128 bytes of one pixel row
+//   B = bf16 weights [N][taps][Cp] (pm_bf16_cast_weights), k-contiguous
+// Staging: global_load_lds, 16 bytes per lane, straight from global memory into LDS -- no staging registers, no ds_write pass. The LDS image is lane-linear
+// (row = 8 lanes x 16 B), so the XOR swizzle that makes the ds_read_b128 fragment reads conflict-free is applied on the SOURCE chunk a lane fetches (and again on
+// the read). Padding taps and rows beyond M fetch a 16-byte zero page instead (a per-lane source address costs nothing: no branch, no buffer descriptor).
+// 256 threads = 4 waves x (BM / WM) x (BN / WN) of v_mfma_f32_32x32x16_bf16 tiles, fp32 accumulation; NST LDS stages (2: the loads of K-step k + 1 fly under the
+// MFMAs of step k; 1 for the single-step reductions of the 64-channel 1x1 convolutions, where four blocks share a CU instead of two).
+// Epilogue staged through LDS: whole 16-byte row segments of eight bf16 (round to nearest even) with the fused bias / folded BatchNorm / residual / ReLU, or
+// fp32 rows for the class logits and the split-K slabs.
+// Replaces nn.Conv2d forward / input gradient of Resnet.py:145-150,195,453-457; deepv3plus.py:72-81,398-424; memory.py:75,104 on the bf16 tier.
+#include <stdlib.h>
+#include <algorithm>
+
+#include "pm_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __attribute__((aligned(64))) unsigned pm_zero_page16[16];      // zero-initialised: the source of every padded / out-of-range 16-byte fetch
+
+namespace {
+
+constexpr int BKB = 128;      // bytes per row and K-step (64 bf16)
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int BM, int BN, int WM, int WN, int NST>
+__global__ __launch_bounds__(256, 2) void conv16_kernel(const pm_conv16 a) {
+  constexpr int A_IT = BM / 32, B_IT = BN / 32;           // 16-byte fetches per lane and K-step: a 256-thread sweep covers 32 rows x 8 chunks
+  constexpr int A_BYTES = BM * BKB, STAGE = (BM + BN) * BKB;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "bad tile config");
+  extern __shared__ __align__(16) char lds[];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, half = lane >> 5;
+  const int lid = xcd_remap(blockIdx.x, a.tiles_m * a.tiles_n);
+  const int m0 = (lid / a.tiles_n) * BM, n0 = (lid % a.tiles_n) * BN;
+  const int z = blockIdx.z;
+  const int kt0 = z * a.ksteps_per, nk = min(a.ksteps - kt0, a.ksteps_per);      // this block's K-steps [kt0, kt0 + nk)
+  const char* zp = reinterpret_cast<const char*>(pm_zero_page16);
+  const long pitchb = a.a_pitch * 2;
+
+  // ---- per-lane staging constants: this lane's rows of the A and B tiles and the (swizzled) 16-byte chunk it fetches of each ----------------------------
+  const char* abase[A_IT];
+  int ay0[A_IT], ax0[A_IT];
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    const int u = it * 256 + t, row = u >> 3, ch = (u & 7) ^ ((row >> 1) & 7);
+    const int m = m0 + row;
+    if (m < a.M) {
+      const int img = m / (a.Ho * a.Wo), rem = m - img * (a.Ho * a.Wo);
+      const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+      ay0[it] = oy * a.stride - a.pad, ax0[it] = ox * a.stride - a.pad;
+      abase[it] = reinterpret_cast<const char*>(a.A) + ((long)(img * a.H + ay0[it]) * a.W + ax0[it]) * pitchb + ch * 16;
+    } else {
+      ay0[it] = ax0[it] = -(1 << 28);      // never inside the image: the row reads zeros
+      abase[it] = zp;
+    }
+  }
+  const char* bbase[B_IT];
+#pragma unroll
+  for (int it = 0; it < B_IT; ++it) {
+    const int u = it * 256 + t, row = u >> 3, ch = (u & 7) ^ ((row >> 1) & 7);
+    const int n = n0 + row;
+    bbase[it] = n < a.Nn ? reinterpret_cast<const char*>(a.B) + (long)n * a.K * 2 + ch * 16 : nullptr;
+  }
+  // wave-uniform K-state: (tap, channel chunk) of the next K-step to stage
+  const int cpc = a.Cp >> 6;      // 64-channel chunks per tap
+  int s_tap = kt0 / cpc, s_ch = kt0 - s_tap * cpc, s_ky = s_tap / a.kw, s_kx = s_tap - s_ky * a.kw;
+  s_tap = __builtin_amdgcn_readfirstlane(s_tap), s_ch = __builtin_amdgcn_readfirstlane(s_ch);
+  s_ky = __builtin_amdgcn_readfirstlane(s_ky), s_kx = __builtin_amdgcn_readfirstlane(s_kx);
+  long s_kb = (long)kt0 * BKB;      // byte offset of the K-step inside a weight row
+
+  auto stage = [&](int buf) {
+    char* la = lds + buf * STAGE;
+    char* lb = la + A_BYTES;
+    const int dy = s_ky * a.dil, dx = s_kx * a.dil;
+    const long toff = ((long)dy * a.W + dx) * pitchb + (long)s_ch * BKB;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const bool ok = ((unsigned)(ay0[it] + dy) < (unsigned)a.H) & ((unsigned)(ax0[it] + dx) < (unsigned)a.W);
+      const char* src = ok ? abase[it] + toff : zp;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(la + (it * 256 + wave * 64) * 16), 16, 0,
+                                       0);
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const char* src = bbase[it] ? bbase[it] + s_kb : zp;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(lb + (it * 256 + wave * 64) * 16), 16, 0,
+                                       0);
+    }
+    // advance the K-state (scalar unit)
+    s_kb += BKB;
+    if (++s_ch == cpc) {
+      s_ch = 0;
+      ++s_tap;
+      if (++s_kx == a.kw) s_kx = 0, ++s_ky;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  auto compute = [&](int buf) {
+    const char* la = lds + buf * STAGE;
+    const char* lb = la + A_BYTES;
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      const int c = kg * 2 + half;      // this lane-half's eight k of the 16-k block
+      bf16x8 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int ra = wm * (BM / WM) + i * 32 + l31;
+        fa[i] = *reinterpret_cast<const bf16x8*>(la + ra * BKB + ((c ^ ((ra >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int rb = wn * (BN / WN) + j * 32 + l31;
+        fb[j] = *reinterpret_cast<const bf16x8*>(lb + rb * BKB + ((c ^ ((rb >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if (nk > 0) {
+    stage(0);
+    __syncthreads();
+    if constexpr (NST == 1) {
+      for (int kt = 0; kt < nk; ++kt) {
+        compute(0);
+        if (kt + 1 < nk) {
+          __syncthreads();      // every wave is done reading the single buffer
+          stage(0);
+          __syncthreads();
+        }
+      }
+    } else {
+      for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) stage((kt + 1) & 1);
+        compute(kt & 1);
+        __syncthreads();
+      }
+    }
+  }
+
+  // ---- epilogue: a wave parks 32 rows of its tile in LDS (the stages are dead) and stores whole row segments ----------------------------------------
+  constexpr int WC = BN / WN, LDC = WC + 4;
+  __syncthreads();
+  float* Ws = reinterpret_cast<float*>(lds) + wave * 32 * LDC;
+  const bool slab = a.ksplit > 1;
+  if (a.c_f32 || slab) {      // fp32 rows: split-K slabs (no epilogue) or the class logits (bias only; 19 columns at pitch 20: per-element stores)
+    float* Cf = reinterpret_cast<float*>(a.C) + (slab ? (long)z * a.c_split : 0);
+    const long cp = slab ? a.Nn : a.c_pitch;
+    constexpr int LPR = WC / 4, RPI = 64 / LPR;
+    const int rr0 = lane / LPR, cc = (lane % LPR) * 4;
+    const int col = n0 + wn * WC + cc;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Ws[((q & 3) + 8 * (q >> 2) + 4 * half) * LDC + n * 32 + l31] = acc[i][n][q];
+#pragma unroll
+      for (int r0 = 0; r0 < 32; r0 += RPI) {
+        const int rr = r0 + rr0;
+        const long row = m0 + wm * (BM / WM) + i * 32 + rr;
+        const float4 v = *reinterpret_cast<const float4*>(Ws + rr * LDC + cc);
+        if (row >= a.M) continue;
+        const float e[4] = {v.x, v.y, v.z, v.w};
+        if (((cp | a.Nn) & 3) == 0 && col + 4 <= a.Nn && !a.bias) PM_ST4(Cf + row * cp + col, v);
+        else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (col + k < a.Nn) Cf[row * cp + col + k] = e[k] + ((a.bias && !slab) ? a.bias[col + k] : 0.f);
+        }
+      }
+    }
+    return;
+  }
+  {
+    constexpr int LPR = WC / 8, RPI = 64 / LPR;
+    static_assert(32 % RPI == 0, "row segments must tile the 32-row slab");
+    const int rr0 = lane / LPR, cc = (lane % LPR) * 8;
+    const int col = n0 + wn * WC + cc;
+    const bool cok = col < a.Nn;      // Nn % 8 == 0: the group is all in or all out
+    const bool aff = a.bias || a.scale, res = a.residual != nullptr, relu = a.relu != 0;
+    float bi[8], sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bi[e] = 0.f, sc[e] = 1.f, sh[e] = 0.f;
+    if (aff && cok) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (a.bias) bi[e] = a.bias[col + e];
+        if (a.scale) sc[e] = a.scale[col + e], sh[e] = a.shift[col + e];
+      }
+    }
+    pm_bf16* C16 = reinterpret_cast<pm_bf16*>(a.C);
+    const pm_bf16* R16 = reinterpret_cast<const pm_bf16*>(a.residual);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Ws[((q & 3) + 8 * (q >> 2) + 4 * half) * LDC + n * 32 + l31] = acc[i][n][q];
+#pragma unroll
+      for (int r0 = 0; r0 < 32; r0 += RPI) {
+        const int rr = r0 + rr0;
+        const long row = m0 + wm * (BM / WM) + i * 32 + rr;
+        const float4 v0 = *reinterpret_cast<const float4*>(Ws + rr * LDC + cc), v1 = *reinterpret_cast<const float4*>(Ws + rr * LDC + cc + 4);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        if (row < a.M && cok) {
+          if (aff) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (v[e] + bi[e]) * sc[e] + sh[e];
+          }
+          if (res) {
+            float q[8];
+            pm_ld8(R16 + row * a.res_pitch + col, q);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += q[e];
+          }
+          if (relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          pm_st8(C16 + row * a.c_pitch + col, v);
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int NST>
+void launch_tile(const pm_conv16& k, dim3 grid, hipStream_t st) {
+  constexpr size_t stage_bytes = (size_t)NST * (BM + BN) * BKB, ep_bytes = (size_t)4 * 32 * (BN / WN + 4) * sizeof(float);
+  constexpr size_t smem = stage_bytes > ep_bytes ? stage_bytes : ep_bytes;
+  static const bool attr_set = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv16_kernel<BM, BN, WM, WN, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return true;
+  }();
+  (void)attr_set;
+  hipLaunchKernelGGL((conv16_kernel<BM, BN, WM, WN, NST>), grid, dim3(256), smem, st, k);
+}
+
+}  // namespace
+
+// Tile / split choice. Rows in tiles of 128 (64 when that fills the 256 CUs better on the 48 x 48 maps), columns in tiles of 128 (64 for <= 64 output
+// channels); split-K (fp32 slabs, fixed-order reduce by the caller) only where the output tiles alone leave most CUs idle AND the reduction is long.
+void pm_conv16_plan(pm_conv16* k) {
+  static const int force_bm = getenv("PM_C16_BM") ? atoi(getenv("PM_C16_BM")) : 0;
+  static const int force_ks = getenv("PM_C16_KS") ? atoi(getenv("PM_C16_KS")) : 0;
+  k->bn = k->Nn > 64 ? 128 : 64;
+  k->tiles_n = pm_cdiv(k->Nn, k->bn);
+  const long t128 = (long)pm_cdiv(k->M, 128) * k->tiles_n, t64 = (long)pm_cdiv(k->M, 64) * k->tiles_n;
+  // rounds of the 256 CUs x 2 resident blocks: take 64-row tiles when 128-row tiles would leave the last round under half full or not fill the chip once
+  auto waste = [](long tiles) { const long r = (tiles + 511) / 512; return (double)(r * 512) / (double)tiles; };
+  k->bm = (t128 < 512 || waste(t128) > 1.25 * waste(t64)) ? 64 : 128;
+  if (force_bm) k->bm = force_bm;
+  k->tiles_m = pm_cdiv(k->M, k->bm);
+  const long tiles = (long)k->tiles_m * k->tiles_n;
+  int ks = 1;
+  if (tiles < 256 && k->ksteps >= 16) ks = (int)std::min<long>(std::min<long>(8, k->ksteps / 8), (512 + tiles - 1) / tiles);
+  if (force_ks) ks = std::min(force_ks, k->ksteps);
+  k->ksteps_per = pm_cdiv(k->ksteps, ks);
+  k->ksplit = pm_cdiv(k->ksteps, k->ksteps_per);
+  k->c_split = (long)k->M * k->Nn;
+}
+size_t pm_conv16_slab_bytes(const pm_conv16* k) { return k->ksplit > 1 ? pm_align_up((size_t)k->ksplit * k->M * k->Nn * sizeof(float), 256) : 0; }
+
+int pm_conv16_launch(const pm_conv16* k0, hipStream_t st) {
+  pm_conv16 k = *k0;
+  dim3 grid(k.tiles_m * k.tiles_n, 1, k.ksplit);
+  const bool one = k.ksteps_per == 1;      // a single K-step per block: one LDS stage, four blocks per CU
+  if (k.bm == 128 && k.bn == 128) one ? launch_tile<128, 128, 2, 2, 1>(k, grid, st) : launch_tile<128, 128, 2, 2, 2>(k, grid, st);
+  else if (k.bm == 64 && k.bn == 128) one ? launch_tile<64, 128, 2, 2, 1>(k, grid, st) : launch_tile<64, 128, 2, 2, 2>(k, grid, st);
+  else if (k.bm == 128 && k.bn == 64) one ? launch_tile<128, 64, 2, 2, 1>(k, grid, st) : launch_tile<128, 64, 2, 2, 2>(k, grid, st);
+  else if (k.bm == 64 && k.bn == 64) one ? launch_tile<64, 64, 2, 2, 1>(k, grid, st) : launch_tile<64, 64, 2, 2, 2>(k, grid, st);
+  else {
+    pm_set_error("conv16: no %d x %d tile", k.bm, k.bn);
+    return PM_EUNSUPPORTED;
+  }
+  return pm_check_launch("conv16");
+}

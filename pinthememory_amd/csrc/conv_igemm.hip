@@ -1088,7 +1088,9 @@ Plan make_plan(int mode, long M, long Nn, long K, bool bf16 = false) {
     if (bm == 128 && mode == MODE_WGRAD && M <= 64 && bn >= 64) continue;
     const int tiles_m = pm_cdiv(M, bm), tiles_n = pm_cdiv(Nn, bn);
     const long tiles = (long)tiles_m * tiles_n;
-    const double unit_us = 2.0 * (bm / 128.0) * (bn / 128.0) * (bm == 64 ? 1.08 : 1.0);
+    // bf16 MFMA: a K-step of a 128 x 128 tile is ~0.25 us of matrix pipe (16 x the fp32 rate), ~0.5 us with its staging; the slab round trip of a split
+    // weighs 4 x more against it than on the fp32 path
+    const double unit_us = (bf16 ? 0.5 : 2.0) * (bm / 128.0) * (bn / 128.0) * (bm == 64 ? 1.08 : 1.0);
     const long ks_max = std::max<long>(1, std::min<long>(ksteps / 4, 512));
     static const int force_ks = getenv("PM_FORCE_KS") ? atoi(getenv("PM_FORCE_KS")) : 0;
     for (long ks = 1; ks <= ks_max; ++ks) {
@@ -1402,8 +1404,11 @@ int wino_wgrad(const pm_tensor* x, const pm_tensor* dy, float* dw, const WinoPla
 // The convolution is handed to the implicit-GEMM kernel as an fp32-typed problem with HALF the input channels: a float of the view is a
 // pair of bf16 channels, a 32-float K-slab is 64 bf16 k-values. Input channels are padded to a multiple of 64 (zero-filled by the cast)
 // so that a slab never straddles a tap and the wave-uniform K-state (K_FAST) applies to every layer.
+int g_conv16 = getenv("PM_CONV16") ? atoi(getenv("PM_CONV16")) : 1;      // pm_set_conv16
 struct Bf16Plan {
   bool use;
+  bool c16;                  // the LDS-DMA kernel (conv16.hip) takes the call; k16 holds its geometry and plan (pointers / epilogue filled at launch)
+  pm_conv16 k16;
   bool inplace;              // the gathered operand already is a bf16 tensor whose rows can be gathered where they lie (no cast / pad pass)
   int Cp;                    // padded input channels (bf16 elements)
   long M, Nn, Kf;            // GEMM extents, K in float units (= taps * Cp / 2)
@@ -1425,9 +1430,26 @@ Bf16Plan bf16_plan(const pm_tensor* xin, const pm_tensor* yout, const pm_conv_pa
   b.pl = make_plan(MODE_FWD, b.M, b.Nn, b.Kf, true);
   if (b.pl.bn < 64) return b;                                     // no bf16 instantiation of the 128 x 32 tile
   b.use = true;
+  // round 4: the LDS-DMA kernel for everything but tiny row counts (the image-pooling branch: M = batch) -- PM_CONV16=0 keeps the register-staged kernel (A/B runs)
+  const int c16_on = g_conv16;
+  static const int c16_min_m = getenv("PM_CONV16_MIN_M") ? atoi(getenv("PM_CONV16_MIN_M")) : 256;
+  b.c16 = false;
+  if (c16_on && b.M >= c16_min_m && p->stride >= 1) {
+    pm_conv16& k = b.k16;
+    k = pm_conv16{};
+    k.N = xin->n, k.H = xin->h, k.W = xin->w, k.Ho = yout->h, k.Wo = yout->w;
+    k.a_pitch = b.inplace ? xin->pitch : b.Cp, k.Cp = b.Cp;
+    k.kh = p->kh, k.kw = p->kw, k.stride = p->stride, k.pad = p->pad, k.dil = p->dil;
+    k.M = (int)b.M, k.Nn = (int)b.Nn, k.K = (int)(T * b.Cp), k.ksteps = k.K / 64;
+    k.c_pitch = yout->pitch, k.c_f32 = pm_is_bf16(yout) ? 0 : 1;
+    pm_conv16_plan(&k);
+    b.c16 = true;
+  }
   return b;
 }
-inline size_t bf16_ws(const Bf16Plan& b) { return b.xb_bytes + b.wb_bytes + pm_align_up(b.pl.ws_bytes, 256); }
+inline size_t bf16_ws(const Bf16Plan& b) {
+  return b.xb_bytes + b.wb_bytes + std::max(pm_align_up(b.pl.ws_bytes, 256), b.c16 ? pm_conv16_slab_bytes(&b.k16) : (size_t)0);
+}
 
 // xin: the tensor the GEMM gathers from (x for the forward pass, dy for the data gradient); `rotate`: w is read as the rotated /
 // transposed filter; pe: geometry of the convolution actually run (the data gradient of a stride-1 convolution is a stride-1
@@ -1446,6 +1468,45 @@ int conv_bf16(const pm_tensor* xin, const float* w, int w_cout, int w_cin, bool 
   if (!(wb_ext && wb_valid))
     if (int e = pm_bf16_cast_weights(w, w_cout, T, w_cin, b.Cp, rotate, wb, st)) return e;
   const long xpitch16 = b.inplace ? xin->pitch : b.Cp;                       // bf16 elements between pixels
+  if (b.c16) {
+    const bool o16 = pm_is_bf16(yout);
+    const bool ep_any = e0.bias || e0.scale || e0.residual || e0.relu;
+    // what the kernel's two epilogues cover: bf16 rows of whole 16-byte groups with the full fused epilogue, or fp32 rows with at most a bias; no statistics
+    const bool ok = !e0.bn_partials &&
+                    (o16 ? ((yout->c | yout->pitch | (e0.residual ? e0.residual_pitch : 0)) & 7) == 0 && pm_aligned16(yout->ptr) && pm_aligned16(e0.residual)
+                         : !(e0.scale || e0.residual || e0.relu));
+    if (ok) {
+      pm_conv16 k = b.k16;
+      k.A = (const pm_bf16*)xb, k.B = (const pm_bf16*)wb;
+      const double fl = 2.0 * (double)b.M * (double)b.Nn * (double)T * (double)xin->c;
+      ProfRec rec;
+      if (g_prof_on) {
+        (void)hipEventCreate(&rec.a), (void)hipEventCreate(&rec.b);
+        rec.mode = 4, rec.bm = k.bm, rec.bn = k.bn, rec.km = 0, rec.prec = 5, rec.nst = k.ksteps_per == 1 ? 1 : 2, rec.M = k.M, rec.Nn = k.Nn, rec.K = k.K / 2, rec.batch = 1,
+        rec.ksplit = k.ksplit, rec.flops = fl;
+        (void)hipEventRecord(rec.a, st);
+      }
+      int e;
+      if (k.ksplit > 1) {
+        k.C = slab;
+        e = pm_conv16_launch(&k, st);
+      } else {
+        k.C = yout->ptr;
+        k.bias = e0.bias, k.scale = e0.scale, k.shift = e0.shift, k.residual = e0.residual, k.res_pitch = e0.residual_pitch, k.relu = e0.relu;
+        e = pm_conv16_launch(&k, st);
+      }
+      if (g_prof_on) {
+        (void)hipEventRecord(rec.b, st);
+        g_prof.push_back(rec);
+      }
+      if (e) return e;
+      if (k.ksplit > 1)
+        return splitk_reduce(slab, k.ksplit, b.M, b.Nn, (float*)yout->ptr, (long)yout->pitch, e0.bias, e0.scale, e0.shift, e0.residual, (long)e0.residual_pitch, e0.relu,
+                             st, o16);
+      (void)ep_any;
+      return PM_OK;
+    }
+  }
   const pm_tensor xv = {xb, xin->n, xin->h, xin->w, b.Cp / 2, xpitch16 / 2};   // fp32-typed view: one float = two bf16 channels
   ConvK k;
   fill_geom(k, &xv, yout, pe);
@@ -1557,6 +1618,10 @@ extern "C" int pm_set_winograd(int mode) {
   g_wino_mode = mode;
   return PM_OK;
 }
+extern "C" int pm_set_conv16(int on) {
+  g_conv16 = on != 0;
+  return PM_OK;
+}
 extern "C" int pm_set_winograd_fused(int on) {
   g_wino_fused = on != 0;
   return PM_OK;
@@ -1631,6 +1696,16 @@ extern "C" size_t pm_conv_wxf_bytes(const pm_tensor* x, const pm_tensor* y, cons
     if (b.use) return b.wb_bytes;
   }
   return 0;
+}
+
+// the same for pm_conv_bwd_data: bytes of the rotated / transposed bf16 filter a stride-1 data gradient of the bf16 tier derives from w (0: none)
+extern "C" size_t pm_conv_wxf_bytes_dgrad(const pm_tensor* dy, const pm_tensor* dx, const pm_conv_params* p0) {
+  if (!dy || !dx || !p0) return 0;
+  const pm_conv_params tp = tier_params(p0, dy, dx);
+  if (!dgrad_bf16_ok(&tp)) return 0;
+  const pm_conv_params q = dgrad_as_fwd(&tp);
+  const Bf16Plan b = bf16_plan(dy, dx, &q);
+  return b.use ? b.wb_bytes : 0;
 }
 
 // Can this forward call hand the BatchNorm statistics of its output out of its own epilogue? Only the unbatched direct GEMM with one K
@@ -1839,7 +1914,8 @@ extern "C" int pm_conv_bwd_data(const pm_tensor* dy0, const float* w, const pm_t
     if (b.use) {
       PM_REQUIRE(ws && ws_bytes >= bf16_ws(b), PM_EWORKSPACE, "conv_bwd_data(bf16): workspace %zu < %zu", ws_bytes, bf16_ws(b));
       const pm_conv_epilogue e1 = {(int64_t)sizeof(pm_conv_epilogue), nullptr, nullptr, nullptr, addp, add_pitch, 0};
-      return conv_bf16(dy, w, dy->c, dx->c, true, dx, &q, b, e1, ws, st0);
+      char* wext = (p->wxf && (size_t)p->wxf_bytes >= b.wb_bytes) ? (char*)p->wxf : nullptr;      // the rotated bf16 filter kept by the caller (pm_conv_wxf_bytes_dgrad)
+      return conv_bf16(dy, w, dy->c, dx->c, true, dx, &q, b, e1, ws, st0, wext, p->wxf_valid != 0);
     }
   }
   {

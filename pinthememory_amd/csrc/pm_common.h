@@ -87,6 +87,29 @@ int pm16_resize_bwd_separable(const pm_tensor* dy, const pm_tensor* dx, int accu
 int pm16_to_f32(const pm_bf16* x, long pitch, int C, long P, float* out, long out_pitch, hipStream_t st);
 int pm16_pad_rows(const pm_bf16* x, long pitch, int C, int Cp, long P, pm_bf16* out, hipStream_t st);
 
+// ---- the LDS-DMA bf16 implicit-GEMM convolution (conv16.hip), driven by the conv entry points in conv_igemm.hip ----------------------------------------
+struct pm_conv16 {
+  const pm_bf16* A;          // bf16 NHWC activations (x, or dy for the data gradient), gathered in place
+  const pm_bf16* B;          // bf16 weights [Nn][taps][Cp] (pm_bf16_cast_weights; rotated / transposed for the data gradient)
+  void* C;                   // bf16 [M][c_pitch] (c_f32 == 0), fp32 [M][c_pitch] (c_f32 != 0), or the fp32 split-K slabs [ksplit][M][Nn] (ksplit > 1)
+  int N, H, W, Ho, Wo;       // input and output pixel grids
+  long a_pitch;              // bf16 elements between input pixels
+  int Cp;                    // channels per tap, a multiple of 64 (zero pad channels inside the pitch)
+  int kh, kw, stride, pad, dil;
+  int M, Nn, K, ksteps;      // GEMM extents; K = taps * Cp, ksteps = K / 64
+  long c_pitch;
+  int c_f32;
+  const float *bias, *scale, *shift;
+  const void* residual;      // bf16, same shape as C
+  long res_pitch;
+  int relu;
+  int bm, bn, tiles_m, tiles_n, ksplit, ksteps_per;      // pm_conv16_plan
+  long c_split;
+};
+void pm_conv16_plan(pm_conv16* k);
+size_t pm_conv16_slab_bytes(const pm_conv16* k);
+int pm_conv16_launch(const pm_conv16* k, hipStream_t st);
+
 // ---- device helpers -------------------------------------------------------------------------------------------
 // eight bf16 channels (16 bytes) <-> eight floats. Round to nearest even on the way out (v_cvt_pk_bf16_f32).
 __device__ __forceinline__ void pm_ld8(const pm_bf16* p, float* v) {

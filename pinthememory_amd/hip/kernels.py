@@ -141,17 +141,18 @@ def _evict(ent):
             ent[2].record_stream(s)
 
 
-def _wino_u(lib, xd, yd, p, w_krsc):
+def _wino_u(lib, xd, yd, p, w_krsc, dgrad=False):
+    """dgrad: (xd, yd) = (dy, dx) of a data gradient on the bf16 tier -- the kept transform is the rotated / transposed bf16 filter."""
     if KEEP_WINOGRAD_U is False:
         return None
     owner = _filter_owner(w_krsc)
     if owner is None and KEEP_WINOGRAD_U is not True:
         return None
-    nbu = lib.pm_conv_wxf_bytes(byref(xd), byref(yd), byref(p))
+    nbu = (lib.pm_conv_wxf_bytes_dgrad if dgrad else lib.pm_conv_wxf_bytes)(byref(xd), byref(yd), byref(p))
     if not nbu:
         return None
     import weakref
-    key = (w_krsc.data_ptr(), tuple(w_krsc.shape), nbu, w_krsc.device.index, p.prec)
+    key = (w_krsc.data_ptr(), tuple(w_krsc.shape), nbu, w_krsc.device.index, p.prec, dgrad)
     ent = _U_CACHE.pop(key, None)
     if ent is not None and (ent[0]() if isinstance(ent[0], weakref.ref) else ent[0]) is not (owner if owner is not None else w_krsc):
         ent = None                 # another tensor now lives at this address: the kept transform is somebody else's
@@ -229,7 +230,13 @@ def conv_bwd_data(dy, w_krsc, x_shape, stride, pad, dil, add=None, dtype=None):
     nb = lib.pm_conv_workspace(byref(dxd), byref(dyd), byref(p), 1)
     ws = workspace(nb, dy.device) if nb else None
     ad = tdesc(add) if add is not None else None
+    u_ent = _wino_u(lib, dyd, dxd, p, w_krsc, dgrad=True) if CONV_PREC == 2 else None      # bf16 tier: the rotated bf16 filter is kept per weight version
     check(lib.pm_conv_bwd_data(byref(dyd), w_krsc.data_ptr(), byref(dxd), byref(p), byref(ad) if ad else None, ptr(ws), nb, stream()), 'pm_conv_bwd_data')
+    if u_ent is not None:
+        ent, version = u_ent
+        cur = torch.cuda.current_stream()
+        ent[3], ent[4] = cur.record_event(), cur.cuda_stream
+        ent[1] = version
     return dx
 
 
@@ -688,6 +695,11 @@ def set_winograd(mode):
 def set_winograd_fused(on):
     """F(4x4) layers: GEMMs + output transform in one kernel (opt-in; slower than the two-pass form on the flagship layers)."""
     check(_lib().pm_set_winograd_fused(1 if on else 0), 'pm_set_winograd_fused')
+
+
+def set_conv16(on):
+    """bf16 tier: LDS-DMA convolution kernel (default) vs the register-staged one."""
+    check(_lib().pm_set_conv16(1 if on else 0), 'pm_set_conv16')
 
 
 def set_bf16_wgrad(on):

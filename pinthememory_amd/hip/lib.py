@@ -57,12 +57,14 @@ SIGNATURES = {
     'pm_version': (c_int, []),
     'pm_conv_winograd_v_bytes': (_sz, [_T, _T, _P]),
     'pm_conv_wxf_bytes': (_sz, [_T, _T, _P]),
+    'pm_conv_wxf_bytes_dgrad': (_sz, [_T, _T, _P]),
     'pm_conv_workspace': (_sz, [_T, _T, _P, _i]),
     'pm_conv_fwd': (_i, [_T, _vp, _T, _P, _E, _vp, _sz, _vp]),
     'pm_conv_bwd_data': (_i, [_T, _vp, _T, _P, _T, _vp, _sz, _vp]),
     'pm_conv_bwd_weight': (_i, [_T, _T, _vp, _vp, _P, _vp, _sz, _vp]),
     'pm_set_winograd': (_i, [_i]),
     'pm_set_winograd_fused': (_i, [_i]),
+    'pm_set_conv16': (_i, [_i]),
     'pm_profile_enable': (_i, [_i]),
     'pm_profile_dump': (_i, [ctypes.c_char_p]),
     'pm_profile_read': (_i, [_i, _i, _i, _i, _i, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64), _i]),

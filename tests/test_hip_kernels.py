@@ -696,7 +696,7 @@ def test_act16_batchnorm(K, shape):
     """csrc/act16.hip: train-mode BatchNorm forward / backward on bf16 activations (fp32 statistics) against the fp32 formulas evaluated on the same bf16
     values: statistics to fp32 round-off, bf16 outputs to one rounding; ReLU masks from the forward output, rebuilt from x, and from the mask bytes."""
     n, c, h, w = shape
-    x = rnd(n, c, h, w, seed=1).bfloat16().float() * 2 + 0.5
+    x = (rnd(n, c, h, w, seed=1) * 2 + 0.5).bfloat16().float()
     res = rnd(n, c, h, w, seed=2).bfloat16().float()
     dy = rnd(n, c, h, w, seed=3).bfloat16().float()
     gamma, beta = rnd(c, seed=4) * 0.2 + 1.0, rnd(c, seed=5) * 0.1
@@ -795,8 +795,9 @@ ACT16_CASES = [CONV_CASES[0], CONV_CASES[1], CONV_CASES[3], CONV_CASES[4], CONV_
                (1, 512, 12, 12, 512, 3, 1, 2, 2, False)]
 
 
+@pytest.mark.parametrize('route', ['lds_dma', 'reg_staged'])
 @pytest.mark.parametrize('case', ACT16_CASES)
-def test_conv_bf16_activations(K, case):
+def test_conv_bf16_activations(K, case, route):
     """BASELINE configs[2], round 4: bf16 tensors in, bf16 tensors out (x, y, dy, dx), fp32 weights / dw, fp32 accumulation. Oracle: the fp32 convolution of
     the bf16-rounded operands; outputs agree to one bf16 rounding, dw to fp32 accumulation order."""
     n, cin, h, w, cout, k, s, p, d, has_bias = case
@@ -807,6 +808,7 @@ def test_conv_bf16_activations(K, case):
     dy = r16(rnd(*y_ref.shape, seed=4))
     skip = r16(rnd(n, cin, h, w, seed=5))
     K.set_conv_precision('bf16')
+    K.set_conv16(route == 'lds_dma')      # csrc/conv16.hip (default) or the register-staged kernel on bf16 rows
     try:
         wg = wt.permute(0, 2, 3, 1).contiguous().cuda()
         xg = K.new((n, h, w, cin), wg, dtype=torch.bfloat16)      # zero-padded + registered when cin % 64 != 0 (304): gathered in place
@@ -825,6 +827,7 @@ def test_conv_bf16_activations(K, case):
             assert torch.equal(y2, y) and torch.equal(dx2, dx)
     finally:
         K.set_conv_precision('f32')
+        K.set_conv16(True)
     x2 = x.clone().requires_grad_(True)
     F.conv2d(x2, r16(wt), None, stride=s, padding=p, dilation=d).backward(dy)
     assert dx.dtype == torch.bfloat16
