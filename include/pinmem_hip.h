@@ -118,8 +118,9 @@ int pm_set_winograd(int mode);
  * 32 channels x all 36 points). Same results to fp32 round-off; measured slower than GEMM + output-transform pass on every flagship layer
  * (DESIGN.md section 7), hence off by default: 0 off, 1 on. Process-wide like pm_set_winograd. */
 int pm_set_winograd_fused(int on);
-/* bf16 tier, forward and stride-1 data gradient: 1 (default) = the LDS-DMA kernel (csrc/conv16.hip: global_load_lds staging, swizzled LDS image), 0 = the
- * register-staged kernel of rounds 2-3 with bf16 rows (A/B runs and tests). Process-wide like pm_set_winograd. */
+/* bf16 tier, forward and stride-1 data gradient: which kernel takes a call. 1 (default) = per shape: the LDS-DMA kernel (csrc/conv16.hip: global_load_lds
+ * staging, swizzled LDS image) on 64-row tiles and single-K-step reductions, the register-staged kernel of rounds 2-3 on 128 x 128 tiles; 2 = LDS-DMA everywhere;
+ * 0 = register-staged everywhere (A/B runs and tests). Process-wide like pm_set_winograd. */
 int pm_set_conv16(int on);
 /* prec = 2 weight gradients on pixel-contiguous bf16 copies of x (one per tap) and dy instead of the staged-fp32 form: 0 off (default: the
  * copies cost more HBM time than the GEMM saves), 1 on. Process-wide like pm_set_winograd. */

@@ -1088,9 +1088,9 @@ Plan make_plan(int mode, long M, long Nn, long K, bool bf16 = false) {
     if (bm == 128 && mode == MODE_WGRAD && M <= 64 && bn >= 64) continue;
     const int tiles_m = pm_cdiv(M, bm), tiles_n = pm_cdiv(Nn, bn);
     const long tiles = (long)tiles_m * tiles_n;
-    // bf16 MFMA: a K-step of a 128 x 128 tile is ~0.25 us of matrix pipe (16 x the fp32 rate), ~0.5 us with its staging; the slab round trip of a split
-    // weighs 4 x more against it than on the fp32 path
-    const double unit_us = (bf16 ? 0.5 : 2.0) * (bm / 128.0) * (bn / 128.0) * (bm == 64 ? 1.08 : 1.0);
+    // (a bf16 K-step is ~4 x shorter; a cost unit of 0.5 us for it was measured: it halves the splits of every weight gradient and loses 1.0 ms/step --
+    //  r04c vs r04a, the side-stream weight gradients want the parallelism more than they mind the slabs -- so the unit is the same for both types)
+    const double unit_us = 2.0 * (bm / 128.0) * (bn / 128.0) * (bm == 64 ? 1.08 : 1.0);
     const long ks_max = std::max<long>(1, std::min<long>(ksteps / 4, 512));
     static const int force_ks = getenv("PM_FORCE_KS") ? atoi(getenv("PM_FORCE_KS")) : 0;
     for (long ks = 1; ks <= ks_max; ++ks) {
@@ -1443,7 +1443,10 @@ Bf16Plan bf16_plan(const pm_tensor* xin, const pm_tensor* yout, const pm_conv_pa
     k.M = (int)b.M, k.Nn = (int)b.Nn, k.K = (int)(T * b.Cp), k.ksteps = k.K / 64;
     k.c_pitch = yout->pitch, k.c_f32 = pm_is_bf16(yout) ? 0 : 1;
     pm_conv16_plan(&k);
-    b.c16 = true;
+    // Where it wins (per-shape A/B, profiles/r04c_conv16_vs_regstaged.txt): 64-row tiles -- the 48 x 48 and 96 x 96 maps, 525 -> 655-700 TF on their 3x3s -- and the
+    // single-K-step 1x1s (four blocks per CU). On 128 x 128 tiles the register-staged kernel's scheduled interleave is still ~10 % ahead (883 vs 982 TF on the
+    // decoder's 3x3): those stay there. PM_CONV16=2 forces the LDS-DMA kernel everywhere.
+    b.c16 = c16_on == 2 || k.bm == 64 || k.ksteps_per == 1;
   }
   return b;
 }
@@ -1619,7 +1622,8 @@ extern "C" int pm_set_winograd(int mode) {
   return PM_OK;
 }
 extern "C" int pm_set_conv16(int on) {
-  g_conv16 = on != 0;
+  PM_REQUIRE(on >= 0 && on <= 2, PM_EINVAL, "pm_set_conv16: %d (0 register-staged, 1 per shape, 2 LDS-DMA everywhere)", on);
+  g_conv16 = on;
   return PM_OK;
 }
 extern "C" int pm_set_winograd_fused(int on) {

@@ -698,8 +698,8 @@ def set_winograd_fused(on):
 
 
 def set_conv16(on):
-    """bf16 tier: LDS-DMA convolution kernel (default) vs the register-staged one."""
-    check(_lib().pm_set_conv16(1 if on else 0), 'pm_set_conv16')
+    """bf16 tier, forward / stride-1 data gradient: 1 = per shape (default: the LDS-DMA kernel where it wins), 2 = LDS-DMA everywhere, 0 = register-staged everywhere."""
+    check(_lib().pm_set_conv16(int(on)), 'pm_set_conv16')
 
 
 def set_bf16_wgrad(on):
