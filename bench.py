@@ -35,6 +35,7 @@ def parse():
     ap.add_argument('--truncate-second-forward', action='store_true',
                     help='skip the decoder in the memory-commit forward (identical results; NOT the default measurement)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-side', action='store_true', help='skip the side.bf16 sub-measurement of the default (f32, one GPU) run')
     ap.add_argument('--launch-timeout', type=float, default=3600.0, help='--gpus N self-launch: seconds after which every rank is killed and the run fails')
     ap.add_argument('--cpu-batch', type=int, default=2)
     ap.add_argument('--no-profile', action='store_true', help='do not bracket conv launches with HIP events')
@@ -46,11 +47,12 @@ def parse():
     ap.add_argument('--input-edge', action='store_true',
                     help='side measurement (not the metric): every step takes a fresh uint8 [B, D, H, W, 3] batch from pinned host memory, copied and '
                          'converted on a side stream while the previous step computes (pinthememory_amd/input_edge.py)')
-    ap.add_argument('--workload', choices=['train', 'config5', 'meminit'], default='train',
+    ap.add_argument('--workload', choices=['train', 'config5', 'meminit', 'mldg'], default='train',
                     help="train = the metric (default). config5 = side measurement of BASELINE configs[4]: ResNet-101 DeepLabV2 sliding-window "
                          "evaluation of 1024x2048 images (crop 1024, overlap 1/3 -> 3 tiles x 2 flips, eval.py:148-274), single GPU. meminit = side "
                          "measurement of the caller before training (train.py:1000-1042): class-prototype initialisation of the memory over --steps batches of "
-                         "bs=8 768x768, eval forwards + the write kernel's soft-label accumulation")
+                         "bs=8 768x768, eval forwards + the write kernel's soft-label accumulation. mldg = side measurement of the regime every pinmem script "
+                         "runs (train.py:493-632, train_GS_pinmem_DR50V3P.sh:9-10): meta-train 4 + meta-test 4 images at 768x768, three weight sets, retain_graph")
     return ap.parse_args()
 
 
@@ -118,6 +120,73 @@ def meminit(a):
                       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                       'config': {'workload': 'memory_initalize (train.py:1000-1042): eval-mode forward of each batch + 4-tap soft-label accumulation of the normalised '
                                              'bot_aspp features, one epoch over %d resident batches, side measurement' % len(batches)},
+                      'roofline': None, 'cpu_baseline': None}), flush=True)
+
+
+def mldg(a):
+    """Side measurement (not the metric): harness.mldg_train_step -- the meta-learning regime of train_memory_mldg (train.py:493-632) at the scripts' size: the bs=8
+    batch split into 4 meta-train + 4 meta-test images at 768 x 768; per step: inner forward + backward (retain_graph), two functional weight sets
+    (theta' = theta - lr g), frozen-encoder memory write, meta-test forward + backward through the written memory, SGD, memory-commit forward.
+    Reports ms/step, peak memory, per-family kernel time (in-library conv events) and how many filter transforms the functional weights force per step."""
+    import copy
+    import torch
+    from pinthememory_amd import harness, synth
+    from pinthememory_amd.hip import kernels as K
+    from pinthememory_amd.network import deepv3plus
+    assert torch.cuda.is_available(), 'bench.py needs a GPU: the HIP path has no CPU fallback'
+    K.set_conv_precision(a.dtype)
+    crit = torch.nn.CrossEntropyLoss(reduction='mean', ignore_index=255)
+    net = synth.load_det_weights(deepv3plus.DeepR50V3PlusD(synth.model_args(gumbel_off=False), 19, crit, crit)).cuda()
+    u1, u2 = copy.deepcopy(net), copy.deepcopy(net)
+    opt, sched = harness.make_optimizer(net)
+    x, y = synth.make_batch(a.batch, a.size, seed=304)
+    x, y = x.cuda(), y.cuda()
+    h = a.batch // 2
+
+    def step():
+        return harness.mldg_train_step(net, u1, u2, opt, x[:h], y[:h], x[h:], y[h:], inner_lr=0.01, sched=sched)
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        losses = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    peak_gb = torch.cuda.max_memory_allocated() / 1e9
+    fam = None
+    if not a.no_profile:
+        K.profile_enable(True)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        K.profile_enable(False)
+        if os.environ.get('PM_PROFILE_DUMP'):
+            K.profile_dump(os.environ['PM_PROFILE_DUMP'])
+        fam = {}
+        for name, mode in (('forward + stride-1 data-gradient convolutions', 0), ('stride-2 data gradients', 1), ('weight gradients', 2), ('LDS-DMA bf16 convolutions', 4)):
+            ms, fl, n = K.profile_read(mode=mode)
+            if n:
+                fam[name] = {'ms_per_step': round(ms / 2, 3), 'launches_per_step': n / 2, 'achieved_TFLOPs': round(fl / (ms * 1e-3) / 1e12, 1)}
+        ms, fl, n = K.profile_read(clear=True)
+        fam['all convolution kernels (weight gradients on their side stream: durations inflate)'] = {'ms_per_step': round(ms / 2, 3), 'launches_per_step': n / 2}
+    xf0 = K.filter_transform_count(enable=True)
+    step()
+    torch.cuda.synchronize()
+    xforms = K.filter_transform_count(enable=False) - xf0
+    assert all(torch.isfinite(v).all() for v in losses.values())
+    print(json.dumps({'metric': 'mldg train imgs/sec 768x768 bs=%d+%d R50-DeepLabV3+ +mem (train.py:493-632)' % (h, a.batch - h), 'value': round(a.batch * a.steps / dt, 3),
+                      'unit': 'imgs/sec', 'n_gpus': 1, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True,
+                      'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+                      'config': {'workload': 'train_memory_mldg (train.py:493-632; every pinmem script: train_GS_pinmem_DR50V3P.sh:9-10): %d meta-train + %d meta-test images %dx%d, '
+                                             'inner fwd + bwd (retain_graph), theta\' = theta - 0.01 g for two weight sets, frozen-encoder memory write, meta-test fwd + bwd '
+                                             'through the written memory, SGD, eval-mode memory-commit fwd; side measurement' % (h, a.batch - h, a.size, a.size),
+                                 'peak_memory_GB': round(peak_gb, 2), 'final_losses': {k: round(float(v), 5) for k, v in losses.items()},
+                                 'filter_transforms_per_step': xforms,
+                                 'filter_transforms_note': 'Winograd U = G w G^T (fp32 tier) / bf16 filter copies (bf16 tier) computed inside one step; functional weights '
+                                                           '(theta\') are not owner-registered parameters, so their transforms are never kept between calls',
+                                 'kernel_families': fam},
                       'roofline': None, 'cpu_baseline': None}), flush=True)
 
 
@@ -300,6 +369,41 @@ def memory_path_roofline(batch, size):
     return out
 
 
+PREC_NAMES = ('v_mfma_f32_32x32x2_f32', 'v_mfma_f32_32x32x16_bf16 on fp32 tiles rounded per fragment', 'v_mfma_f32_32x32x16_bf16 on bf16 tiles (bf16 operands in HBM)',
+              'v_mfma_f32_32x32x16_bf16 on bf16 LDS tiles rounded from gathered fp32 rows, ds_read_b64_tr_b16 fragments',
+              'v_mfma_f32_32x32x16_bf16 on bf16 LDS tiles gathered from bf16 activations, ds_read_b64_tr_b16 fragments',
+              'v_mfma_f32_32x32x16_bf16 on bf16 LDS tiles filled by global_load_lds (LDS-DMA), source-side XOR swizzle')
+
+
+def dominant_conv_kernel(K, bf16):
+    """The convolution-kernel instantiation with the largest total time among the launches recorded since the last clear (in-library HIP events, pm_profile_*):
+    -> ((ms, flops, launches), symbol, description) or None. conv_igemm_kernel<mode, bm, bn, wm, wn, km, prec, nst> (csrc/conv_igemm.hip) and, on the bf16 tier,
+    conv16_kernel<bm, bn, wm, wn, nst> (csrc/conv16.hip, recorded as mode 4 / prec 5)."""
+    best = None
+    for mode in ((0, 1, 2) if not bf16 else (0, 1, 2, 4)):
+        for bm in (128, 64):
+            for bn in (128, 64, 32):
+                for km in (0, 1, 2):
+                    for nst in (2, 1):
+                        for prec in ((0,) if not bf16 else ((5,) if mode == 4 else (2, 4, 3, 1))):
+                            r = K.profile_read(mode=mode, bm=bm, bn=bn, km=km, nst=nst, prec=prec)
+                            if r[2] and (best is None or r[0] > best[0][0]):
+                                best = (r, (mode, bm, bn, km, nst), prec)
+    if best is None:
+        return None
+    r, (mode, bm, bn, km, nst), kprec = best
+    if mode == 4:
+        sym = 'conv16_kernel<%d, %d, 2, 2, %d>' % (bm, bn, nst)
+        what = 'forward / stride-1 data gradient on bf16 activations, %dx%dx64 tile, %s, %s; FLOPs = 2*M*N*K executed' % (
+            bm, bn, 'two LDS stages' if nst == 2 else 'one LDS stage (single-K-step reductions)', PREC_NAMES[5])
+    else:
+        sym = 'conv_igemm_kernel<%d, %d, %d, %s, %d, %d, %d>' % (mode, bm, bn, '4, 1' if bn == 32 else '2, 2', km, kprec, nst)
+        what = '%s, %dx%dx32 tile, %s K-state, %s LDS, %s; direct convolutions and the batched Winograd F(4x4,3x3) / F(2x2,3x3) GEMMs; FLOPs = 2*M*N*K executed' % (
+            ('forward', 'data gradient', 'weight gradient')[mode], bm, bn, ('wave-uniform', 'per-lane', 'per-lane looping')[km],
+            'double-buffered' if nst == 2 else 'single-stage', PREC_NAMES[kprec])
+    return r, sym, what
+
+
 def free_port():
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
@@ -372,6 +476,8 @@ def main():
         return config5(a)
     if a.workload == 'meminit':
         return meminit(a)
+    if a.workload == 'mldg':
+        return mldg(a)
     if a.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(a.gpus, sys.argv[1:], timeout=a.launch_timeout))
     import torch
@@ -441,6 +547,8 @@ def main():
     for _ in range(a.warmup):
         step()
     prof = not a.no_profile
+    from pinthememory_amd.hip import ops as _ops
+    overlap_defaults = (_ops.OVERLAP_WGRAD, harness.COMMIT_OVERLAP)
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
@@ -488,27 +596,12 @@ def main():
         K.profile_enable(False)
         if os.environ.get('PM_PROFILE_DUMP'):
             K.profile_dump(os.environ['PM_PROFILE_DUMP'])
-        # dominant kernel = the conv_igemm_kernel instantiation with the largest total time in the serialised pass
-        best = None
-        for mode in (0, 1, 2):
-            for bm in (128, 64):
-                for bn in (128, 64, 32):
-                    for km in (0, 1, 2):
-                        for nst in (2, 1):
-                            for prec in ((0,) if not bf16 else (2, 4, 3, 1)):
-                                r = K.profile_read(mode=mode, bm=bm, bn=bn, km=km, nst=nst, prec=prec)
-                                if r[2] and (best is None or r[0] > best[0][0]):
-                                    best = (r, (mode, bm, bn, km, nst), prec)
+        # dominant kernel = the convolution-kernel instantiation with the largest total time in the serialised pass
+        best = dominant_conv_kernel(K, bf16)
         tot_ms, tot_fl, tot_n = K.profile_read(clear=True)
         if best:
-            (ms, fl, n), (mode, bm, bn, km, nst), kprec = best
+            (ms, fl, n), sym, what = best
             ach = fl / (ms * 1e-3) / 1e12
-            sym = 'conv_igemm_kernel<%d, %d, %d, %s, %d, %d, %d>' % (mode, bm, bn, '4, 1' if bn == 32 else '2, 2', km, kprec, nst)
-            what = '%s, %dx%dx32 tile, %s K-state, %s LDS, %s; direct convolutions and the batched Winograd F(4x4,3x3) / F(2x2,3x3) GEMMs; FLOPs = 2*M*N*K executed' % (
-                ('forward', 'data gradient', 'weight gradient')[mode], bm, bn, ('wave-uniform', 'per-lane', 'per-lane looping')[km],
-                'double-buffered' if nst == 2 else 'single-stage', ('v_mfma_f32_32x32x2_f32', 'v_mfma_f32_32x32x16_bf16 on fp32 tiles rounded per fragment', 'v_mfma_f32_32x32x16_bf16 on bf16 tiles (bf16 operands in HBM)',
-                                                                    'v_mfma_f32_32x32x16_bf16 on bf16 LDS tiles rounded from gathered fp32 rows, ds_read_b64_tr_b16 fragments',
-                                                                    'v_mfma_f32_32x32x16_bf16 on bf16 LDS tiles gathered from bf16 activations, ds_read_b64_tr_b16 fragments')[kprec])
             traffic, traffic_src = None, None      # HBM bytes per launch of that symbol, from the committed PMC passes of this command
             traffic_stale = None
             try:
@@ -530,6 +623,46 @@ def main():
                                          'launches_per_step': tot_n / prof_steps,
                                          'timed_region_overlapped': {'achieved': round(ov_fl / (ov_ms * 1e-3) / 1e12, 2), 'ms_per_step': round(ov_ms / ov_steps, 3),
                                                                      'measured': '%d untimed steps with the stream overlaps of the timed region (weight gradients on a side stream, commit forward of step t under the training forward of step t + 1)' % ov_steps}}}
+    side = None
+    if a.dtype == 'f32' and not multi and not a.no_side and edge is None:
+        # BASELINE configs[2] in the driver's own run: the SAME process, model and batch switched to the bf16 tier after the timed region -- a few untimed steps, a
+        # few timed ones (barrier-free single GPU: synchronize on both sides), then two serialised steps for its dominant kernel. Never part of `value`.
+        _ops.OVERLAP_WGRAD, harness.COMMIT_OVERLAP = overlap_defaults
+        K.set_conv_precision('bf16')
+        try:
+            s_warm, s_steps = 3, 5
+            for _ in range(s_warm):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(s_steps):
+                l16 = step()
+            torch.cuda.synchronize()
+            dt16 = time.perf_counter() - t1
+            side = {'bf16': {'workload': 'configs[2]: the same model, batch and agg train step on the bf16 tier (bf16 activations and activation gradients between layers, '
+                                         'bf16-MFMA convolutions with fp32 accumulation, fp32 statistics / losses / memory / parameters)',
+                             'ms_per_step': round(dt16 / s_steps * 1e3, 3), 'value': round(a.batch * s_steps / dt16, 3), 'unit': 'imgs/sec', 'steps': s_steps, 'warmup': s_warm,
+                             'final_loss': round(float(l16['total']), 5), 'dtype': 'bf16', 'measured': 'after the timed fp32 region of this run, same process'}}
+            if prof:
+                _ops.OVERLAP_WGRAD, harness.COMMIT_OVERLAP = False, False
+                torch.cuda.synchronize()
+                K.profile_enable(True)
+                for _ in range(2):
+                    step()
+                torch.cuda.synchronize()
+                K.profile_enable(False)
+                if os.environ.get('PM_PROFILE_DUMP'):
+                    K.profile_dump(os.environ['PM_PROFILE_DUMP'] + '.bf16')
+                b16 = dominant_conv_kernel(K, True)
+                t16_ms, t16_fl, t16_n = K.profile_read(clear=True)
+                if b16:
+                    (ms, fl, n), sym, what = b16
+                    side['bf16']['roofline'] = {'bound': 'mfma', 'kernel': '%s (%s)' % (sym, what), 'achieved': round(fl / (ms * 1e-3) / 1e12, 2), 'peak': PEAK_TFLOPS_BF16_MFMA,
+                                                'unit': 'TFLOP/s', 'frac': round(fl / (ms * 1e-3) / 1e12 / PEAK_TFLOPS_BF16_MFMA, 4), 'launches_per_step': n / 2,
+                                                'all_conv_kernels': {'achieved': round(t16_fl / (t16_ms * 1e-3) / 1e12, 2), 'ms_per_step': round(t16_ms / 2, 3)}}
+        finally:
+            K.set_conv_precision('f32')
+            _ops.OVERLAP_WGRAD, harness.COMMIT_OVERLAP = overlap_defaults
     if rank == 0:
         imgs = a.batch * world * a.steps
         gf_img = STEP_GFLOP_PER_IMG * (a.size / 768.0) ** 2      # conv FLOPs scale with the pixel count
@@ -551,6 +684,8 @@ def main():
                           'step_mfma_frac': round(gf_img * a.batch * world * a.steps / 1e3 / dt / (peak * world), 4),
                           'final_loss': round(float(losses['total']), 5)},
                'roofline': roof}
+        if side is not None:
+            out['side'] = side
         if edge is not None:
             out['config']['input_edge'] = edge
             out['data'] = 'synthetic, fresh uint8 batch from pinned host memory every step (PCIe-inclusive side measurement)'

@@ -176,6 +176,16 @@ def _wino_u(lib, xd, yd, p, w_krsc, dgrad=False):
     return None if valid else (ent, version)
 
 
+_XFORM_COUNT = [0, False]      # [convolution calls that had to derive a transformed filter (Winograd U / bf16 copy) instead of finding a kept one, counting on]
+
+
+def filter_transform_count(enable=None):
+    """Diagnostic (bench.py --workload mldg): number of forward convolutions that transformed their filter while counting was on."""
+    if enable is not None:
+        _XFORM_COUNT[1] = bool(enable)
+    return _XFORM_COUNT[0]
+
+
 def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, residual=None, relu=False, out=None, keep_v=None, bn_partials=None, out_dtype=None):
     """keep_v: a list; if this convolution and its weight gradient both take the Winograd route, the transformed input V is written
     to a fresh tensor that is appended to the list (else None is appended) -- pass it to conv_bwd_weight(wino_v=...).
@@ -199,6 +209,8 @@ def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, res
     u_ent = None
     if (kh == 3 and CONV_PREC == 0) or CONV_PREC == 2:
         u_ent = _wino_u(lib, xd, yd, p, w_krsc)        # (cache entry this call is about to (re)write, version to commit once the launch is enqueued) or None
+    if _XFORM_COUNT[1] and p.wxf_valid == 0 and lib.pm_conv_wxf_bytes(byref(xd), byref(yd), byref(p)):
+        _XFORM_COUNT[0] += 1      # this call transforms its filter
     nb = lib.pm_conv_workspace(byref(xd), byref(yd), byref(p), 0)
     ws = workspace(nb, x.device) if nb else None
     part = None

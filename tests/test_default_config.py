@@ -159,9 +159,11 @@ def test_default_config_agg_step_with_gumbel_and_dropout(env):
     assert abs(float(free['loss2']) - float(want['loss2'])) > 1e-5 or abs(float(free['loss1']) - float(want['loss1'])) > 1e-5
 
 
-def test_reference_init_gamma_one_eval_forward(env):
+def test_reference_init_gamma_one_eval_forward(env, capsys):
     """The reference's OWN initialisation (same torch seed -> the same init draws on both sides; BatchNorm gamma = 1, beta = 0, running moments
-    0 / 1 -- no damping of the residual branches): eval logits of configs[0]'s 1 x 3 x 256 x 256 input within 1e-3, argmax margin-gated."""
+    0 / 1 -- no damping of the residual branches): eval logits of configs[0]'s 1 x 3 x 256 x 256 input. With untrained BatchNorms in eval mode (identity) the
+    activations grow through the 16 residual blocks, so the logits are NOT O(1): the error is printed next to their scale, held to north_star's absolute 1e-3
+    when the scale is <= 1 and to 1e-3 of the scale otherwise (the reader sees what was met)."""
     synth = env['synth']
     args = synth.model_args()
     torch.manual_seed(304)
@@ -178,7 +180,56 @@ def test_reference_init_gamma_one_eval_forward(env):
         want, got = ref(x), net(x.cuda())
     lg = got[0].cpu()
     scale = want[0].abs().max().item()
-    assert (lg - want[0]).abs().max().item() < LOGIT_TOL * max(1.0, scale), ((lg - want[0]).abs().max().item(), scale)
+    err = (lg - want[0]).abs().max().item()
+    with capsys.disabled():
+        print('\n[reference init, gamma = 1, eval 1x3x256^2] max |logit err| %.3e, logit scale (max |logit|) %.3e -> %.2e of the scale; absolute bar 1e-3 %s'
+              % (err, scale, err / max(scale, 1e-30), 'met' if err < LOGIT_TOL else 'NOT met (bar relative to the scale applies)'))
+    assert err < LOGIT_TOL * max(1.0, scale), (err, scale)
     ok, frac = argmax_gate(lg, want[0], tol=LOGIT_TOL * max(1.0, scale))
     assert ok, frac
     assert (got[1][1].cpu() - want[1][1]).abs().max().item() < 1e-4
+
+
+def test_reference_init_gamma_one_train_step_three_way(env, capsys):
+    """A TRAINING step on the reference's own initialisation (gamma = 1 on every BatchNorm, no damping): train-mode forward + every parameter gradient, HIP vs
+    the fp64 oracle vs the fp32 oracle. At this initialisation a train-mode ResNet is chaotic (an fp32 round-off grows ~1.35 x per block, ReLU masks flip:
+    tools/grad_conditioning.py measured the reference's OWN fp32 gradients 35 % (median) from fp64), so fixed bounds mean nothing; the criterion is the
+    three-way one of test_train_forward_backward_vs_oracle: the HIP path is never further from the fp64 truth than a small multiple of the reference's own
+    fp32 arithmetic -- losses individually, gradients in the median and at the 90th percentile of the per-tensor error ratio."""
+    import copy
+    synth, o_h, h = env['synth'], env['o_harness'], env['harness']
+    args = synth.model_args()
+    x, y = synth.make_batch(2, 128)
+
+    def grads(net, xx, yy, hh):
+        net.dsn[3].p = 0.0
+        net.train()
+        out = net(xx, gts=yy, aux_gts=yy, memory_writing=True, writing_detach=False)
+        hh.total_loss(out).backward()
+        return ([out[0].detach().double().cpu(), out[1].detach().double().cpu(), out[-2].detach().double().cpu()],
+                {k: v.grad.detach().double().cpu() for k, v in net.named_parameters() if v.grad is not None})
+    torch.manual_seed(304)
+    ref32 = env['o_deeplab'].DeepR50V3PlusD(args, 19, CRIT, CRIT)
+    ref64 = copy.deepcopy(ref32).double()
+    ref64.memory.m_items = ref64.memory.m_items.double()
+    torch.manual_seed(304)
+    net = env['deepv3plus'].DeepR50V3PlusD(args, 19, CRIT, CRIT).cuda()
+    l64, g64 = grads(ref64, x.double(), y, o_h)
+    l32, g32 = grads(ref32, x, y, o_h)
+    lh, gh = grads(net, x.cuda(), y.cuda(), h)
+    for a, b, c in zip(lh, l32, l64):
+        assert abs(a.item() - c.item()) <= 4 * abs(b.item() - c.item()) + 1e-5 * max(1.0, abs(c.item())), (a.item(), b.item(), c.item())
+    ratios, eh_all, eo_all = [], [], []
+    for k, t in g64.items():
+        if t.norm().item() < 1e-7:
+            continue
+        e_h = (gh[k] - t).norm().item() / t.norm().item()
+        e_o = (g32[k] - t).norm().item() / t.norm().item()
+        ratios.append(e_h / max(e_o, 1e-7))
+        eh_all.append(e_h), eo_all.append(e_o)
+    ratios.sort(), eh_all.sort(), eo_all.sort()
+    med, p90 = ratios[len(ratios) // 2], ratios[int(len(ratios) * 0.9)]
+    with capsys.disabled():
+        print('\n[reference init, gamma = 1, train fwd+bwd 2x128^2] gradient error vs fp64: hip median %.3e / max %.3e, fp32 oracle median %.3e / max %.3e; '
+              'per-tensor ratio hip / fp32-oracle: median %.2f, 90th percentile %.2f' % (eh_all[len(eh_all) // 2], eh_all[-1], eo_all[len(eo_all) // 2], eo_all[-1], med, p90))
+    assert med < 2.0 and p90 < 4.0, (med, p90)

@@ -514,6 +514,65 @@ def test_config2_production_size_step_vs_oracle(env, capsys):
     assert st[0][0] < 1e-4, st[:6]
 
 
+def test_config2_headline_size_bs8_step_vs_oracle(env, capsys):
+    """BASELINE configs[1] at EXACTLY the size the metric is quoted on: one agg iteration at bs=8, 768 x 768 on the HIP path against the
+    CPU oracle's fp32 step of the same batch (~20 s and ~20 GB on the box's host cores): five losses 2e-4, committed memory 1e-4, every post-step
+    parameter / buffer 1e-4 of its norm."""
+    import os
+    if (os.cpu_count() or 1) < 8:
+        pytest.skip('the bs=8 768^2 oracle step needs the GPU box\'s host cores')
+    synth = env['synth']
+    x, y = synth.make_batch(8, 768)
+    hip = _hip(env, x, y, True)
+    torch.set_num_threads(min(32, os.cpu_count() or 8))      # torch's CPU convolutions are fastest at 16-32 threads on the pool's hosts (bench.py cpu_baseline)
+    o32 = _oracle(env, torch.float32, x, y, True)
+    for k, t in o32['losses'].items():
+        assert abs(hip['losses'][k].item() - t.item()) < 2e-4 * max(1.0, abs(t.item())), (k, hip['losses'][k].item(), t.item())
+    dm = (hip['m_items'] - o32['m_items']).abs().max().item()
+    st = _grad_stats(hip, o32, 'state')
+    with capsys.disabled():
+        print('\n[bs=8 768^2 step] losses %s; max|m_items - oracle| %.2e; worst post-step state rel. errors %s'
+              % ({k: round(v.item(), 5) for k, v in hip['losses'].items()}, dm, [(round(e, 6), k) for e, k in st[:4]]))
+    assert dm < 1e-4, dm
+    assert st[0][0] < 1e-4, st[:6]
+
+
+def test_config3_bf16_tier_production_size_step_vs_oracle(env, capsys):
+    """BASELINE configs[2] at the production crop: the bf16 tier (bf16 activations and activation gradients, bf16 MFMA, fp32 statistics /
+    losses / memory / parameters) against the fp32 CPU oracle at bs=2, 768 x 768 -- eval logits within 0.5 % of their range with the class map identical
+    wherever the oracle's top-2 margin exceeds 0.1; one agg train step: five losses within 1 %, the committed memory within 2e-2."""
+    from pinthememory_amd.hip import kernels as K
+    synth = env['synth']
+    args = synth.model_args()
+    x, y = synth.make_batch(2, 768)
+    ref = synth.load_det_weights(env['o_deeplab'].DeepR50V3PlusD(args, 19, CRIT, CRIT)).eval()
+    with torch.no_grad():
+        want = ref(x[:1])[0]
+    o32 = _oracle(env, torch.float32, x, y, True)
+    K.set_conv_precision('bf16')
+    try:
+        net = synth.load_det_weights(env['deepv3plus'].DeepR50V3PlusD(args, 19, CRIT, CRIT)).cuda().eval()
+        with torch.no_grad():
+            got = net(x[:1].cuda())[0].cpu()
+        hip = _hip(env, x, y, True)
+    finally:
+        K.set_conv_precision('f32')
+    scale = (want.max() - want.min()).item()
+    err = (got - want).abs().max().item()
+    top2 = want.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 0.1
+    with capsys.disabled():
+        print('\n[bf16 tier 768^2] eval: max |logit err| %.3e = %.2e of the logit range %.2f, argmax agreement %.5f (safe fraction %.3f); step losses %s vs fp32 oracle %s; '
+              'max|m_items - oracle| %.2e' % (err, err / scale, scale, (got.argmax(1) == want.argmax(1)).float().mean().item(), safe.float().mean().item(),
+                                              {k: round(v.item(), 4) for k, v in hip['losses'].items()}, {k: round(v.item(), 4) for k, v in o32['losses'].items()},
+                                              (hip['m_items'] - o32['m_items']).abs().max().item()))
+    assert err < 5e-3 * scale, (err, scale)
+    assert (got.argmax(1)[safe] == want.argmax(1)[safe]).all() and safe.float().mean().item() > 0.5
+    for k, t in o32['losses'].items():
+        assert abs(hip['losses'][k].item() - t.item()) < 1e-2 * max(1.0, abs(t.item())), (k, hip['losses'][k].item(), t.item())
+    assert (hip['m_items'] - o32['m_items']).abs().max().item() < 2e-2
+
+
 def test_config2_production_size_eval_vs_oracle(env):
     synth = env['synth']
     args = synth.model_args()
