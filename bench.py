@@ -165,7 +165,7 @@ def mldg(a):
         if os.environ.get('PM_PROFILE_DUMP'):
             K.profile_dump(os.environ['PM_PROFILE_DUMP'])
         fam = {}
-        for name, mode in (('forward + stride-1 data-gradient convolutions', 0), ('stride-2 data gradients', 1), ('weight gradients', 2), ('LDS-DMA bf16 convolutions', 4)):
+        for name, mode in (('forward-form kernel (fp32: forward + Winograd GEMMs; bf16: forward + stride-1 data gradients, register-staged)', 0), ('data-gradient-form kernel (fp32: direct data gradients; bf16: stride-2 only)', 1), ('weight gradients', 2), ('LDS-DMA bf16 convolutions (forward + stride-1 data gradients)', 4)):
             ms, fl, n = K.profile_read(mode=mode)
             if n:
                 fam[name] = {'ms_per_step': round(ms / 2, 3), 'launches_per_step': n / 2, 'achieved_TFLOPs': round(fl / (ms * 1e-3) / 1e12, 1)}

@@ -210,6 +210,7 @@ x, y = synth.make_batch(2, 128)
 x, y = x.cuda(), y.cuda()
 for _ in range(2):
     out = harness.agg_train_step(net, opt, x, y, sched=sched, buckets=buckets)
+harness.finish_commit(net)          # every rank: the memory commit of the last step is finished explicitly (an attribute read never hides a collective)
 torch.cuda.synchronize()
 h = hashlib.sha256()
 core = net.module if hasattr(net, 'module') else net
