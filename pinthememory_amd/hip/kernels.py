@@ -169,10 +169,11 @@ def _wino_u(lib, xd, yd, p, w_krsc, dgrad=False):
         ent[1] = -1                     # invalid until the launch that fills it has been enqueued (conv_fwd commits the version after check())
     _U_CACHE[key] = ent
     p.wxf, p.wxf_bytes, p.wxf_valid = ent[2].data_ptr(), nbu, 1 if valid else 0
-    cur = torch.cuda.current_stream()
-    _U_STREAMS.setdefault(cur.cuda_stream, cur)
-    if valid and ent[3] is not None and ent[4] != cur.cuda_stream:
-        cur.wait_event(ent[3])          # the transform was written by a launch on another stream (harness: the commit forward runs on its own)
+    raw = stream()
+    if raw not in _U_STREAMS:
+        _U_STREAMS[raw] = torch.cuda.current_stream()
+    if valid and ent[3] is not None and ent[4] != raw:
+        _U_STREAMS[raw].wait_event(ent[3])          # the transform was written by a launch on another stream (harness: the commit forward runs on its own)
     return None if valid else (ent, version)
 
 
