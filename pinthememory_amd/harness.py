@@ -60,9 +60,12 @@ COMMIT_OVERLAP = __import__('os').environ.get('PM_COMMIT_OVERLAP', '1') == '1'
 _commit_streams = {}
 
 
+COMMIT_CUS = int(__import__('os').environ.get('PM_COMMIT_CUS', '0'))      # A/B knob: confine the commit forward's stream to n CUs (ops.masked_stream)
+
+
 def _commit_stream(device):
     if device.index not in _commit_streams:
-        _commit_streams[device.index] = torch.cuda.Stream(device=device)
+        _commit_streams[device.index] = ops.masked_stream(COMMIT_CUS, device.index, first=1) if COMMIT_CUS > 0 else torch.cuda.Stream(device=device)
     return _commit_streams[device.index]
 
 

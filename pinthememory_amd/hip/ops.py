@@ -81,10 +81,36 @@ _side = {}
 _proxy = {}            # id(weight tensor) -> deferred proxy, valid for the current forward only
 
 
+def masked_stream(n_cus, device=None, first=0):
+    """A HIP stream whose kernels may only run on `n_cus` of the 256 CUs (hipExtStreamCreateWithCUMask through ctypes on the process's libamdhip64, wrapped as a
+    torch ExternalStream) -- VERDICT r3 item 2a: a side stream that owns a fixed CU set instead of alternating whole-GPU kernels with the main stream. The mask
+    takes every (256 / n_cus)-th CU starting at `first`, so the set is spread evenly over the 8 XCDs / 32 shader engines."""
+    import ctypes
+    dev = torch.cuda.current_device() if device is None else device
+    total = torch.cuda.get_device_properties(dev).multi_processor_count
+    n_cus = max(1, min(int(n_cus), total))
+    words = (total + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    picked = {(first + (i * total) // n_cus) % total for i in range(n_cus)}
+    for cu in picked:
+        mask[cu // 32] |= 1 << (cu % 32)
+    hip = ctypes.CDLL('libamdhip64.so')
+    st = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        err = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(words), mask)
+    if err != 0 or not st.value:
+        raise RuntimeError('hipExtStreamCreateWithCUMask(%d CUs) failed: %d' % (n_cus, err))
+    return torch.cuda.ExternalStream(st.value, device=dev)
+
+
+# PM_WGRAD_CUS=n: the weight-gradient side stream is confined to n CUs (A/B knob; default: an ordinary stream sharing all 256 with the main stream)
+WGRAD_CUS = int(_os.environ.get('PM_WGRAD_CUS', '0'))
+
+
 def _side_stream():
     dev = torch.cuda.current_device()
     if dev not in _side:
-        _side[dev] = torch.cuda.Stream(device=dev)
+        _side[dev] = masked_stream(WGRAD_CUS, dev) if WGRAD_CUS > 0 else torch.cuda.Stream(device=dev)
     return _side[dev]
 
 
