@@ -141,15 +141,13 @@ def _evict(ent):
             ent[2].record_stream(s)
 
 
-def _wino_u(lib, xd, yd, p, w_krsc, dgrad=False):
-    """dgrad: (xd, yd) = (dy, dx) of a data gradient on the bf16 tier -- the kept transform is the rotated / transposed bf16 filter."""
-    if KEEP_WINOGRAD_U is False:
+def _wino_u(p, w_krsc, nbu, dgrad=False):
+    """nbu: bytes of the transformed filter of this call (pm_conv_wxf_bytes / _dgrad; 0: none). dgrad: the kept transform is the rotated / transposed bf16 filter
+    of a data gradient on the bf16 tier."""
+    if KEEP_WINOGRAD_U is False or not nbu:
         return None
     owner = _filter_owner(w_krsc)
     if owner is None and KEEP_WINOGRAD_U is not True:
-        return None
-    nbu = (lib.pm_conv_wxf_bytes_dgrad if dgrad else lib.pm_conv_wxf_bytes)(byref(xd), byref(yd), byref(p))
-    if not nbu:
         return None
     import weakref
     key = (w_krsc.data_ptr(), tuple(w_krsc.shape), nbu, w_krsc.device.index, p.prec, dgrad)
@@ -171,10 +169,25 @@ def _wino_u(lib, xd, yd, p, w_krsc, dgrad=False):
     p.wxf, p.wxf_bytes, p.wxf_valid = ent[2].data_ptr(), nbu, 1 if valid else 0
     raw = stream()
     if raw not in _U_STREAMS:
-        _U_STREAMS[raw] = torch.cuda.current_stream()
+        _U_STREAMS[raw] = L.stream_obj()
     if valid and ent[3] is not None and ent[4] != raw:
         _U_STREAMS[raw].wait_event(ent[3])          # the transform was written by a launch on another stream (harness: the commit forward runs on its own)
     return None if valid else (ent, version)
+
+
+# Size queries of the convolution entry points (workspace, kept Winograd V, transformed filter, statistics partials) depend on shapes and on the library's
+# process-wide switches only: asked once per distinct call signature instead of three ctypes round trips per launch (the bf16 tier is host-bound).
+_SIZES = {}
+_GEN = [0]      # bumped by every switch that changes the library's routing (set_winograd, set_conv16, ...)
+
+
+def _sizes(key, fn):
+    v = _SIZES.get(key)
+    if v is None:
+        if len(_SIZES) > 8192:
+            _SIZES.clear()
+        v = _SIZES[key] = fn()
+    return v
 
 
 _XFORM_COUNT = [0, False]      # [convolution calls that had to derive a transformed filter (Winograd U / bf16 copy) instead of finding a kept one, counting on]
@@ -201,22 +214,24 @@ def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, res
     xd, yd = tdesc(x), tdesc(y)
     p = L.conv_params(kh, kw, stride, pad, dil, CONV_PREC)
     lib = _lib()
+    nbv, nbu, nb, npb = _sizes(('f', x.shape, x.stride(), x.dtype, xd.flags, w_krsc.shape, y.stride(), y.dtype, stride, pad, dil, CONV_PREC, _GEN[0]),
+                               lambda: (lib.pm_conv_winograd_v_bytes(byref(xd), byref(yd), byref(p)), lib.pm_conv_wxf_bytes(byref(xd), byref(yd), byref(p)),
+                                        lib.pm_conv_workspace(byref(xd), byref(yd), byref(p), 0), lib.pm_conv_bn_partials_bytes(byref(xd), byref(yd), byref(p))))
     if keep_v is not None:
-        nbv = lib.pm_conv_winograd_v_bytes(byref(xd), byref(yd), byref(p)) if KEEP_WINOGRAD_V else 0
+        nbv = nbv if KEEP_WINOGRAD_V else 0
         v = torch.empty(nbv // 4, dtype=torch.float32, device=x.device) if nbv else None
         keep_v.append(v)
         if v is not None:
             p.wino_v, p.wino_v_bytes = v.data_ptr(), nbv
     u_ent = None
     if (kh == 3 and CONV_PREC == 0) or CONV_PREC == 2:
-        u_ent = _wino_u(lib, xd, yd, p, w_krsc)        # (cache entry this call is about to (re)write, version to commit once the launch is enqueued) or None
-    if _XFORM_COUNT[1] and p.wxf_valid == 0 and lib.pm_conv_wxf_bytes(byref(xd), byref(yd), byref(p)):
+        u_ent = _wino_u(p, w_krsc, nbu)        # (cache entry this call is about to (re)write, version to commit once the launch is enqueued) or None
+    if _XFORM_COUNT[1] and p.wxf_valid == 0 and nbu:
         _XFORM_COUNT[0] += 1      # this call transforms its filter
-    nb = lib.pm_conv_workspace(byref(xd), byref(yd), byref(p), 0)
     ws = workspace(nb, x.device) if nb else None
     part = None
     if bn_partials is not None:
-        npb = lib.pm_conv_bn_partials_bytes(byref(xd), byref(yd), byref(p)) if (BN_EPILOGUE and residual is None and not relu) else 0
+        npb = npb if (BN_EPILOGUE and residual is None and not relu) else 0
         part = torch.empty(npb // 4, dtype=torch.float32, device=x.device) if npb else None
         bn_partials.append(part)
     ep = None
@@ -227,7 +242,7 @@ def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, res
     check(lib.pm_conv_fwd(byref(xd), w_krsc.data_ptr(), byref(yd), byref(p), byref(ep) if ep else None, ptr(ws), nb, stream()), 'pm_conv_fwd')
     if u_ent is not None:               # the launch is enqueued: only now is the kept transform valid; hits from another stream wait for this event
         ent, version = u_ent
-        cur = torch.cuda.current_stream()
+        cur = L.stream_obj()
         ent[3], ent[4] = cur.record_event(), cur.cuda_stream
         ent[1] = version
     return y
@@ -240,20 +255,22 @@ def conv_bwd_data(dy, w_krsc, x_shape, stride, pad, dil, add=None, dtype=None):
     dyd, dxd = tdesc(dy), tdesc(dx)
     p = L.conv_params(kh, kw, stride, pad, dil, CONV_PREC)
     lib = _lib()
-    nb = lib.pm_conv_workspace(byref(dxd), byref(dyd), byref(p), 1)
+    nb, nbu = _sizes(('d', dy.shape, dy.stride(), dy.dtype, dyd.flags, w_krsc.shape, dx.shape, dx.stride(), dx.dtype, stride, pad, dil, CONV_PREC, _GEN[0]),
+                     lambda: (lib.pm_conv_workspace(byref(dxd), byref(dyd), byref(p), 1), lib.pm_conv_wxf_bytes_dgrad(byref(dyd), byref(dxd), byref(p))))
     ws = workspace(nb, dy.device) if nb else None
     ad = tdesc(add) if add is not None else None
-    u_ent = _wino_u(lib, dyd, dxd, p, w_krsc, dgrad=True) if CONV_PREC == 2 else None      # bf16 tier: the rotated bf16 filter is kept per weight version
+    u_ent = _wino_u(p, w_krsc, nbu, dgrad=True) if CONV_PREC == 2 else None      # bf16 tier: the rotated bf16 filter is kept per weight version
     check(lib.pm_conv_bwd_data(byref(dyd), w_krsc.data_ptr(), byref(dxd), byref(p), byref(ad) if ad else None, ptr(ws), nb, stream()), 'pm_conv_bwd_data')
     if u_ent is not None:
         ent, version = u_ent
-        cur = torch.cuda.current_stream()
+        cur = L.stream_obj()
         ent[3], ent[4] = cur.record_event(), cur.cuda_stream
         ent[1] = version
     return dx
 
 
-def conv_bwd_weight(x, dy, w_shape_krsc, stride, pad, dil, want_bias=False, wino_v=None):
+def conv_bwd_weight(x, dy, w_shape_krsc, stride, pad, dil, want_bias=False, wino_v=None, on_stream=None):
+    """on_stream: launch on that torch stream instead of the current one (the caller orders it and tells the allocator: ops._wgrad)."""
     cout, kh, kw, cin = w_shape_krsc
     dw = torch.empty(w_shape_krsc, dtype=torch.float32, device=x.device)
     db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_bias else None
@@ -262,9 +279,11 @@ def conv_bwd_weight(x, dy, w_shape_krsc, stride, pad, dil, want_bias=False, wino
     if wino_v is not None:       # Winograd-transformed x kept by conv_fwd(keep_v=...)
         p.wino_v, p.wino_v_bytes = wino_v.data_ptr(), wino_v.numel() * 4
     lib = _lib()
-    nb = lib.pm_conv_workspace(byref(xd), byref(dyd), byref(p), 2)
-    ws = workspace(nb, x.device)
-    check(lib.pm_conv_bwd_weight(byref(xd), byref(dyd), dw.data_ptr(), ptr(db), byref(p), ptr(ws), nb, stream()), 'pm_conv_bwd_weight')
+    nb = _sizes(('w', x.shape, x.stride(), x.dtype, dy.shape, dy.stride(), dy.dtype, w_shape_krsc, stride, pad, dil, CONV_PREC, wino_v is not None, _GEN[0]),
+                lambda: lib.pm_conv_workspace(byref(xd), byref(dyd), byref(p), 2))
+    raw = stream() if on_stream is None else on_stream.cuda_stream
+    ws = workspace(nb, x.device, on_stream)
+    check(lib.pm_conv_bwd_weight(byref(xd), byref(dyd), dw.data_ptr(), ptr(db), byref(p), ptr(ws), nb, raw), 'pm_conv_bwd_weight')
     return dw, db
 
 
@@ -275,7 +294,7 @@ def bn_stats(x):
     mom = torch.empty(3 * c, dtype=torch.float32, device=x.device)
     xd = tdesc(x)
     lib = _lib()
-    nb = lib.pm_bn_workspace(byref(xd))
+    nb = _sizes(('bn', x.shape, x.dtype), lambda: lib.pm_bn_workspace(byref(xd)))
     ws = workspace(nb, x.device)
     check(lib.pm_bn_stats(byref(xd), mom.data_ptr(), ptr(ws), nb, stream()), 'pm_bn_stats')
     return mom
@@ -288,7 +307,7 @@ def bn_stats_finalize(x, eps, running_mean=None, running_var=None, momentum=0.1)
     invstd = torch.empty_like(mean)
     xd = tdesc(x)
     lib = _lib()
-    nb = lib.pm_bn_workspace(byref(xd))
+    nb = _sizes(('bn', x.shape, x.dtype), lambda: lib.pm_bn_workspace(byref(xd)))
     ws = workspace(nb, x.device)
     check(lib.pm_bn_stats_finalize(byref(xd), eps, mean.data_ptr(), invstd.data_ptr(), ptr(running_mean), ptr(running_var), momentum, ptr(ws), nb, stream()),
           'pm_bn_stats_finalize')
@@ -370,7 +389,7 @@ def bn_bwd_reduce_mask(dy, mask, x, mean, invstd, want_gmask=True, with_count=Fa
         sums[2 * c:].fill_(float(x.shape[0] * x.shape[1] * x.shape[2]))
     xd = tdesc(x)
     lib = _lib()
-    nb = lib.pm_bn_workspace(byref(xd))
+    nb = _sizes(('bn', x.shape, x.dtype), lambda: lib.pm_bn_workspace(byref(xd)))
     ws = workspace(nb, x.device)
     gm = torch.empty(x.shape, dtype=x.dtype, device=x.device) if want_gmask else None
     gd = tdesc(gm) if want_gmask else None
@@ -398,7 +417,7 @@ def bn_bwd_reduce(dy, y, x, mean, invstd, relu, gamma=None, beta=None, want_gmas
         sums[2 * c:].fill_(float(x.shape[0] * x.shape[1] * x.shape[2]))
     xd = tdesc(x)
     lib = _lib()
-    nb = lib.pm_bn_workspace(byref(xd))
+    nb = _sizes(('bn', x.shape, x.dtype), lambda: lib.pm_bn_workspace(byref(xd)))
     ws = workspace(nb, x.device)
     yd = tdesc(y) if relu == 1 else None
     gm = torch.empty(x.shape, dtype=x.dtype, device=x.device) if want_gmask else None
@@ -703,20 +722,24 @@ def set_winograd(mode):
     """Winograd route of the wide stride-1 3x3 convs: 4 / True = prefer F(4x4,3x3) (default), 2 = F(2x2,3x3) only, 0 / False = direct."""
     mode = 4 if mode is True else (0 if mode is False else int(mode))
     check(_lib().pm_set_winograd(mode), 'pm_set_winograd')
+    _GEN[0] += 1
 
 
 def set_winograd_fused(on):
     """F(4x4) layers: GEMMs + output transform in one kernel (opt-in; slower than the two-pass form on the flagship layers)."""
     check(_lib().pm_set_winograd_fused(1 if on else 0), 'pm_set_winograd_fused')
+    _GEN[0] += 1
 
 
 def set_conv16(on):
     """bf16 tier, forward / stride-1 data gradient: 1 = per shape (default: the LDS-DMA kernel where it wins), 2 = LDS-DMA everywhere, 0 = register-staged everywhere."""
     check(_lib().pm_set_conv16(int(on)), 'pm_set_conv16')
+    _GEN[0] += 1
 
 
 def set_bf16_wgrad(on):
     check(_lib().pm_set_bf16_wgrad(1 if on else 0), 'pm_set_bf16_wgrad')
+    _GEN[0] += 1
 
 
 def profile_enable(on):

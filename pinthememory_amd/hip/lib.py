@@ -179,37 +179,61 @@ def register_zero_pad(base, c, pitch):
     _ZERO_PAD[base.data_ptr()] = (weakref.ref(base), c, pitch)
 
 
+_TD = {}      # (shape, stride, dtype) -> (n, h, w, c, pitch, dtype code): the layout checks of a view run once per distinct layout, not once per launch
+
+
 def tdesc(t):
     """pm_tensor view of a torch tensor shaped [N,H,W,C] (channels innermost; may be a channel slice of a wider buffer); fp32 or bf16."""
-    assert t.dim() == 4 and t.dtype in (torch.float32, torch.bfloat16) and t.is_cuda, 'expected a CUDA fp32 / bf16 NHWC tensor, got %s %s' % (tuple(t.shape), t.dtype)
-    n, h, w, c = t.shape
-    sn, sh, sw, sc = t.stride()
-    # size-1 dims carry arbitrary strides in torch: take the pixel pitch from the innermost spatial dim that is > 1
-    pitch = sw if w > 1 else (sh if h > 1 else (sn if n > 1 else c))
-    assert (sc == 1 or c == 1) and pitch >= c, 'channels must be innermost: shape %s stride %s' % (tuple(t.shape), t.stride())
-    assert (h == 1 or w == 1 or sh == w * pitch) and (n == 1 or h * w == 1 or sn == h * w * pitch), \
-        'not an NHWC view: shape %s stride %s' % (tuple(t.shape), t.stride())
-    if t.dtype == torch.float32:
-        return PmTensor(t.data_ptr(), n, h, w, c, pitch, PM_F32, 0)
+    key = (t.shape, t.stride(), t.dtype)
+    m = _TD.get(key)
+    if m is None:
+        assert t.dim() == 4 and t.dtype in (torch.float32, torch.bfloat16) and t.is_cuda, 'expected a CUDA fp32 / bf16 NHWC tensor, got %s %s' % (tuple(t.shape), t.dtype)
+        n, h, w, c = t.shape
+        sn, sh, sw, sc = t.stride()
+        # size-1 dims carry arbitrary strides in torch: take the pixel pitch from the innermost spatial dim that is > 1
+        pitch = sw if w > 1 else (sh if h > 1 else (sn if n > 1 else c))
+        assert (sc == 1 or c == 1) and pitch >= c, 'channels must be innermost: shape %s stride %s' % (tuple(t.shape), t.stride())
+        assert (h == 1 or w == 1 or sh == w * pitch) and (n == 1 or h * w == 1 or sn == h * w * pitch), \
+            'not an NHWC view: shape %s stride %s' % (tuple(t.shape), t.stride())
+        if len(_TD) > 4096:
+            _TD.clear()
+        m = _TD[key] = (n, h, w, c, pitch, PM_F32 if t.dtype == torch.float32 else PM_BF16)
+    assert t.is_cuda
+    if m[5] == PM_F32 or m[3] % 64 == 0:
+        return PmTensor(t.data_ptr(), m[0], m[1], m[2], m[3], m[4], m[5], 0)
     flags = 0
-    if c % 64:
-        z = _ZERO_PAD.get(t.data_ptr())
-        if z is not None and z[0]() is not None and z[1] == c and z[2] == pitch:
-            flags = PM_TF_ZERO_PAD64
-    return PmTensor(t.data_ptr(), n, h, w, c, pitch, PM_BF16, flags)
+    z = _ZERO_PAD.get(t.data_ptr())
+    if z is not None and z[0]() is not None and z[1] == m[3] and z[2] == m[4]:
+        flags = PM_TF_ZERO_PAD64
+    return PmTensor(t.data_ptr(), m[0], m[1], m[2], m[3], m[4], m[5], flags)
 
 
 _ws = {}
 
 
-def workspace(nbytes, device):
-    """Grow-only scratch buffer per (device, stream); kernels on one stream are ordered, so reuse is safe."""
-    key = (device.index, stream())
+def workspace(nbytes, device, on_stream=None):
+    """Grow-only scratch buffer per (device, stream); kernels on one stream are ordered, so reuse is safe. on_stream: the torch stream the launch goes to when
+    that is not the current one (the weight-gradient side stream): the buffer comes from the current stream's pool, so the allocator is told who really uses it."""
+    key = (device.index, stream() if on_stream is None else on_stream.cuda_stream)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        if on_stream is not None:
+            buf.record_stream(on_stream)
         _ws[key] = buf
     return buf
+
+
+_stream_objs = {}
+
+
+def stream_obj():
+    """torch.cuda.current_stream() without its per-call device bookkeeping: the Stream object is cached per raw handle."""
+    raw = stream()
+    s = _stream_objs.get(raw)
+    if s is None:
+        s = _stream_objs[raw] = torch.cuda.current_stream()
+    return s
 
 
 def ptr(t):

@@ -7,6 +7,7 @@ import os as _os
 import torch
 
 from . import kernels as K
+from . import lib as L
 from .. import dist as D
 
 
@@ -121,7 +122,7 @@ class _Defer(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        torch.cuda.current_stream().wait_stream(_side_stream())
+        L.stream_obj().wait_stream(_side_stream())
         return g
 
 
@@ -148,17 +149,20 @@ def _w(weight):
 def _wgrad(x, dy, wshape, geom, want_bias=False, deferred=False, wino_v=None):
     if not deferred:
         return K.conv_bwd_weight(x, dy, wshape, *geom, want_bias=want_bias, wino_v=wino_v)
-    side = _side_stream()
+    # on the side stream, behind everything the main stream has enqueued so far; the launch takes the stream explicitly (no torch.cuda.stream() context: its
+    # enter / exit cost 10 us per weight gradient on a host-bound step). Outputs are allocated by the main stream's pool and first written on the side stream.
+    side, main = _side_stream(), L.stream_obj()
     ev = torch.cuda.Event()
-    ev.record()
-    with torch.cuda.stream(side):
-        side.wait_event(ev)
-        out = K.conv_bwd_weight(x, dy, wshape, *geom, want_bias=want_bias, wino_v=wino_v)
+    ev.record(main)
+    side.wait_event(ev)
+    out = K.conv_bwd_weight(x, dy, wshape, *geom, want_bias=want_bias, wino_v=wino_v, on_stream=side)
     if wino_v is not None:
         wino_v.record_stream(side)
     x.record_stream(side)
     dy.record_stream(side)
-    out[0].record_stream(torch.cuda.current_stream())
+    for t in out:
+        if t is not None:
+            t.record_stream(side)
     return out
 
 
