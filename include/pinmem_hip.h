@@ -304,6 +304,9 @@ typedef struct pm_sgd_entry {
   int64_t numel;
 } pm_sgd_entry;
 int pm_sgd_momentum_multi(const pm_sgd_entry* entries, int n, float lr, float momentum, float weight_decay, void* stream);
+/* the same with the learning rate read from device memory when lr_dev != NULL (one float; `lr` is then ignored): a training step captured in a hipGraph follows
+ * the LR schedule by a 4-byte write before each replay instead of a re-capture (harness.GraphedAggStep). */
+int pm_sgd_momentum_multi_dev(const pm_sgd_entry* entries, int n, float lr, const float* lr_dev, float momentum, float weight_decay, void* stream);
 
 #ifdef __cplusplus
 }

@@ -381,11 +381,17 @@ inline FusedPlan fused_plan(const CEGeom& g) {
 constexpr size_t FUSED_MAX_LDS = 159 * 1024;   // dynamic part; the kernel also declares 160 B of static LDS
 template <int CC, int PP, bool WITH_T>
 void fused_launch_one(const CEGeom& g, const FusedPlan& p, float* part, float* T, hipStream_t st) {
-  static const bool attr_set = [] {   // > 64 KB of dynamic LDS (logit rows wider than ~420 pixels x 19 classes) needs an explicit opt-in, once per kernel
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ce_fused_rows_kernel<CC, PP, WITH_T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_MAX_LDS);
-    return true;
-  }();
-  (void)attr_set;
+  // > 64 KB of dynamic LDS (logit rows wider than ~420 pixels x 19 classes) needs an explicit opt-in, once per kernel AND device (the guard
+  // used to cover the first device of a multi-device process only, and dropped the call's status)
+  static bool attr_set[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ce_fused_rows_kernel<CC, PP, WITH_T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_MAX_LDS) != hipSuccess)
+      (void)hipGetLastError();      // the launch below then fails with its own error for rows beyond 64 KB
+    else
+      attr_set[dev] = true;
+  }
   hipLaunchKernelGGL((ce_fused_rows_kernel<CC, PP, WITH_T>), dim3(g.n * g.H), dim3(p.threads), p.lds, st, g, part, T);
 }
 template <bool WITH_T>
@@ -411,8 +417,12 @@ int fused_launch(const CEGeom& g, const FusedPlan& p, float* part, float* T, hip
 }  // namespace
 
 extern "C" size_t pm_upsample_ce_field_bytes(const pm_tensor* logits, int H, int W) {
-  if ((logits && !pm_is_f32(logits))) return 0;      // fp32 tensors only
-  (void)W;
+  if (!logits || !pm_is_f32(logits)) return 0;      // fp32 tensors only
+  // 0 also when the fused row kernel cannot take the shape -- two low-res logit rows + the label row of one hi-res row must fit LDS (159 KB: w <= ~1000 low-res
+  // columns at 19 classes) -- so that a caller routes such shapes elsewhere instead of meeting PM_EUNSUPPORTED (ops.upsample_ce composes resize + CE then)
+  CEGeom g{};
+  g.w = logits->w, g.W = W, g.C = logits->c;
+  if (fused_plan(g).lds > FUSED_MAX_LDS) return 0;
   return (size_t)logits->n * H * logits->w * logits->c * sizeof(float);
 }
 

@@ -211,7 +211,8 @@ struct SgdBatch {
   int chunk_start[SGD_BATCH + 1];
   int n;
 };
-__global__ __launch_bounds__(256) void sgd_multi_kernel(const SgdBatch tab, float lr, float mom, float wd) {
+__global__ __launch_bounds__(256) void sgd_multi_kernel(const SgdBatch tab, float lr, float mom, float wd, const float* __restrict__ lr_dev) {
+  if (lr_dev) lr = *lr_dev;      // learning rate from device memory: a captured (hipGraph) step follows the schedule without being re-captured
   const int total_chunks = tab.chunk_start[tab.n];
   for (int c = blockIdx.x; c < total_chunks; c += gridDim.x) {
     int lo = 0, hi = tab.n;                        // largest t with chunk_start[t] <= c
@@ -248,7 +249,11 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const SgdBatch tab, floa
   }
 }
 }  // namespace
+extern "C" int pm_sgd_momentum_multi_dev(const pm_sgd_entry* entries, int n, float lr, const float* lr_dev, float momentum, float wd, void* stream);
 extern "C" int pm_sgd_momentum_multi(const pm_sgd_entry* entries, int n, float lr, float momentum, float wd, void* stream) {
+  return pm_sgd_momentum_multi_dev(entries, n, lr, nullptr, momentum, wd, stream);
+}
+extern "C" int pm_sgd_momentum_multi_dev(const pm_sgd_entry* entries, int n, float lr, const float* lr_dev, float momentum, float wd, void* stream) {
   PM_REQUIRE(entries && n >= 0, PM_EINVAL, "sgd_multi: bad args");
   for (int base = 0; base < n; base += SGD_BATCH) {
     SgdBatch b;
@@ -262,7 +267,7 @@ extern "C" int pm_sgd_momentum_multi(const pm_sgd_entry* entries, int n, float l
     }
     const int total = b.chunk_start[b.n];
     if (total == 0) continue;
-    hipLaunchKernelGGL(sgd_multi_kernel, dim3(std::min(total, 256 * 16)), dim3(256), 0, (hipStream_t)stream, b, lr, momentum, wd);
+    hipLaunchKernelGGL(sgd_multi_kernel, dim3(std::min(total, 256 * 16)), dim3(256), 0, (hipStream_t)stream, b, lr, momentum, wd, lr_dev);
   }
   return pm_check_launch("sgd_momentum_multi");
 }

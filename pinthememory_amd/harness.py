@@ -170,6 +170,65 @@ def agg_train_step(net, opt, x, gts, aux_gts=None, sched=None, buckets=None, tru
                 cls=outputs[-3][1].detach(), total=loss.detach())
 
 
+class GraphedAggStep:
+    """One agg train step (train forward + backward + SGD + memory-commit forward) captured in a hipGraph and replayed: ~1 300 kernel launches, their stream forks /
+    joins and allocations become ONE graph launch per step. For the regime where the step is launch-bound -- the bf16 tier: 28 ms of Python + HIP enqueue per step
+    against 27-29 ms of GPU time (DESIGN section 7 "Round 4"); the fp32 step is GPU-bound and gains only its ~1.5 ms of stream-join gaps.
+
+    What makes the step replayable: static input buffers (`x`, `gts` are copied in before each replay), the committed memory lives in one static buffer
+    (`Memory_sup.m_items` points at it; the captured step reads it first and writes it last), weights / BatchNorm buffers / momentum buffers are updated in place, the
+    learning rate is read from device memory (`optim.SGD.lr_device`, pm_sgd_momentum_multi_dev), random draws (gumbel noise, Dropout2d) go through torch's graph-safe
+    generator, and the kept filter transforms are recomputed INSIDE the captured step exactly where an eager step recomputes them (commit forward, after the SGD), so the
+    cache stays consistent with the weights across replays. The commit forward runs serially inside the graph (no cross-step overlap). Single process only.
+
+        g = GraphedAggStep(net, opt, x, gts, sched=sched)      # warms up eagerly, then captures
+        losses = g.step(x, gts)                                  # every further step; tensors of the returned dict are overwritten by the next replay
+    """
+
+    def __init__(self, net, opt, x, gts, sched=None, warmup=3):
+        global COMMIT_OVERLAP
+        assert x.is_cuda and not D.is_dist(), 'GraphedAggStep: single-process GPU training only'
+        assert len(opt.param_groups) == 1, 'GraphedAggStep: one parameter group (optimizer.py:21-25)'
+        self.net, self.opt, self.sched = net, opt, sched
+        m = net.module if hasattr(net, 'module') else net
+        self.x = ops.nchw(K.nchw_to_nhwc(x.float(), c_pad=4)) if x.shape[1] == 3 else x.clone()      # the stem's NHWC4 layout, converted once per step outside the graph
+        self.gts = gts.clone()
+        self.lr = torch.zeros(1, dtype=torch.float32, device=x.device)
+        prev_overlap, COMMIT_OVERLAP = COMMIT_OVERLAP, False
+        try:
+            opt.lr_device = self.lr
+            for _ in range(warmup):      # allocates workspaces, momentum buffers, filter caches, sets every kernel's LDS attribute
+                self.lr.fill_(float(opt.param_groups[0]['lr']))
+                agg_train_step(net, opt, self.x, self.gts, sched=sched)
+            finish_commit(net)
+            self.mem = m.memory.m_items.detach().clone()
+            m.memory.m_items = self.mem
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            self.lr.fill_(float(opt.param_groups[0]['lr']))
+            with torch.cuda.graph(self.graph):
+                self.out = agg_train_step(net, opt, self.x, self.gts, sched=None)
+                self.mem.copy_(m.memory.m_items)
+            m.memory.m_items = self.mem
+            torch.cuda.synchronize()
+        finally:
+            COMMIT_OVERLAP = prev_overlap
+
+    def step(self, x=None, gts=None):
+        if x is not None and x.data_ptr() != self.x.data_ptr():
+            if x.shape[1] == 3:
+                self.x.copy_(ops.nchw(K.nchw_to_nhwc(x.float(), c_pad=4)))
+            else:
+                self.x.copy_(x)
+        if gts is not None and gts.data_ptr() != self.gts.data_ptr():
+            self.gts.copy_(gts)
+        self.lr.fill_(float(self.opt.param_groups[0]['lr']))
+        self.graph.replay()
+        if self.sched is not None:
+            self.sched.step()
+        return self.out
+
+
 def memory_initialize(net, batches, epochs=2):
     """Class-prototype initialisation: sum of normalised bot_aspp features per soft class / count (no writenet).
     The reference builds a one-hot + F.interpolate per batch (train.py:1020-1030); here it is the write kernel's

@@ -615,6 +615,11 @@ def upsample_ce_bwd(logits, labels, loss_out, gscale, inv_temp=1.0):
     return dl
 
 
+def upsample_ce_fused_ok(logits, label_hw):
+    """Can the fused up-sample + CE kernels take this shape (two low-res logit rows + one label row in LDS: up to ~1000 low-res columns at 19 classes)?"""
+    return _sizes(('ce', logits.shape, logits.stride(), tuple(label_hw)), lambda: _lib().pm_upsample_ce_field_bytes(byref(tdesc(logits)), label_hw[0], label_hw[1])) != 0
+
+
 def upsample_ce_fwd_field(logits, labels, inv_temp=1.0):
     """Training forward: -> (loss_out[2], field). The field is what upsample_ce_bwd_field needs instead of a second sweep over labels and logits."""
     n, H, W = labels.shape
@@ -710,12 +715,13 @@ def sgd_momentum(param, grad, buf, lr, momentum, wd, first):
     check(_lib().pm_sgd_momentum(param.data_ptr(), grad.data_ptr(), buf.data_ptr(), param.numel(), lr, momentum, wd, 1 if first else 0, stream()), 'pm_sgd_momentum')
 
 
-def sgd_momentum_multi(triples, lr, momentum, wd):
-    """triples: [(param, grad, momentum_buffer)] of same-layout dense fp32 CUDA tensors; updated in place by a few launches."""
+def sgd_momentum_multi(triples, lr, momentum, wd, lr_device=None):
+    """triples: [(param, grad, momentum_buffer)] of same-layout dense fp32 CUDA tensors; updated in place by a few launches.
+    lr_device: a one-element fp32 CUDA tensor the kernel reads the learning rate from (captured steps); `lr` is then ignored."""
     arr = (L.PmSgdEntry * len(triples))()
     for i, (p, g, m) in enumerate(triples):
         arr[i].param, arr[i].grad, arr[i].momentum_buffer, arr[i].numel = p.data_ptr(), g.data_ptr(), m.data_ptr(), p.numel()
-    check(_lib().pm_sgd_momentum_multi(arr, len(triples), lr, momentum, wd, stream()), 'pm_sgd_momentum_multi')
+    check(_lib().pm_sgd_momentum_multi_dev(arr, len(triples), lr, ptr(lr_device), momentum, wd, stream()), 'pm_sgd_momentum_multi')
 
 
 def set_winograd(mode):

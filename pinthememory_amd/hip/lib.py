@@ -126,6 +126,7 @@ SIGNATURES = {
     'pm_conv_bn_partials_bytes': (_sz, [_T, _T, POINTER(PmConvParams)]),
     'pm_bn_partials_finalize': (_i, [_vp, _i64, _i, _f, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
     'pm_sgd_momentum_multi': (_i, [_vp, _i, _f, _f, _f, _vp]),
+    'pm_sgd_momentum_multi_dev': (_i, [_vp, _i, _f, _vp, _f, _f, _vp]),
     'pm_cast': (_i, [_T, _T, _vp]),
 }
 

@@ -685,6 +685,11 @@ def cast(x, dtype):
 
 
 def upsample_ce(logits, labels, inv_temp=1.0):
+    if not K.upsample_ce_fused_ok(nhwc(logits), tuple(labels.shape[1:])):
+        # rows too wide for the fused kernels' LDS (> ~1000 low-res columns: no training crop of the reference reaches it): the same loss composed from the
+        # bilinear kernel and torch's cross entropy on the materialised logits -- correct for any size, not tuned
+        full = resize(logits, tuple(labels.shape[1:]))
+        return torch.nn.functional.cross_entropy(full * float(inv_temp), labels, ignore_index=255, reduction='mean')
     return _UpsampleCE.apply(logits, labels, float(inv_temp), bool(torch.is_grad_enabled() and logits.requires_grad))
 
 

@@ -24,6 +24,7 @@ class SGD(torch.optim.SGD):
                 raise ValueError('pinthememory_amd.optim.SGD does not take %s=%r (step() is one multi-tensor launch of the HIP library)' % (k, kw[k]))
             kw.pop(k, None)
         super().__init__(params, lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=nesterov, **kw)
+        self.lr_device = None      # harness.GraphedAggStep: one-element CUDA tensor the fused update reads the learning rate from (single param group)
         self._register_filters()
 
     def _register_filters(self):
@@ -65,7 +66,7 @@ class SGD(torch.optim.SGD):
                 fused.append((p, g, buf))
             if fused:
                 K.register_filter_owners(p for p, _, _ in fused)      # parameters moved to the GPU after the optimizer was built
-                K.sgd_momentum_multi(fused, float(group['lr']), float(group['momentum']), float(group['weight_decay']))
+                K.sgd_momentum_multi(fused, float(group['lr']), float(group['momentum']), float(group['weight_decay']), lr_device=getattr(self, 'lr_device', None))
                 # the kernel writes through raw pointers: tell autograd (saved-tensor checks) and the Winograd filter cache (hip/kernels.py)
                 torch.autograd.graph.increment_version([t for p, _, buf in fused for t in (p, buf)])
             if rest:

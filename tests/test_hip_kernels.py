@@ -947,3 +947,23 @@ def test_c_abi_error_conventions(K):
     # and the library is still usable
     torch.cuda.synchronize()
     assert rel(nchw(K.conv_fwd(x, w, 1, 1, 1)), F.conv2d(nchw(x), w.permute(0, 3, 1, 2).cpu(), padding=1)) < 2e-5
+
+
+def test_upsample_ce_rows_too_wide_for_lds_take_the_composed_route(K):
+    """the fused up-sample + CE kernels keep two low-res logit rows and one label row in LDS (159 KB: ~1000 low-res columns at 19 classes). Wider
+    shapes are reported by pm_upsample_ce_field_bytes == 0 and ops.upsample_ce composes the same loss from the bilinear kernel and torch's cross entropy instead
+    of raising -- value and gradient against the reference's expression."""
+    from pinthememory_amd.hip import ops
+    n, C, hw, HW = 1, 19, (3, 1100), (9, 4400)
+    lg = rnd(n, C, *hw, seed=1) * 3
+    lab = torch.randint(0, C, (n, *HW), generator=torch.Generator().manual_seed(2))
+    lab[:, :1] = 255
+    assert not K.upsample_ce_fused_ok(nhwc(lg), HW) and K.upsample_ce_fused_ok(nhwc(lg[..., :900]), (9, 3600))
+    lr = lg.clone().requires_grad_(True)
+    F.cross_entropy(F.interpolate(lr, size=HW, mode='bilinear', align_corners=True), lab, ignore_index=255).backward()
+    lgg = nhwc(lg).permute(0, 3, 1, 2).requires_grad_(True)      # logical NCHW over NHWC memory, as the networks hand it over
+    loss = ops.upsample_ce(lgg, lab.cuda())
+    loss.backward()
+    ref = F.cross_entropy(F.interpolate(lg, size=HW, mode='bilinear', align_corners=True), lab, ignore_index=255)
+    assert abs(loss.item() - ref.item()) < 1e-5 * max(1, abs(ref.item()))
+    assert rel(lgg.grad.cpu(), lr.grad) < 1e-4
