@@ -209,6 +209,8 @@ class GraphedAggStep:
             with torch.cuda.graph(self.graph):
                 self.out = agg_train_step(net, opt, self.x, self.gts, sched=None)
                 self.mem.copy_(m.memory.m_items)
+                if ops.OVERLAP_WGRAD:      # every stream forked into the capture rejoins it (the weight-gradient stream's last event record trails its last join)
+                    torch.cuda.current_stream().wait_stream(ops._side_stream())
             m.memory.m_items = self.mem
             torch.cuda.synchronize()
         finally:

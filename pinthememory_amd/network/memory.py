@@ -187,7 +187,9 @@ class Memory_sup(nn.Module):
 
     def diversityloss(self, mem):                     # memory.py:264-272
         cos_sim_pos = torch.matmul(mem, torch.t(mem)).clamp_min(0)    # == cos[cos < 0] = 0 without the host sync of a mask write
-        return (torch.sum(cos_sim_pos) - torch.trace(cos_sim_pos)) / (self.memory_size * (self.memory_size - 1))
+        # the trace as the sum of the diagonal view: torch.trace's BACKWARD (index_fill_ with a tensor value -> .item()) synchronises the host with the GPU at the
+        # start of every backward pass -- the host loses its lead over the GPU each step (round 4: the bf16 tier is host-bound) and the step cannot be captured
+        return (torch.sum(cos_sim_pos) - cos_sim_pos.diagonal().sum()) / (self.memory_size * (self.memory_size - 1))
 
     def forward(self, query, mask=None, memory_writing=True, writing_detach=True):   # memory.py:191-204
         updated_query, softmax_score_query, softmax_score_memory, readloss = self.read(query, mask, memory_writing)
