@@ -880,3 +880,36 @@ def test_commit_forward_overlap_flagship_size_default_config(env):
     for a_, b_ in zip(l1, l0):
         assert all(torch.equal(a_[k], b_[k]) for k in a_)
     assert torch.equal(m1, m0) and all(torch.equal(s1[k], s0[k]) for k in s1)
+
+
+def test_graphed_agg_step_is_bit_identical_to_eager(env):
+    """harness.GraphedAggStep: the agg train step captured in a hipGraph (train forward + backward with the weight gradients on their side stream + SGD with the
+    learning rate read from device memory + serial commit forward) and replayed -- parameters, buffers and the committed memory after 3 warm-up + 4 replayed steps
+    carry the bits of 7 eager steps in the same (serial-commit) order, on fresh batches copied into the graph's static inputs, with the LR schedule stepping."""
+    synth, h = env['synth'], env['harness']
+
+    def make():
+        net = synth.load_det_weights(env['deepv3plus'].DeepR50V3PlusD(synth.model_args(), 19, CRIT, CRIT)).cuda()
+        net.dsn[3].p = 0.0
+        opt, sched = h.make_optimizer(net)
+        return net, opt, sched
+    batches = [tuple(t.cuda() for t in synth.make_batch(2, 128, seed=40 + i)) for i in range(3)]
+    prev = h.COMMIT_OVERLAP
+    h.COMMIT_OVERLAP = False
+    try:
+        net_e, opt_e, sched_e = make()
+        for i in range(7):
+            x, y = batches[0] if i < 3 else batches[(i - 3) % 3]
+            le = h.agg_train_step(net_e, opt_e, x, y, sched=sched_e)
+    finally:
+        h.COMMIT_OVERLAP = prev
+    net_g, opt_g, sched_g = make()
+    g = h.GraphedAggStep(net_g, opt_g, batches[0][0], batches[0][1], sched=sched_g, warmup=3)
+    for i in range(4):
+        lg = g.step(*batches[i % 3])
+    torch.cuda.synchronize()
+    assert opt_g.param_groups[0]['lr'] == opt_e.param_groups[0]['lr'] < 0.01
+    for (k, a), b in zip(net_e.state_dict().items(), net_g.state_dict().values()):
+        assert torch.equal(a, b), k
+    assert torch.equal(net_e.memory.m_items, net_g.memory.m_items)
+    assert all(torch.equal(le[k], lg[k]) for k in le)
