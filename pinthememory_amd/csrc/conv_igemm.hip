@@ -105,10 +105,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   // to LDS as they are -- half the gather instructions, no conversion.
   constexpr bool TR = (PREC == 3 || PREC == 4);
   constexpr bool NAT16 = (PREC == 4);
+  // K-step of this instantiation. PREC 4 takes 64 pixels per step (a thread gathers two pixel rows, r and r + 32): the bf16 MFMA phase of a 32-pixel step is 256
+  // cycles per wave -- too short for one barrier pair and one round of address arithmetic; the forward kernels' steps are 64 deep as well (round 4: 465 -> see DESIGN)
+  constexpr int KX = NAT16 ? 2 : 1, BKW = BK * KX;
   static_assert(!TR || MODE == MODE_WGRAD, "PREC 3 / 4 are the weight-gradient forms");
   constexpr int LDA_T = BM + 32, LDB_T = BN + 32;   // bf16 elements per k-row
-  constexpr int A_FLOATS = A_KC ? BM * LDK : (TR ? BK * LDA_T / 2 : BK * BM);
-  constexpr int B_FLOATS = B_KC ? BN * LDK : (TR ? BK * LDB_T / 2 : BK * BN);
+  constexpr int A_FLOATS = A_KC ? BM * LDK : (TR ? BKW * LDA_T / 2 : BK * BM);
+  constexpr int B_FLOATS = B_KC ? BN * LDK : (TR ? BKW * LDB_T / 2 : BK * BN);
   constexpr int STAGE = A_FLOATS + B_FLOATS;
   constexpr int A_N = BM / 32, B_N = BN / 32;  // float4 per thread and tile
   static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BK == 32, "bad tile config");
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   const int z = blockIdx.z;
   const int k_begin = z * a.kper;
   const int k_end = min(a.K, k_begin + a.kper);
-  const int nk = (k_end - k_begin + BK - 1) / BK;
+  const int nk = (k_end - k_begin + BKW - 1) / BKW;
   const int T = a.T_eff;                 // taps iterated by this launch
   const int Treal = a.kh * a.kw;         // tap stride of the KRSC weight layout
 
@@ -145,6 +148,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   int a_ch = 0, a_tap = 0, a_ky = 0, a_kx = 0;     // MID/SMALL FWD+DGRAD A
   int b_co = 0, b_tap = 0;                         // MID/SMALL DGRAD B row (tap, co)
   int p_ox = 0, p_oy = 0, p_img = 0;               // WGRAD B: output pixel of this thread's k-row
+  int q_ox = 0, q_oy = 0, q_img = 0;               // ... and of its second k-row (r + 32) when the K-step is 64 pixels (KX == 2)
   // static per-item constants
   int a_base[A_N], a_y0[A_N], a_x0[A_N];           // FWD/DGRAD A rows: byte offset of the window origin, window origin
   int a_col4[A_N];                                 // WGRAD A: byte offset of dy channel group j (OOB beyond Cout)
@@ -230,12 +234,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
     const int rem = p - p_img * (a.Ho * a.Wo);
     p_oy = rem / a.Wo;
     p_ox = rem - p_oy * a.Wo;
+    if constexpr (KX == 2) {
+      const int q = p + 32;
+      q_img = q / (a.Ho * a.Wo);
+      const int rq = q - q_img * (a.Ho * a.Wo);
+      q_oy = rq / a.Wo;
+      q_ox = rq - q_oy * a.Wo;
+    }
   }
 
   float4 ra[A_N], rb[B_N];
 
   auto load_tiles = [&](int kt) {   // branch-free: every lane always issues its loads, invalid ones at offset OOB
-    const int kbase = k_begin + kt * BK;
+    const int kbase = k_begin + kt * BKW;
     if constexpr (MODE == MODE_FWD) {
       const int ky = FAST ? u_ky : a_ky, kx = FAST ? u_kx : a_kx, tap = FAST ? u_tap : a_tap, ch = FAST ? u_ch : a_ch;
       const int dy = ky * a.dil, dx = kx * a.dil;
@@ -291,21 +302,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
         }
       }
     } else {
-      const int p = kbase + r;
-      const bool pok = p < k_end;
-      const int poff = p * yp4;
 #pragma unroll
-      for (int j = 0; j < A_NL; ++j) {
-        const int off = poff + a_col4[j];
-        ra[j] = bload(rA, (pok & (a_col4[j] != OOB)) ? off : OOB);
-      }
-      const int by = p_oy * a.stride, bx = p_ox * a.stride;
-      const int rowbase = ((p_img * a.H + by) * a.W + bx) * xp4;
+      for (int kk = 0; kk < KX; ++kk) {      // KX == 2: the thread's second pixel row, 32 further on
+        const int p = kbase + r + 32 * kk;
+        const bool pok = p < k_end;
+        const int poff = p * yp4;
 #pragma unroll
-      for (int j = 0; j < B_NL; ++j) {
-        const bool ok = pok & (b_base[j] != OOB) & ((unsigned)(by + b_dy[j]) < (unsigned)a.H) & ((unsigned)(bx + b_dx[j]) < (unsigned)a.W);
-        const int off = rowbase + b_base[j];
-        rb[j] = bload(rB, ok ? off : OOB);
+        for (int j = 0; j < A_NL; ++j) {
+          const int off = poff + a_col4[j];
+          ra[kk * A_NL + j] = bload(rA, (pok & (a_col4[j] != OOB)) ? off : OOB);
+        }
+        const int by = (kk ? q_oy : p_oy) * a.stride, bx = (kk ? q_ox : p_ox) * a.stride;
+        const int rowbase = (((kk ? q_img : p_img) * a.H + by) * a.W + bx) * xp4;
+#pragma unroll
+        for (int j = 0; j < B_NL; ++j) {
+          const bool ok = pok & (b_base[j] != OOB) & ((unsigned)(by + b_dy[j]) < (unsigned)a.H) & ((unsigned)(bx + b_dx[j]) < (unsigned)a.W);
+          const int off = rowbase + b_base[j];
+          rb[kk * B_NL + j] = bload(rB, ok ? off : OOB);
+        }
       }
     }
   };
@@ -348,19 +362,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
         }
       }
     } else {
-      p_ox += BK;
-      if constexpr (KM == K_SMALL) {
-        while (p_ox >= a.Wo) {
-          p_ox -= a.Wo;
-          if (++p_oy == a.Ho) p_oy = 0, ++p_img;
+      auto step = [&](int& ox, int& oy, int& img) {
+        ox += BKW;
+        if constexpr (KM == K_SMALL) {
+          while (ox >= a.Wo) {
+            ox -= a.Wo;
+            if (++oy == a.Ho) oy = 0, ++img;
+          }
+        } else {      // Wo >= BKW: at most one wrap per step
+          const bool wrap = ox >= a.Wo;
+          ox -= wrap ? a.Wo : 0;
+          const bool imgw = wrap & (oy + 1 == a.Ho);
+          oy = imgw ? 0 : oy + (wrap ? 1 : 0);
+          img += imgw ? 1 : 0;
         }
-      } else {
-        const bool wrap = p_ox >= a.Wo;
-        p_ox -= wrap ? a.Wo : 0;
-        const bool imgw = wrap & (p_oy + 1 == a.Ho);
-        p_oy = imgw ? 0 : p_oy + (wrap ? 1 : 0);
-        p_img += imgw ? 1 : 0;
-      }
+      };
+      step(p_ox, p_oy, p_img);
+      if constexpr (KX == 2) step(q_ox, q_oy, q_img);
     }
   };
 
@@ -373,6 +391,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   auto store_tiles = [&](int buf) {
     float* As = smem + buf * STAGE;
     float* Bs = As + A_FLOATS;
+    if constexpr (NAT16) {      // two pixel rows per thread (r, r + 32), 16 bytes = eight channels per gather, stored as they are
+#pragma unroll
+      for (int kk = 0; kk < KX; ++kk) {
+#pragma unroll
+        for (int i = 0; i < A_NL; ++i)
+          *reinterpret_cast<float4*>(reinterpret_cast<char*>(As) + ((r + 32 * kk) * LDA_T + (g + 8 * i) * 8) * 2) = ra[kk * A_NL + i];
+#pragma unroll
+        for (int i = 0; i < B_NL; ++i)
+          *reinterpret_cast<float4*>(reinterpret_cast<char*>(Bs) + ((r + 32 * kk) * LDB_T + (g + 8 * i) * 8) * 2) = rb[kk * B_NL + i];
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < A_NL; ++i) {
       if constexpr (A_KC) *reinterpret_cast<float4*>(As + (r + 32 * i) * LDK + g * 4) = ra[i];
@@ -515,7 +545,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   };
   auto compute = [&](int buf) {
 #pragma unroll
-    for (int kg = 0; kg < BK / 8; ++kg) compute_kg(buf, kg);
+    for (int kg = 0; kg < BKW / 8; ++kg) compute_kg(buf, kg);
   };
 
   // ---- main loop: the gathers of slab kt+1 are issued (branch-free) ahead of the MFMAs of slab kt, whose 4096 matrix-pipe
@@ -550,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
       advance();
       __builtin_amdgcn_sched_group_barrier(0x100, TM + TN + (A_KC ? 0 : 3 * TM) + (B_KC ? 0 : 3 * TN), 0);  // fragment DS reads
 #define PM_SG(I)                                                                   \
-      if constexpr (A_NL + B_NL > I) {                                                \
+      if constexpr ((A_NL + B_NL) * KX > I) {                                                \
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  /* 2 MFMA            */ \
         __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);  /* <= 8 VALU / SALU  */ \
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  /* 1 buffer load     */ \
@@ -560,7 +590,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
       __builtin_amdgcn_sched_barrier(0);
       // Region 2: the remaining three k-groups cover the load latency; then the LDS write of slab kt+1 and the barrier
 #pragma unroll
-      for (int kg = 1; kg < BK / 8; ++kg) compute_kg(kt & 1, kg);
+      for (int kg = 1; kg < BKW / 8; ++kg) compute_kg(kt & 1, kg);
       store_tiles((kt + 1) & 1);
       __syncthreads();
     }
@@ -1200,7 +1230,7 @@ int launch(const ConvK& k0, const Plan& p, hipStream_t st, int batch = 1, double
   constexpr bool akc = MODE != MODE_WGRAD, bkc = MODE == MODE_FWD;
   const bool tr = MODE == MODE_WGRAD && (k.prec == 3 || k.prec == 4) && p.bn >= 64;      // bf16 [k][m + 32] tiles: 2 bytes per element
   auto smem = [&](int bm, int bn) {
-    if (tr) return (size_t)2 * (BK * (bm + 32) + BK * (bn + 32)) * 2;
+    if (tr) return (size_t)2 * ((k.prec == 4 ? 2 : 1) * BK * (bm + 32) + (k.prec == 4 ? 2 : 1) * BK * (bn + 32)) * 2;
     return (size_t)2 * ((akc ? bm * LDK : BK * bm) + (bkc ? bn * LDK : BK * bn)) * sizeof(float);
   };
   if (p.bm == 64) {
@@ -2005,11 +2035,14 @@ extern "C" int pm_conv_bwd_weight(const pm_tensor* x0, const pm_tensor* dy0, flo
   if (native16) {
     PM_REQUIRE(x->c % 8 == 0 && dy->c % 8 == 0 && pl.bn >= 64, PM_EUNSUPPORTED, "conv_bwd_weight(bf16): channels %% 8 != 0 or a tile narrower than 64");
     k.prec = 4;
+    // the PREC 4 kernel steps 64 pixels at a time: the K range of a split must be a multiple of that (the slab count can only shrink, the workspace was sized for more)
+    pl.kper = (pl.kper + 63) / 64 * 64;
+    pl.ksplit = (int)((K + pl.kper - 1) / pl.kper);
   }
   const int esz = native16 ? 2 : 4;
   k.A = (const float*)dy->ptr, k.B = (const float*)x->ptr;
   k.M = (int)M, k.Nn = (int)Nn, k.K = (int)K;
-  k.a_bytes = (unsigned)(pm_pixels(dy) * dy->pitch * esz), k.b_bytes = (unsigned)(pm_pixels(x) * x->pitch * esz), k.kmode = dy->w >= BK ? 1 : 2;
+  k.a_bytes = (unsigned)(pm_pixels(dy) * dy->pitch * esz), k.b_bytes = (unsigned)(pm_pixels(x) * x->pitch * esz), k.kmode = dy->w >= (native16 ? 2 * BK : BK) ? 1 : 2;
   if (wp.use || bw.use) {
   } else if (pl.ksplit > 1) {
     k.C = (float*)ws, k.c_pitch = Nn, k.c_split = M * Nn;
