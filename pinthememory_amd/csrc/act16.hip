@@ -5,6 +5,8 @@
 // fixed-order (atomic-free, deterministic) reductions. The extern "C" entry points of those files dispatch here on dtype.
 // Replaces on the tier: mynn.Norm2d (/root/reference/network/mynn.py:8-14) train forward / backward, nn.MaxPool2d(3,2,1) (Resnet.py:432),
 // nn.AdaptiveAvgPool2d(1) (deepv3plus.py:85), mynn.Upsample (mynn.py:57-62), the residual / fan-in adds of autograd.
+#include <stdlib.h>
+
 #include "pm_common.h"
 
 namespace {
@@ -198,6 +200,90 @@ __global__ __launch_bounds__(256) void bn16_bwd_final(const float* __restrict__ 
   sums[c] = (float)s1;
   sums[C + c] = (float)s2;
 }
+
+// The two elementwise BatchNorm passes with the per-channel constants in REGISTERS: thread = one 8-channel group (fixed) x a strided set of pixels. The generic
+// driver above re-loads mean / invstd / gamma / beta (/ sums) -- 128-192 bytes of L1 traffic -- for every 16-byte group of activations it moves, which held these
+// passes at 4.0-4.4 TB/s where their fp32 twins reach 5.6 (twice the tensor bytes per parameter load). Taken when the channel groups divide the block (C = 64 ... 2048).
+template <bool RES, bool MASK, bool RELU>
+__global__ __launch_bounds__(256) void bn16_apply_fixed_kernel(const pm_bf16* __restrict__ x, long xp, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta, const pm_bf16* __restrict__ res, long rp,
+                                                               pm_bf16* __restrict__ y, long yp, uint8_t* __restrict__ mask, long pixels, int cg) {
+  const int grp = threadIdx.x % cg, pl = threadIdx.x / cg, ppb = 256 / cg, ch = grp * V;
+  float sc[V], sh[V];
+  {
+    float mu[V], is[V], ga[V], be[V];
+    ld8f(mean + ch, mu), ld8f(invstd + ch, is), ld8f(gamma + ch, ga), ld8f(beta + ch, be);
+#pragma unroll
+    for (int e = 0; e < V; ++e) sc[e] = is[e] * ga[e], sh[e] = fmaf(-mu[e], sc[e], be[e]);      // bn_affine(v) == fmaf(v, sc, sh): the same two FMAs
+  }
+  for (long p = (long)blockIdx.x * ppb + pl; p < pixels; p += (long)gridDim.x * ppb) {
+    float v[V], o[V];
+    pm_ld8(x + p * xp + ch, v);
+#pragma unroll
+    for (int e = 0; e < V; ++e) o[e] = fmaf(v[e], sc[e], sh[e]);
+    if constexpr (RES) {
+      float q[V];
+      pm_ld8(res + p * rp + ch, q);
+#pragma unroll
+      for (int e = 0; e < V; ++e) o[e] += q[e];
+    }
+    if constexpr (MASK) {
+      unsigned m = 0;
+#pragma unroll
+      for (int e = 0; e < V; ++e) m |= o[e] > 0.f ? (1u << e) : 0u;
+      mask[p * cg + grp] = (unsigned char)m;
+    }
+    if constexpr (RELU) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) o[e] = fmaxf(o[e], 0.f);
+    }
+    pm_st8(y + p * yp + ch, o);
+  }
+}
+
+// MODE 0: no ReLU (dy is already the masked gradient); 1: mask = forward output > 0; 2: mask rebuilt from x
+template <int MODE, bool DRES>
+__global__ __launch_bounds__(256) void bn16_bwd_apply_fixed_kernel(const pm_bf16* __restrict__ dy, long dp, const pm_bf16* __restrict__ yo, long op, const pm_bf16* __restrict__ x,
+                                                                   long xp, const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, const float* __restrict__ sums, float host_inv_n, int dev_count, int C,
+                                                                   pm_bf16* __restrict__ dx, long dxp, pm_bf16* __restrict__ dres, long drp, long pixels, int cg) {
+  const int grp = threadIdx.x % cg, pl = threadIdx.x / cg, ppb = 256 / cg, ch = grp * V;
+  float mu[V], is[V], k1[V], k2[V], sg[V], sc[V], sh[V];
+  {
+    const float inv_n = dev_count ? 1.f / sums[2 * C] : host_inv_n;
+    float ga[V], s1[V], s2[V];
+    ld8f(mean + ch, mu), ld8f(invstd + ch, is), ld8f(gamma + ch, ga), ld8f(sums + ch, s1), ld8f(sums + C + ch, s2);
+#pragma unroll
+    for (int e = 0; e < V; ++e) k1[e] = s1[e] * inv_n, k2[e] = s2[e] * inv_n, sg[e] = is[e] * ga[e];
+    if constexpr (MODE == 2) {
+      float be[V];
+      ld8f(beta + ch, be);
+#pragma unroll
+      for (int e = 0; e < V; ++e) sc[e] = sg[e], sh[e] = fmaf(-mu[e], sg[e], be[e]);
+    }
+  }
+  for (long p = (long)blockIdx.x * ppb + pl; p < pixels; p += (long)gridDim.x * ppb) {
+    float g[V], v[V], r[V];
+    pm_ld8(dy + p * dp + ch, g);
+    pm_ld8(x + p * xp + ch, v);
+    if constexpr (MODE == 1) {
+      float o[V];
+      pm_ld8(yo + p * op + ch, o);
+#pragma unroll
+      for (int e = 0; e < V; ++e) g[e] = o[e] > 0.f ? g[e] : 0.f;
+    }
+    if constexpr (MODE == 2) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) g[e] = fmaf(v[e], sc[e], sh[e]) > 0.f ? g[e] : 0.f;
+    }
+    if constexpr (DRES) pm_st8(dres + p * drp + ch, g);
+#pragma unroll
+    for (int e = 0; e < V; ++e) r[e] = (g[e] - k1[e] - (v[e] - mu[e]) * is[e] * k2[e]) * sg[e];      // the generic kernel's expression, constants hoisted
+    pm_st8(dx + p * dxp + ch, r);
+  }
+}
+inline bool fixed_ok(int c) { const int cg = c / V; return c % V == 0 && cg >= 1 && cg <= 256 && 256 % cg == 0; }
+inline int fixed_grid(long pixels, int c) { const int ppb = 256 / (c / V); return (int)std::min<long>((pixels + ppb - 1) / ppb, 256 * 16); }
 
 int check16(const pm_tensor* t, const char* who) {
   PM_REQUIRE(t && t->ptr && pm_vec8(t), PM_EINVAL, "%s: bf16 tensors must be 16B aligned with pitch %% 8 == 0 and C %% 8 == 0", who);
@@ -530,6 +616,23 @@ int pm16_bn_apply_mask(const pm_tensor* x, const float* mean, const float* invst
   const pm_bf16 *px = (const pm_bf16*)x->ptr, *pr = res ? (const pm_bf16*)res->ptr : nullptr;
   pm_bf16* py = (pm_bf16*)y->ptr;
   const long a = x->pitch, b = res ? res->pitch : 0, c = y->pitch, cq = x->c >> 3;
+  static const int fixed_on = getenv("PM_BN16_FIXED") ? atoi(getenv("PM_BN16_FIXED")) : 1;      // A/B knob
+  if (fixed_on && fixed_ok(x->c) && pm_pixels(x) > 0) {
+    const long P = pm_pixels(x);
+    const dim3 grid(fixed_grid(P, x->c));
+    const int cg = x->c / V;
+#define PM16_APPLY(R, M, L) hipLaunchKernelGGL((bn16_apply_fixed_kernel<R, M, L>), grid, dim3(256), 0, st, px, a, mean, invstd, gamma, beta, pr, b, py, c, mask, P, cg)
+    if (pr && mask && relu) PM16_APPLY(true, true, true);
+    else if (pr && relu) PM16_APPLY(true, false, true);
+    else if (pr && mask) PM16_APPLY(true, true, false);
+    else if (pr) PM16_APPLY(true, false, false);
+    else if (mask && relu) PM16_APPLY(false, true, true);
+    else if (relu) PM16_APPLY(false, false, true);
+    else if (mask) PM16_APPLY(false, true, false);
+    else PM16_APPLY(false, false, false);
+#undef PM16_APPLY
+    return pm_check_launch("bn_apply(bf16, fixed groups)");
+  }
   return ew16_launch(pm_pixels(x), x->c, st, "bn_apply(bf16)", [=] __device__(long p, int ch) {
     float v[V], mu[V], is[V], ga[V], be[V], o[V];
     pm_ld8(px + p * a + ch, v);
@@ -612,6 +715,20 @@ int pm16_bn_bwd_apply(const pm_tensor* dy, const pm_tensor* y, const pm_tensor* 
   const int C = x->c;
   const bool dev_count = !(count > 0.f);
   const float host_inv_n = dev_count ? 0.f : 1.f / count;
+  static const int fixed_on = getenv("PM_BN16_FIXED") ? atoi(getenv("PM_BN16_FIXED")) : 1;
+  if (fixed_on && fixed_ok(C) && pm_pixels(x) > 0) {
+    const long P = pm_pixels(x);
+    const dim3 grid(fixed_grid(P, C));
+    const int cg = C / V;
+#define PM16_BAPPLY(M, D)                                                                                                                                            \
+  hipLaunchKernelGGL((bn16_bwd_apply_fixed_kernel<M, D>), grid, dim3(256), 0, st, pd, a, po, b, px, c, mean, invstd, gamma, beta, sums, host_inv_n, dev_count ? 1 : 0, C, pdx, d, \
+                     pdr, e2, P, cg)
+    if (relu == 0) { if (pdr) PM16_BAPPLY(0, true); else PM16_BAPPLY(0, false); }
+    else if (relu == 1) { if (pdr) PM16_BAPPLY(1, true); else PM16_BAPPLY(1, false); }
+    else { if (pdr) PM16_BAPPLY(2, true); else PM16_BAPPLY(2, false); }
+#undef PM16_BAPPLY
+    return pm_check_launch("bn_bwd_apply(bf16, fixed groups)");
+  }
   return ew16_launch(pm_pixels(x), C, st, "bn_bwd_apply(bf16)", [=] __device__(long p, int ch) {
     const float inv_n = dev_count ? 1.f / sums[2 * C] : host_inv_n;
     float g[V], v[V], mu[V], is[V], ga[V], s1[V], s2[V], r[V];
