@@ -96,6 +96,19 @@ size_t pm_conv_wxf_bytes(const pm_tensor* x, const pm_tensor* y, const pm_conv_p
 /* the same for pm_conv_bwd_data on the bf16 tier: bytes of the rotated / transposed bf16 filter a stride-1 data gradient derives from w (0: none). The caller
  * passes the buffer in pm_conv_params.wxf / wxf_bytes / wxf_valid exactly as for pm_conv_fwd. */
 size_t pm_conv_wxf_bytes_dgrad(const pm_tensor* dy, const pm_tensor* dx, const pm_conv_params* p);
+/* bf16 tier: rewrite MANY kept bf16 filters (the buffers of pm_conv_wxf_bytes / _dgrad with prec == 2) from their fp32 weights in one or two launches, e.g.
+ * right after the optimizer moved the weights -- the next pm_conv_fwd / pm_conv_bwd_data calls then arrive with wxf_valid = 1 and derive nothing (142 small
+ * casts per training step otherwise). Layout written = the one those calls read: forward [cout][kh*kw][round64(cin)], dgrad (rotated / transposed)
+ * [cin][kh*kw][round64(cout)] with tap t <- kh*kw-1-t; pad channels zero. wxf_bytes is checked against that size. */
+typedef struct pm_wxf_job {
+  const float* w;      /* KRSC fp32 weights [cout][kh][kw][cin] */
+  void* wxf;           /* the kept buffer */
+  int64_t wxf_bytes;
+  int32_t cout, kh, kw, cin;
+  int32_t dgrad;       /* 0: forward copy, 1: rotated / transposed copy of the data gradient */
+  int32_t reserved;
+} pm_wxf_job;
+int pm_conv_wxf_refresh_bf16(const pm_wxf_job* jobs, int n, void* stream);
 /* bytes of pm_conv_epilogue.bn_partials for this forward call, 0 if the call cannot emit them (then run pm_bn_stats* on y as before) */
 size_t pm_conv_bn_partials_bytes(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p);
 int pm_conv_fwd(const pm_tensor* x, const float* w_krsc, const pm_tensor* y, const pm_conv_params* p,

@@ -126,7 +126,81 @@ __global__ __launch_bounds__(256) void transpose_taps_kernel(const float* __rest
   }
 }
 
+// Batched form of the two weight casts above: every block takes one 32 x 32 tile (rows x padded channels of one tap) of one job; the job table travels in the
+// kernel arguments (no device-side table to keep alive), blocks find their job by bisection over the tile prefix sums.
+constexpr int WX_BATCH = 64;
+struct WxJobs {
+  const float* w[WX_BATCH];
+  unsigned short* out[WX_BATCH];
+  int cout[WX_BATCH], T[WX_BATCH], cin[WX_BATCH], cp[WX_BATCH], rot[WX_BATCH];
+  int tile_start[WX_BATCH + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void cast_weights_multi_kernel(const WxJobs tab) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = tab.n;                        // largest j with tile_start[j] <= blockIdx.x
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tab.tile_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+  }
+  const int j = lo, Cout = tab.cout[j], T = tab.T[j], Cin = tab.cin[j], Cp = tab.cp[j];
+  const float* __restrict__ w = tab.w[j];
+  unsigned short* __restrict__ out = tab.out[j];
+  const int R = tab.rot[j] ? Cin : Cout;         // rows of the output
+  const int ctiles = Cp / 32, rtiles = (R + 31) / 32;
+  int id = blockIdx.x - tab.tile_start[j];
+  const int ct = id % ctiles; id /= ctiles;
+  const int rt = id % rtiles;
+  const int t = id / rtiles;
+  const int r0 = rt * 32, c0 = ct * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  if (!tab.rot[j]) {                             // out[r][t][c] = w[r][t][c], c < Cin, else 0
+    for (int jj = ty; jj < 32; jj += 8) {
+      const int r = r0 + jj, c = c0 + tx;
+      if (r < R) out[((long)r * T + t) * Cp + c] = f2bf(c < Cin ? w[((long)r * T + t) * Cin + c] : 0.f);
+    }
+    return;
+  }
+  for (int jj = ty; jj < 32; jj += 8) {          // out[r][t][c] = w[c][T-1-t][r]: r over Cin, c over Cout (padded to Cp)
+    const int c = c0 + jj, r = r0 + tx;
+    tile[jj][tx] = (c < Cout && r < Cin) ? w[((long)c * T + (T - 1 - t)) * Cin + r] : 0.f;
+  }
+  __syncthreads();
+  for (int jj = ty; jj < 32; jj += 8) {
+    const int r = r0 + jj, c = c0 + tx;
+    if (r < Cin) out[((long)r * T + t) * Cp + c] = f2bf(tile[tx][jj]);
+  }
+}
+
 }  // namespace
+
+extern "C" int pm_conv_wxf_refresh_bf16(const pm_wxf_job* jobs, int n, void* stream) {
+  PM_REQUIRE(n >= 0 && (jobs || n == 0), PM_EINVAL, "conv_wxf_refresh_bf16: bad job table");
+  for (int i = 0; i < n; ++i) {
+    const pm_wxf_job& q = jobs[i];
+    PM_REQUIRE(q.w && q.wxf && q.cout > 0 && q.cin > 0 && q.kh > 0 && q.kw > 0, PM_EINVAL, "conv_wxf_refresh_bf16: job %d: bad arguments", i);
+    const long rows = q.dgrad ? q.cin : q.cout, cp = ((q.dgrad ? q.cout : q.cin) + 63) / 64 * 64;
+    PM_REQUIRE(q.wxf_bytes >= rows * q.kh * q.kw * cp * 2, PM_EINVAL, "conv_wxf_refresh_bf16: job %d: buffer of %ld bytes, the filter needs %ld", i, (long)q.wxf_bytes,
+               rows * q.kh * q.kw * cp * 2);
+    PM_REQUIRE(pm_aligned16(q.wxf), PM_EINVAL, "conv_wxf_refresh_bf16: job %d: buffer must be 16-byte aligned", i);
+  }
+  for (int i0 = 0; i0 < n; i0 += WX_BATCH) {
+    WxJobs tab;
+    tab.n = std::min(WX_BATCH, n - i0);
+    long tiles = 0;
+    for (int i = 0; i < tab.n; ++i) {
+      const pm_wxf_job& q = jobs[i0 + i];
+      tab.w[i] = q.w, tab.out[i] = (unsigned short*)q.wxf, tab.cout[i] = q.cout, tab.T[i] = q.kh * q.kw, tab.cin[i] = q.cin, tab.rot[i] = q.dgrad ? 1 : 0;
+      tab.cp[i] = ((q.dgrad ? q.cout : q.cin) + 63) / 64 * 64;
+      tab.tile_start[i] = (int)tiles;
+      tiles += (long)(((q.dgrad ? q.cin : q.cout) + 31) / 32) * (tab.cp[i] / 32) * tab.T[i];
+      PM_REQUIRE(tiles < (1l << 30), PM_EINVAL, "conv_wxf_refresh_bf16: too many tiles in one batch");
+    }
+    tab.tile_start[tab.n] = (int)tiles;
+    hipLaunchKernelGGL(cast_weights_multi_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, tab);
+    if (int e = pm_check_launch("conv_wxf_refresh_bf16")) return e;
+  }
+  return PM_OK;
+}
 
 int pm_bf16_cast_rows(const float* x, long pitch, int C, int Cp, long P, void* out, hipStream_t st) {
   const long total = P * (Cp / 8);

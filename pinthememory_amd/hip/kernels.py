@@ -160,7 +160,8 @@ def _wino_u(p, w_krsc, nbu, dgrad=False):
             _evict(_U_CACHE.pop(k))
         while _U_CACHE and (len(_U_CACHE) >= _U_CACHE_MAX or sum(e[2].numel() * 4 for e in _U_CACHE.values()) + nbu > _U_CACHE_BYTES):
             _evict(_U_CACHE.pop(next(iter(_U_CACHE))))
-        ent = [weakref.ref(owner) if owner is not None else w_krsc, -1, torch.empty(nbu // 4, dtype=torch.float32, device=w_krsc.device), None, None]
+        ent = [weakref.ref(owner) if owner is not None else w_krsc, -1, torch.empty(nbu // 4, dtype=torch.float32, device=w_krsc.device), None, None, True]
+    ent[5] = True                       # used since the last refresh_bf16_filters()
     version = (owner if owner is not None else w_krsc)._version
     valid = ent[1] == version
     if not valid:
@@ -173,6 +174,42 @@ def _wino_u(p, w_krsc, nbu, dgrad=False):
     if valid and ent[3] is not None and ent[4] != raw:
         _U_STREAMS[raw].wait_event(ent[3])          # the transform was written by a launch on another stream (harness: the commit forward runs on its own)
     return None if valid else (ent, version)
+
+
+def refresh_bf16_filters():
+    """bf16 tier, called by the optimizer right after it moved the weights: rewrite every kept bf16 filter (forward copy, rotated copy of the data gradient) that
+    was used since the last call and is now out of date, in ONE or two launches (pm_conv_wxf_refresh_bf16) instead of one small cast in front of each of the
+    ~142 convolution calls of the next step. Entries nobody used in the last step are left to go stale (their convolution re-derives them if it returns).
+    The caller has already made sure no other stream still reads the buffers (optim.SGD.step: ops.wait_commit()). Returns the number of filters rewritten."""
+    if CONV_PREC != 2 or KEEP_WINOGRAD_U is False or not _U_CACHE:
+        return 0
+    import weakref
+    dev = torch.cuda.current_device()
+    todo = []
+    for key, ent in _U_CACHE.items():
+        if key[4] != 2 or key[3] != dev or not ent[5]:
+            continue
+        ent[5] = False
+        owner = ent[0]() if isinstance(ent[0], weakref.ref) else ent[0]
+        if owner is None or owner.data_ptr() != key[0] or ent[1] == owner._version or not ent[2].is_cuda:
+            continue
+        todo.append((key, ent, owner))
+    if not todo:
+        return 0
+    jobs = (L.PmWxfJob * len(todo))()
+    for j, (key, ent, owner) in zip(jobs, todo):
+        cout, kh, kw, cin = key[1]
+        j.w, j.wxf, j.wxf_bytes, j.cout, j.kh, j.kw, j.cin, j.dgrad = key[0], ent[2].data_ptr(), key[2], cout, kh, kw, cin, 1 if key[5] else 0
+        ent[1] = -1
+    check(_lib().pm_conv_wxf_refresh_bf16(jobs, len(todo), stream()), 'pm_conv_wxf_refresh_bf16')
+    cur = L.stream_obj()
+    raw = cur.cuda_stream
+    if raw not in _U_STREAMS:
+        _U_STREAMS[raw] = cur
+    ev = cur.record_event()
+    for key, ent, owner in todo:
+        ent[1], ent[3], ent[4] = owner._version, ev, raw
+    return len(todo)
 
 
 # Size queries of the convolution entry points (workspace, kept Winograd V, transformed filter, statistics partials) depend on shapes and on the library's

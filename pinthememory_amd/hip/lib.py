@@ -22,6 +22,11 @@ class PmSgdEntry(ctypes.Structure):
     _fields_ = [('param', c_void_p), ('grad', c_void_p), ('momentum_buffer', c_void_p), ('numel', c_int64)]
 
 
+class PmWxfJob(ctypes.Structure):
+    _fields_ = [('w', c_void_p), ('wxf', c_void_p), ('wxf_bytes', c_int64), ('cout', c_int32), ('kh', c_int32), ('kw', c_int32), ('cin', c_int32),
+                ('dgrad', c_int32), ('reserved', c_int32)]
+
+
 class PmConvParams(ctypes.Structure):
     _fields_ = [('struct_size', c_int32), ('kh', c_int32), ('kw', c_int32), ('stride', c_int32), ('pad', c_int32), ('dil', c_int32), ('prec', c_int32),
                 ('wino_v', c_void_p), ('wino_v_bytes', c_int64),
@@ -58,6 +63,7 @@ SIGNATURES = {
     'pm_conv_winograd_v_bytes': (_sz, [_T, _T, _P]),
     'pm_conv_wxf_bytes': (_sz, [_T, _T, _P]),
     'pm_conv_wxf_bytes_dgrad': (_sz, [_T, _T, _P]),
+    'pm_conv_wxf_refresh_bf16': (_i, [_vp, _i, _vp]),
     'pm_conv_workspace': (_sz, [_T, _T, _P, _i]),
     'pm_conv_fwd': (_i, [_T, _vp, _T, _P, _E, _vp, _sz, _vp]),
     'pm_conv_bwd_data': (_i, [_T, _vp, _T, _P, _T, _vp, _sz, _vp]),

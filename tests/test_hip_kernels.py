@@ -840,6 +840,58 @@ def test_conv_bf16_activations(K, case, route):
         assert rel(db, b2.grad) < 2e-5
 
 
+def test_bf16_filter_refresh_after_optimizer_step(K):
+    """bf16 tier: optim.SGD.step() rewrites the kept bf16 filters (forward copy and the rotated copy of the data gradient) of the weights it moved in one batched
+    launch (pm_conv_wxf_refresh_bf16). The next convolutions must find them valid and compute exactly what a freshly derived filter gives -- for a 3x3, a 1x1,
+    and channel counts that need padding to 64 on either side."""
+    from pinthememory_amd import optim
+    K.set_conv_precision('bf16')
+    was = K.KEEP_WINOGRAD_U
+    K.KEEP_WINOGRAD_U = None
+    K._U_CACHE.clear()
+    K.unregister_filter_owners()
+    try:
+        cases = [(128, 64, 3, 1, 1), (96, 160, 1, 0, 1), (64, 256, 3, 2, 2)]        # (cout, cin, k, pad, dil)
+        ws, xs = [], []
+        for i, (co, ci, k, pad, dil) in enumerate(cases):
+            ws.append(torch.nn.Parameter(rnd(co, ci, k, k, seed=10 + i).mul(0.05).cuda().contiguous(memory_format=torch.channels_last)))
+            xs.append(K.cast(nhwc(rnd(2, ci, 20, 24, seed=20 + i)), torch.bfloat16))
+        opt = optim.SGD(ws, lr=0.1, momentum=0.9, weight_decay=0.0)
+
+        def run():
+            out = []
+            for w, x, (co, ci, k, pad, dil) in zip(ws, xs, cases):
+                wk = w.detach().permute(0, 2, 3, 1)
+                y = K.conv_fwd(x, wk, 1, pad, dil)
+                dx = K.conv_bwd_data(y, wk, x.shape, 1, pad, dil)
+                out += [y, dx]
+            return out
+        first = run()
+        assert len(K._U_CACHE) == 2 * len(cases)
+        for w in ws:
+            w.grad = torch.full_like(w, 0.01)
+        K.filter_transform_count(True)
+        n0 = K.filter_transform_count()
+        opt.step()                                                   # moves the weights, bumps the versions, refreshes the six kept filters
+        assert all(e[1] == w._version for e in K._U_CACHE.values() for w in ws if (e[0]() is w))
+        second = run()
+        assert K.filter_transform_count() == n0                      # no forward call derived a filter again
+        K.filter_transform_count(False)
+        assert not any(torch.equal(a, b) for a, b in zip(first, second))
+        K.KEEP_WINOGRAD_U = False                                    # the same calls with filters derived on the spot
+        fresh = run()
+        for a, b in zip(second, fresh):
+            assert torch.equal(a, b)
+        K.KEEP_WINOGRAD_U = None
+        assert K.refresh_bf16_filters() == 0                         # nothing out of date: no launch
+    finally:
+        K.filter_transform_count(False)
+        K.KEEP_WINOGRAD_U = was
+        K.unregister_filter_owners()
+        K._U_CACHE.clear()
+        K.set_conv_precision('f32')
+
+
 def test_conv_bf16_tier_mixed_edges(K):
     """The mixed-type call sites of the tier: the stem (fp32 NHWC4 image -> bf16, weight gradient from a bf16 dy), a 19-class head (bf16 -> fp32 logits with
     bias, fp32 dy -> bf16 dx, weight / bias gradient), a stride-2 3x3 and a stride-2 1x1 data gradient (bf16 dy -> bf16 dx + bf16 skip)."""
