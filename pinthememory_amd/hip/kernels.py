@@ -176,12 +176,15 @@ def _wino_u(p, w_krsc, nbu, dgrad=False):
     return None if valid else (ent, version)
 
 
+WXF_REFRESH = os.environ.get('PM_WXF_REFRESH', '1') != '0'      # A/B knob
+
+
 def refresh_bf16_filters():
     """bf16 tier, called by the optimizer right after it moved the weights: rewrite every kept bf16 filter (forward copy, rotated copy of the data gradient) that
     was used since the last call and is now out of date, in ONE or two launches (pm_conv_wxf_refresh_bf16) instead of one small cast in front of each of the
     ~142 convolution calls of the next step. Entries nobody used in the last step are left to go stale (their convolution re-derives them if it returns).
     The caller has already made sure no other stream still reads the buffers (optim.SGD.step: ops.wait_commit()). Returns the number of filters rewritten."""
-    if CONV_PREC != 2 or KEEP_WINOGRAD_U is False or not _U_CACHE:
+    if CONV_PREC != 2 or KEEP_WINOGRAD_U is False or not _U_CACHE or not WXF_REFRESH:
         return 0
     import weakref
     dev = torch.cuda.current_device()
