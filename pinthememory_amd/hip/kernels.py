@@ -44,7 +44,8 @@ def new(shape, like, pitch_pad=False, zero_pad=True, dtype=None):
     dtype = _act_dtype(like) if dtype is None else dtype
     if dtype == torch.bfloat16:
         if c % 64:
-            base = torch.zeros((n, h, w, (c + 63) // 64 * 64), dtype=dtype, device=like.device)
+            base = torch.empty((n, h, w, (c + 63) // 64 * 64), dtype=dtype, device=like.device)
+            base[..., c:].zero_()              # only the pad channels: every producer writes all c valid ones (a full clear of the 304 -> 320 concat buffer was 31 us)
             L.register_zero_pad(base, c, base.shape[3])
             return base[..., :c]
         return torch.empty((n, h, w, c), dtype=dtype, device=like.device)
