@@ -757,6 +757,47 @@ def test_sibling_archs_eval_and_step_vs_oracle(env, arch):
     assert worst[0] < 2e-4, worst
 
 
+@pytest.mark.parametrize('arch', ['DeepR50V3PlusD_OS8', 'DeepR50V2D', 'DeepR101V2D'])
+def test_sibling_archs_on_the_bf16_tier_vs_oracle(env, arch, capsys):
+    """The siblings on the bf16 tier (BASELINE configs[2] arithmetic on the other architectures the path serves): output stride 8 (ASPP rates 12 / 24 / 36,
+    layer3 / layer4 dilated), DeepLabV2 on ResNet-50 and on ResNet-101 (deepv2.py:44-58: four dilated 19-class heads summed -- fp32 logits out of bf16
+    features). Eval logits against the fp32 CPU oracle within 1 % of their range with identical argmax wherever the oracle's top-2 margin exceeds 0.1 (2 % of the range where the logits span less than 5), then one
+    agg step whose five losses match the oracle's fp32 step to 1 % and whose committed memory stays within 2e-2."""
+    from pinthememory_amd.hip import kernels as K
+    synth, h, o_h = env['synth'], env['harness'], env['o_harness']
+    mod = env['deepv2'] if 'V2D' in arch else env['deepv3plus']
+    ref = synth.load_det_weights(getattr(env['o_deeplab'], arch)(synth.model_args(), 19, CRIT, CRIT)).eval()
+    net = synth.load_det_weights(getattr(mod, arch)(synth.model_args(), 19, CRIT, CRIT)).cuda().eval()
+    x, y = synth.make_batch(2, 192, seed=21)
+    K.set_conv_precision('bf16')
+    try:
+        with torch.no_grad():
+            want, got = ref(x)[0], net(x.cuda())[0].cpu()
+        scale = (want.max() - want.min()).item()
+        err = (got - want).abs().max().item()
+        top2 = want.topk(2, dim=1).values
+        safe = (top2[:, 0] - top2[:, 1]) > max(0.1, 0.02 * scale) if scale > 5 else (top2[:, 0] - top2[:, 1]) > 0.02 * scale      # DeepLabV2's logits span 0.55 on these weights
+        with capsys.disabled():
+            print('\n[bf16 %s eval 2x192^2] max |logit err| %.3e = %.2e of the logit range %.2f; safe fraction %.3f' % (arch, err, err / scale, scale, safe.float().mean().item()))
+        assert got.shape == want.shape and err < 1e-2 * scale, (err, scale)
+        assert (got.argmax(1)[safe] == want.argmax(1)[safe]).all() and safe.float().mean().item() > 0.05
+        for n_ in (ref, net):
+            n_.dsn[3].p = 0.0
+        o_opt, _ = o_h.make_optimizer(ref)
+        opt, _ = h.make_optimizer(net)
+        w_l = o_h.agg_train_step(ref, o_opt, x, y)
+        g_l = h.agg_train_step(net, opt, x.cuda(), y.cuda())
+    finally:
+        K.set_conv_precision('f32')
+    for k in w_l:
+        assert abs(float(g_l[k]) - float(w_l[k])) <= 1e-2 * max(1.0, abs(float(w_l[k]))), (k, float(g_l[k]), float(w_l[k]))
+    dm = (net.memory.m_items.cpu() - ref.memory.m_items).abs().max().item()
+    with capsys.disabled():
+        print('[bf16 %s step] losses %s vs fp32 oracle %s; max |m_items - oracle| %.2e' % (arch, {k: round(float(v), 4) for k, v in g_l.items()},
+                                                                                          {k: round(float(v), 4) for k, v in w_l.items()}, dm))
+    assert dm < 2e-2, dm
+
+
 def test_three_agg_steps_vs_oracle(env):
     """Three consecutive agg steps on one batch: what a single step cannot show -- state carried from step to step (SGD momentum, BatchNorm running
     moments, the committed memory, and the Winograd filter transforms the library keeps between calls, which must follow every weight update).
