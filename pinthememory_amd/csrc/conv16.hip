@@ -30,7 +30,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int BM, int BN, int WM, int WN, int NST>
+template <int BM, int BN, int WM, int WN, int NST, bool STATS>
 __global__ __launch_bounds__(256, 2) void conv16_kernel(const pm_conv16 a) {
   constexpr int A_IT = BM / 32, B_IT = BN / 32;           // 16-byte fetches per lane and K-step: a 256-thread sweep covers 32 rows x 8 chunks
   constexpr int A_BYTES = BM * BKB, STAGE = (BM + BN) * BKB;
@@ -241,20 +241,27 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const pm_conv16 a) {
           pm_st8(C16 + row * a.c_pitch + col, v);
         }
       }
+      if constexpr (STATS)      // a separate instantiation: the kernels without statistics keep their register budget
+        pm_slab_stats16<LDC, LPR, RPI>(Ws, rr0, cc, (long)m0 + wm * (BM / WM) + i * 32, a.M, a.Nn, col, cok, bi, sc, sh, a.stats);
     }
   }
 }
 
-template <int BM, int BN, int WM, int WN, int NST>
-void launch_tile(const pm_conv16& k, dim3 grid, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, int NST, bool STATS>
+void launch_tile_s(const pm_conv16& k, dim3 grid, hipStream_t st) {
   constexpr size_t stage_bytes = (size_t)NST * (BM + BN) * BKB, ep_bytes = (size_t)4 * 32 * (BN / WN + 4) * sizeof(float);
   constexpr size_t smem = stage_bytes > ep_bytes ? stage_bytes : ep_bytes;
   static const bool attr_set = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv16_kernel<BM, BN, WM, WN, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv16_kernel<BM, BN, WM, WN, NST, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return true;
   }();
   (void)attr_set;
-  hipLaunchKernelGGL((conv16_kernel<BM, BN, WM, WN, NST>), grid, dim3(256), smem, st, k);
+  hipLaunchKernelGGL((conv16_kernel<BM, BN, WM, WN, NST, STATS>), grid, dim3(256), smem, st, k);
+}
+template <int BM, int BN, int WM, int WN, int NST>
+void launch_tile(const pm_conv16& k, dim3 grid, hipStream_t st) {
+  if (k.stats && k.ksplit == 1 && !k.c_f32) launch_tile_s<BM, BN, WM, WN, NST, true>(k, grid, st);
+  else launch_tile_s<BM, BN, WM, WN, NST, false>(k, grid, st);
 }
 
 }  // namespace

@@ -663,6 +663,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
           pm_st8(C16 + row * a.c_pitch + col, v);
         }
       }
+      if constexpr (STATS) {      // bf16 tier: statistics of the ROUNDED values of this 32-row slab (pm_common.h)
+        if (a.stats) pm_slab_stats16<LDC, LPR, RPI>(Ws, rr0, cc, (long)m0 + wm * (BM / WM) + i * 32, a.M, a.Nn, col, cok, bi, sc, sh, a.stats);
+      }
     }
     return;
   }
@@ -1505,7 +1508,7 @@ int conv_bf16(const pm_tensor* xin, const float* w, int w_cout, int w_cin, bool 
     const bool o16 = pm_is_bf16(yout);
     const bool ep_any = e0.bias || e0.scale || e0.residual || e0.relu;
     // what the kernel's two epilogues cover: bf16 rows of whole 16-byte groups with the full fused epilogue, or fp32 rows with at most a bias; no statistics
-    const bool ok = !e0.bn_partials &&
+    const bool ok = (!e0.bn_partials || o16) &&
                     (o16 ? ((yout->c | yout->pitch | (e0.residual ? e0.residual_pitch : 0)) & 7) == 0 && pm_aligned16(yout->ptr) && pm_aligned16(e0.residual)
                          : !(e0.scale || e0.residual || e0.relu));
     if (ok) {
@@ -1526,6 +1529,7 @@ int conv_bf16(const pm_tensor* xin, const float* w, int w_cout, int w_cin, bool 
       } else {
         k.C = yout->ptr;
         k.bias = e0.bias, k.scale = e0.scale, k.shift = e0.shift, k.residual = e0.residual, k.res_pitch = e0.residual_pitch, k.relu = e0.relu;
+        k.stats = o16 ? e0.bn_partials : nullptr;
         e = pm_conv16_launch(&k, st);
       }
       if (g_prof_on) {
@@ -1746,11 +1750,16 @@ extern "C" size_t pm_conv_wxf_bytes_dgrad(const pm_tensor* dy, const pm_tensor* 
 // split and a 16-byte-aligned output takes the staged epilogue; everything else (Winograd route, split-K, the 19-class heads) answers 0.
 static bool bn_partials_route(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p) {
   if (!x || !y || !p || check_common(x, y, p) != PM_OK) return false;
-  if (pm_is_bf16(x) || pm_is_bf16(y)) return false;      // the statistics epilogue exists for fp32 outputs only
-  if ((y->c & 3) || (y->pitch & 3) || !pm_aligned16(y->ptr)) return false;
   static const int on = getenv("PM_BN_EPILOGUE") ? atoi(getenv("PM_BN_EPILOGUE")) : 1;
   static const int stage_ep = getenv("PM_STAGE_EP") ? atoi(getenv("PM_STAGE_EP")) : 1;
   if (!on || !stage_ep) return false;
+  if (pm_is_bf16(y)) {      // bf16 tier: both bf16 kernels carry the statistics in their 8-column staged epilogue (one K split, whole 16-byte groups)
+    if (!pm_vec8(y)) return false;
+    const Bf16Plan b = bf16_plan(x, y, p);
+    return b.use && (b.c16 ? b.k16.ksplit == 1 : b.pl.ksplit == 1);
+  }
+  if (pm_is_bf16(x)) return false;
+  if ((y->c & 3) || (y->pitch & 3) || !pm_aligned16(y->ptr)) return false;
   if (p->prec == 2) {
     const Bf16Plan b = bf16_plan(x, y, p);
     if (b.use) return b.pl.ksplit == 1;

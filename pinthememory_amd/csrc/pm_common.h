@@ -103,6 +103,7 @@ struct pm_conv16 {
   const void* residual;      // bf16, same shape as C
   long res_pitch;
   int relu;
+  float* stats;              // train-mode BatchNorm statistics of the bf16 output: (mean, M2) per 32-row slab and channel (pm_conv_epilogue.bn_partials), or null
   int bm, bn, tiles_m, tiles_n, ksplit, ksteps_per;      // pm_conv16_plan
   long c_split;
 };
@@ -130,6 +131,59 @@ __device__ __forceinline__ void pm_st8(pm_bf16* p, const float* v) {
 }
 __device__ __forceinline__ float pm_bf16_to_f32(pm_bf16 h) { return __uint_as_float((unsigned)h << 16); }
 __device__ __forceinline__ pm_bf16 pm_f32_to_bf16(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+
+// BatchNorm statistics of one 32-row slab of a bf16 convolution output, taken where the slab is still parked in LDS as fp32 (the staged epilogues of conv16.hip
+// and conv_igemm.hip): the values are first rounded to bf16 exactly as they are stored -- the statistics are those of the tensor the BatchNorm will read -- then,
+// per column, the mean over the valid rows and M2 around it (two passes over LDS, as the fp32 statistics epilogue). A lane owns eight columns (cc ... cc + 7) of rows
+// rr0 + k * RPI; the RPI... 64 / LPR lanes sharing a column group are combined by lane exchanges in a fixed order. Output layout = pm_bn_partials_finalize's:
+// stats[(slab * Nn + col) * 2 + {0: mean, 1: M2}]. bi / sc / sh: the fused affine of the epilogue (identity in train mode unless the convolution has a bias).
+template <int LDC, int LPR, int RPI>
+__device__ __forceinline__ void pm_slab_stats16(const float* Ws, int rr0, int cc, long slab_row0, long M, long Nn, int col, bool cok, const float* bi, const float* sc,
+                                                const float* sh, float* stats) {
+  const float cnt = (float)max(0l, min(32l, M - slab_row0));
+  float s1[8], mu[8], m2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s1[e] = 0.f, m2[e] = 0.f;
+  auto slab_row = [&](int r0, float* v) {
+    const float4 v0 = *reinterpret_cast<const float4*>(Ws + (r0 + rr0) * LDC + cc), v1 = *reinterpret_cast<const float4*>(Ws + (r0 + rr0) * LDC + cc + 4);
+    const float t[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = pm_bf16_to_f32(pm_f32_to_bf16((t[e] + bi[e]) * sc[e] + sh[e]));
+    return slab_row0 + r0 + rr0 < M;
+  };
+#pragma unroll
+  for (int r0 = 0; r0 < 32; r0 += RPI) {
+    float v[8];
+    const bool rok = slab_row(r0, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] += rok ? v[e] : 0.f;
+  }
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] += __shfl_xor(s1[e], o, 64);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) mu[e] = cnt > 0.f ? s1[e] / cnt : 0.f;
+#pragma unroll
+  for (int r0 = 0; r0 < 32; r0 += RPI) {
+    float v[8];
+    const bool rok = slab_row(r0, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float d = v[e] - mu[e];
+      m2[e] += rok ? d * d : 0.f;
+    }
+  }
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m2[e] += __shfl_xor(m2[e], o, 64);
+  if (rr0 == 0 && cok && cnt > 0.f) {
+    float* dst = stats + ((slab_row0 >> 5) * Nn + col) * 2;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) *reinterpret_cast<float4*>(dst + 2 * e) = make_float4(mu[e], m2[e], mu[e + 1], m2[e + 1]);
+  }
+}
 
 __device__ __forceinline__ float pm_wave_sum(float v) {
 #pragma unroll

@@ -86,6 +86,11 @@ KEEP_WINOGRAD_V = os.environ.get('PM_KEEP_V', '1') == '1'   # forward keeps the 
 # round-off of zero, and with the default flipped one bias gradient of the mldg test (layer4.2.bn3.bias: 5.9e-3 of its norm, inside the fixed 1e-2
 # bound) lands outside that test's RELATIVE bar (3 x the reference's own fp32 error + 1e-4). A 0.3 % gain is not worth a looser gate.
 BN_EPILOGUE = os.environ.get('PM_BN_EPILOGUE', '0') == '1'
+# bf16 tier (round 4): the same epilogue exists in both bf16 kernels (pm_slab_stats16) and measures SLOWER than the separate pass -- same box, two alternated
+# pairs (tools/gpu_r4_envab.sh PM_BN_EPILOGUE16): 26.52 / 26.61 ms/step without, 26.94 / 26.94 with. The statistics pass reads a tensor the convolution has just
+# left in the 256 MB infinity cache (10 us per layer), while the epilogue form adds two LDS sweeps and 48 lane exchanges per slab to an MFMA-bound kernel and
+# hands the finalize 9 216 slab partials instead of <= 288 block partials. Opt-in (PM_BN_EPILOGUE16=1), covered by test_conv_epilogue_bn_statistics_bf16.
+BN_EPILOGUE16 = os.environ.get('PM_BN_EPILOGUE16', '0') == '1'
 
 
 # Transformed filters -- the Winograd U = G w G^T, or the bf16 copy of the weights in the bf16 tier -- kept between calls: the eval-mode forward of
@@ -272,7 +277,7 @@ def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, res
     ws = workspace(nb, x.device) if nb else None
     part = None
     if bn_partials is not None:
-        npb = npb if (BN_EPILOGUE and residual is None and not relu) else 0
+        npb = npb if ((BN_EPILOGUE16 if y.dtype == torch.bfloat16 else BN_EPILOGUE) and residual is None and not relu and scale is None) else 0
         part = torch.empty(npb // 4, dtype=torch.float32, device=x.device) if npb else None
         bn_partials.append(part)
     ep = None

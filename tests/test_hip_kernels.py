@@ -206,6 +206,51 @@ def test_conv_epilogue_bn_statistics(K, case):
     assert ps2 == [None, None, None]
 
 
+@pytest.mark.parametrize('route', [1, 2, 0])
+@pytest.mark.parametrize('case', [(2, 64, 24, 20, 256, 1, 1, 0, 1, False), (3, 64, 45, 37, 64, 3, 1, 1, 1, True), (2, 256, 47, 33, 128, 1, 1, 0, 1, False),
+                                  (8, 128, 60, 52, 128, 3, 1, 2, 2, False), (8, 512, 48, 48, 256, 3, 1, 6, 6, False)])
+def test_conv_epilogue_bn_statistics_bf16(K, case, route):
+    """The same on the bf16 tier (round 4): both bf16 kernels (route 2: LDS-DMA everywhere, 0: register-staged everywhere, 1: the per-shape default) hand out
+    the statistics of the ROUNDED bf16 output they store -- the tensor the BatchNorm reads -- so they must agree with the statistics pass over that tensor
+    (pm_bn_stats_finalize on bf16) and with torch on its values, incl. ragged last slabs, a bias, and the SyncBN moment format; the output bits do not depend on
+    the request."""
+    n, cin, h, w, cout, k, s, p, d, with_bias = case
+    x, wt = rnd(n, cin, h, w, seed=1), rnd(cout, cin, k, k, seed=2, scale=(2.0 / (cin * k * k)) ** 0.5)
+    b = rnd(cout, seed=3).cuda() if with_bias else None
+    K.set_conv_precision('bf16')
+    K.set_conv16(route)
+    try:
+        xg, wg = K.cast(nhwc(x), torch.bfloat16), wt.permute(0, 2, 3, 1).contiguous().cuda()
+        ps = []
+        prev = K.BN_EPILOGUE16
+        K.BN_EPILOGUE16 = True               # opt-in (PM_BN_EPILOGUE16=1): measured slower than the separate statistics pass, see hip/kernels.py
+        try:
+            y = K.conv_fwd(xg, wg, s, p, d, bias=b, bn_partials=ps)
+        finally:
+            K.BN_EPILOGUE16 = prev
+        assert y.dtype == torch.bfloat16 and (ps[0] is not None or route != 1), 'the default routing must take the epilogue-statistics route on these shapes'
+        assert torch.equal(K.conv_fwd(xg, wg, s, p, d, bias=b), y)
+        if ps[0] is None:      # a forced kernel that splits K on this shape: no statistics, the caller runs the pass
+            return
+        pixels = y.shape[0] * y.shape[1] * y.shape[2]
+        rm1, rv1 = torch.zeros(cout, device='cuda'), torch.ones(cout, device='cuda')
+        rm2, rv2 = rm1.clone(), rv1.clone()
+        mean1, inv1 = K.bn_partials_finalize(ps[0], pixels, cout, 1e-5, rm1, rv1, 0.1)
+        mean2, inv2 = K.bn_stats_finalize(y, 1e-5, rm2, rv2, 0.1)
+        yr = y.double().permute(0, 3, 1, 2)
+        assert rel(mean1, yr.mean((0, 2, 3))) < 1e-6 and rel(inv1, 1.0 / torch.sqrt(yr.var((0, 2, 3), unbiased=False) + 1e-5)) < 1e-6
+        assert rel(mean1, mean2) < 1e-6 and rel(inv1, inv2) < 1e-6 and rel(rm1, rm2) < 1e-6 and rel(rv1, rv2) < 1e-6
+        mom = K.bn_partials_moments(ps[0], pixels, cout)
+        assert rel(mom[cout:2 * cout], ((yr - yr.mean((0, 2, 3), keepdim=True)) ** 2).sum((0, 2, 3))) < 1e-5 and torch.all(mom[2 * cout:] == pixels)
+        assert torch.equal(K.conv_fwd(xg, wg, s, p, d, bias=b), y)
+        ps2 = []
+        K.conv_fwd(xg, wg, s, p, d, bias=b, bn_partials=ps2)      # default: off, the caller runs the statistics pass
+        assert ps2 == [None]
+    finally:
+        K.set_conv16(1)
+        K.set_conv_precision('f32')
+
+
 def test_conv_epilogue_and_slices(K):
     """eval-mode fold (scale/shift), residual, relu, and writing into a channel slice of a wider concat buffer."""
     x, wt = rnd(2, 64, 12, 12, seed=1), rnd(32, 64, 3, 3, seed=2, scale=0.05)
