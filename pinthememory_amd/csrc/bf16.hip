@@ -171,7 +171,39 @@ __global__ __launch_bounds__(256) void cast_weights_multi_kernel(const WxJobs ta
   }
 }
 
+// Stride-2 data gradient on the bf16 tier: the sub-filter of one input-pixel parity class, as the [Cin][taps'][Coutp] operand of a stride-1 forward convolution
+// of dy (conv16.hip). Taps of the class: ky = ky0 + 2 i, kx = kx0 + 2 j; the forward form visits them in flipped order (dy row = py + i' with i' = nky - 1 - i).
+// blockIdx.z = (class, tap'); a 32 x 32 [Cout][Cin] -> [Cin][Coutp] transpose per block.
+__global__ __launch_bounds__(256) void cast_weights_s2_kernel(const float* __restrict__ w, int Cout, int kh, int kw, int Cin, int Cp, const PmS2Classes cl) {
+  __shared__ float tile[32][33];
+  int zz = blockIdx.z, c = 0;
+  while (c < 4 && zz >= cl.nky[c] * cl.nkx[c]) zz -= cl.nky[c] * cl.nkx[c], ++c;
+  if (c >= 4) return;
+  const int nkx = cl.nkx[c], iy = zz / nkx, ix = zz - iy * nkx;
+  const int ky = cl.ky0[c] + 2 * (cl.nky[c] - 1 - iy), kx = cl.kx0[c] + 2 * (nkx - 1 - ix);
+  const int Tc = cl.nky[c] * nkx;
+  unsigned short* __restrict__ out = reinterpret_cast<unsigned short*>(cl.out[c]);
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // r over Cin (rows of the output), c over Cout (padded to Cp)
+  for (int j = ty; j < 32; j += 8) {
+    const int co = c0 + j, ci = r0 + tx;
+    tile[j][tx] = (co < Cout && ci < Cin) ? w[(((long)co * kh + ky) * kw + kx) * Cin + ci] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int ci = r0 + j, co = c0 + tx;
+    if (ci < Cin && co < Cp) out[((long)ci * Tc + zz) * Cp + co] = f2bf(tile[tx][j]);
+  }
+}
+
 }  // namespace
+
+int pm_bf16_cast_weights_s2(const float* w, int Cout, int kh, int kw, int Cin, int Cp, const PmS2Classes* cl, hipStream_t st) {
+  int taps = 0;
+  for (int c = 0; c < 4; ++c) taps += cl->nky[c] * cl->nkx[c];
+  if (taps == 0) return PM_OK;
+  hipLaunchKernelGGL(cast_weights_s2_kernel, dim3((Cin + 31) / 32, (Cp + 31) / 32, taps), dim3(256), 0, st, w, Cout, kh, kw, Cin, Cp, *cl);
+  return pm_check_launch("bf16_cast_weights_s2");
+}
 
 extern "C" int pm_conv_wxf_refresh_bf16(const pm_wxf_job* jobs, int n, void* stream) {
   PM_REQUIRE(n >= 0 && (jobs || n == 0), PM_EINVAL, "conv_wxf_refresh_bf16: bad job table");

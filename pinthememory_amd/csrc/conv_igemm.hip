@@ -1590,6 +1590,86 @@ inline int upcast(const pm_tensor* t, void* dst, pm_tensor* out, hipStream_t st)
 // k-contiguous GEMM as the forward pass (M = Cout, N = taps * Cin, K = pixels), split over K with fp32 slabs and a fixed-order reduce.
 // Off by default: the nine shifted copies of x a 3x3 layer needs cost more HBM time than the faster GEMM saves (bench.py --dtype bf16: GEMM
 // time 26.8 -> 23.0 ms/step, step 45.7 -> 48.1 ms); pm_set_bf16_wgrad(1) enables it (kernel tests, and the day the producers emit the copies).
+// ---- stride-2 data gradient on the bf16 tier, native (round 4): each input-pixel parity class is a stride-1 FORWARD convolution of the bf16 dy with the class'
+// sub-filter (taps ky0 + 2 i, kx0 + 2 j, visited in flipped order), run by the LDS-DMA kernel on dy where it lies; the compact class results stay fp32 (the sum
+// with the fused skip gradient is rounded ONCE, as in every other data gradient of the tier) and are interleaved into dx. Replaces: widening dy to fp32 and four
+// fp32-row gathers with per-fragment rounding.
+struct S2Native {
+  bool ok;
+  pm_conv16 k[4];
+  bool valid[4];
+  PmS2Classes cl;
+  size_t wb_off[4], out_off[4], slab_off, total;
+  long class_stride;      // floats between class buffers
+};
+S2Native s2_native_plan(const pm_tensor* dy, const pm_tensor* dx, const pm_conv_params* p) {
+  S2Native s{};
+  static const int on = getenv("PM_S2_NATIVE16") ? atoi(getenv("PM_S2_NATIVE16")) : 1;
+  if (!on || !g_conv16 || p->stride != 2 || p->dil != 1 || !pm_is_bf16(dy) || !pm_is_bf16(dx) || !pm_vec8(dy) || !pm_vec8(dx) || dy->c % 64 || dx->c % 8) return s;
+  size_t off = 0, out_bytes = 0, slab = 0;
+  for (int cls = 0; cls < 4; ++cls) {
+    const S2Class c = s2_class(cls, dx, p);
+    s.valid[cls] = c.M > 0 && c.nky * c.nkx > 0;
+    s.cl.ky0[cls] = c.ky0, s.cl.nky[cls] = s.valid[cls] ? c.nky : 0, s.cl.kx0[cls] = c.kx0, s.cl.nkx[cls] = s.valid[cls] ? c.nkx : 0;
+    out_bytes = std::max(out_bytes, (size_t)c.M * dx->c * sizeof(float));
+    if (!s.valid[cls]) continue;
+    // dy row of tap i' (flipped order) = py + (cy + pad - ky0) / 2 - (nky - 1) + i'  ->  the forward form's pad is (nky - 1) - (cy + pad - ky0) / 2, the same in x
+    const int pady = (c.nky - 1) - (c.cy + p->pad - c.ky0) / 2, padx = (c.nkx - 1) - (c.cx + p->pad - c.kx0) / 2;
+    if (pady != padx || pady < 0) return s;      // one pad for both axes in the kernel: 3x3 / pad 1 and 1x1 / pad 0 give 0 everywhere
+    pm_conv16& k = s.k[cls];
+    k = pm_conv16{};
+    k.N = dy->n, k.H = dy->h, k.W = dy->w, k.Ho = c.Hc, k.Wo = c.Wc;
+    k.a_pitch = dy->pitch, k.Cp = dy->c;
+    k.kh = c.nky, k.kw = c.nkx, k.stride = 1, k.pad = pady, k.dil = 1;
+    k.M = (int)c.M, k.Nn = dx->c, k.K = c.nky * c.nkx * dy->c, k.ksteps = k.K / 64;
+    k.c_pitch = dx->c, k.c_f32 = 1;
+    pm_conv16_plan(&k);
+    s.wb_off[cls] = off;
+    off += pm_align_up((size_t)dx->c * c.nky * c.nkx * dy->c * 2, 256);
+    slab = std::max(slab, pm_conv16_slab_bytes(&k));
+  }
+  out_bytes = pm_align_up(out_bytes, 256);
+  for (int cls = 0; cls < 4; ++cls) s.out_off[cls] = off + cls * out_bytes;
+  s.class_stride = (long)(out_bytes / sizeof(float));
+  s.slab_off = off + 4 * out_bytes;
+  s.total = s.slab_off + slab + 256;
+  s.ok = true;
+  return s;
+}
+int dgrad_s2_bf16(const pm_tensor* dy, const float* w, const pm_tensor* dx, const pm_conv_params* p, const pm_tensor* add, S2Native& s, void* ws, hipStream_t st) {
+  for (int cls = 0; cls < 4; ++cls) s.cl.out[cls] = (char*)ws + s.wb_off[cls];
+  if (int e = pm_bf16_cast_weights_s2(w, dy->c, p->kh, p->kw, dx->c, dy->c, &s.cl, st)) return e;
+  float* slab = (float*)((char*)ws + s.slab_off);
+  for (int cls = 0; cls < 4; ++cls) {
+    if (!s.valid[cls]) continue;
+    pm_conv16 k = s.k[cls];
+    k.A = (const pm_bf16*)dy->ptr, k.B = (const pm_bf16*)((char*)ws + s.wb_off[cls]);
+    void* out = (char*)ws + s.out_off[cls];
+    ProfRec rec;
+    if (g_prof_on) {
+      (void)hipEventCreate(&rec.a), (void)hipEventCreate(&rec.b);
+      rec.mode = 4, rec.bm = k.bm, rec.bn = k.bn, rec.km = 0, rec.prec = 5, rec.nst = k.ksteps_per == 1 ? 1 : 2, rec.M = k.M, rec.Nn = k.Nn, rec.K = k.K / 2, rec.batch = 1,
+      rec.ksplit = k.ksplit, rec.flops = 2.0 * (double)k.M * (double)k.Nn * (double)k.K;
+      (void)hipEventRecord(rec.a, st);
+    }
+    k.C = k.ksplit > 1 ? (void*)slab : out;
+    const int e = pm_conv16_launch(&k, st);
+    if (g_prof_on) {
+      (void)hipEventRecord(rec.b, st);
+      g_prof.push_back(rec);
+    }
+    if (e) return e;
+    if (k.ksplit > 1)
+      if (int e2 = splitk_reduce(slab, k.ksplit, k.M, k.Nn, (float*)out, (long)dx->c, nullptr, nullptr, nullptr, nullptr, 0l, 0, st, false)) return e2;
+  }
+  const int valid_mask = s.valid[0] | (s.valid[1] << 1) | (s.valid[2] << 2) | (s.valid[3] << 3);
+  const long total = pm_pixels(dx) * (dx->c / 4);
+  hipLaunchKernelGGL(dgrad_s2_interleave_kernel<true>, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, st, (const float*)((char*)ws + s.out_off[0]),
+                     s.class_stride, valid_mask, (float*)dx->ptr, (long)dx->pitch, dx->n, dx->h, dx->w, dx->c, add ? (const float*)add->ptr : nullptr,
+                     add ? (long)add->pitch : 0l);
+  return pm_check_launch("dgrad_s2_interleave(native bf16 classes)");
+}
+
 int g_bf16_wgrad = 0;
 struct Bf16WgradPlan {
   bool use;
@@ -1780,6 +1860,10 @@ extern "C" size_t pm_conv_workspace(const pm_tensor* x, const pm_tensor* y, cons
   const pm_conv_params tp = tier_params(p0, x, y);
   const pm_conv_params* p = &tp;
   if (which == MODE_DGRAD && p->stride == 2) {   // four parity classes: compact results + the largest split-K slab set
+    {
+      const S2Native s = s2_native_plan(y, x, p);      // (x = dx, y = dy in this query)
+      if (s.ok) return s.total;
+    }
     size_t slab = 0, tmp = 0;      // (+ the fp32 copy of a bf16 dy below: on the bf16 tier the stride-2 data gradient still gathers fp32 rows)
     for (int cls = 0; cls < 4; ++cls) {
       const S2Class c = s2_class(cls, x, p);
@@ -1907,7 +1991,11 @@ extern "C" int pm_conv_bwd_data(const pm_tensor* dy0, const float* w, const pm_t
     const size_t need = pm_conv_workspace(dx, dy, p, MODE_DGRAD);
     PM_REQUIRE(ws && ws_bytes >= need, PM_EWORKSPACE, "conv_bwd_data(stride 2): workspace %zu < %zu", ws_bytes, need);
     PM_REQUIRE(dx->c % 4 == 0, PM_EUNSUPPORTED, "conv_bwd_data(stride 2): Cin %% 4 != 0");
-    if (pm_is_bf16(dy)) {      // bf16 tier: the parity-class gather reads fp32 rows -- dy (a quarter of dx's pixels) is widened once, at the end of the workspace
+    {
+      S2Native s = s2_native_plan(dy, dx, p);
+      if (s.ok) return dgrad_s2_bf16(dy, w, dx, p, add, s, ws, st0);
+    }
+    if (pm_is_bf16(dy)) {      // bf16 tier, shapes the native form does not take: the parity-class gather reads fp32 rows -- dy (a quarter of dx's pixels) is widened once, at the end of the workspace
       if (int e = upcast(dy0, (char*)ws + need - upcast_bytes(dy0), &dy32, st0)) return e;
       dy = &dy32;
     }

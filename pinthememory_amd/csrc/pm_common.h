@@ -59,6 +59,11 @@ int pm_wino_dw_xf(const float* slab, int ks, int Cout, int Cin, int Kp, int m, f
 // ---- bf16 operand preparation of the convolution kernels (bf16.hip; prec = 2) ----------------------------------------------------------
 int pm_bf16_cast_rows(const float* x, long pitch, int C, int Cp, long P, void* out, hipStream_t st);
 int pm_bf16_cast_weights(const float* w, int Cout, int T, int Cin, int Cp, bool rotate, void* out, hipStream_t st);
+struct PmS2Classes {      // the four input-pixel parity classes of a stride-2 data gradient: tap subset (ky0 + 2 i, kx0 + 2 j) and the class' bf16 sub-filter buffer
+  int ky0[4], nky[4], kx0[4], nkx[4];
+  void* out[4];
+};
+int pm_bf16_cast_weights_s2(const float* w, int Cout, int kh, int kw, int Cin, int Cp, const PmS2Classes* cl, hipStream_t st);
 int pm_bf16_transpose_taps(const float* x, long pitch, int C, int N, int H, int W, int Ho, int Wo, int kh, int kw, int stride, int pad, int dil, void* out,
                            hipStream_t st);
 

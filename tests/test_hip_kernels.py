@@ -974,16 +974,20 @@ def test_conv_bf16_tier_mixed_edges(K):
         F.conv2d(x, w2, b2).backward(r16(dy))
         assert rel(dw.permute(0, 3, 1, 2), w2.grad) < 2e-4 and rel(db, dy.sum((0, 2, 3))) < 2e-5
         # stride-2 data gradients
-        for cin, cout, k, p in ((128, 128, 3, 1), (256, 512, 1, 0)):
+        # (round 4: each parity class is a forward convolution of the bf16 dy with its sub-filter, on the LDS-DMA kernel; odd map sizes leave the classes unequal;
+        #  a 96-channel dy -- not a multiple of 64 -- takes the older fp32-row form)
+        for cin, cout, k, p, hh, ww in ((128, 128, 3, 1, 24, 24), (256, 512, 1, 0, 24, 24), (128, 128, 3, 1, 25, 23), (64, 192, 1, 0, 17, 31), (64, 96, 3, 1, 20, 18)):
             wt = rnd(cout, cin, k, k, seed=8, scale=(2.0 / (cin * k * k)) ** 0.5)
             wg = wt.permute(0, 2, 3, 1).contiguous().cuda()
-            x2 = torch.zeros(2, cin, 24, 24, requires_grad=True)
+            x2 = torch.zeros(2, cin, hh, ww, requires_grad=True)
             yr = F.conv2d(x2, r16(wt), None, stride=2, padding=p)
-            dy, skip = r16(rnd(*yr.shape, seed=9)), r16(rnd(2, cin, 24, 24, seed=10))
+            dy, skip = r16(rnd(*yr.shape, seed=9)), r16(rnd(2, cin, hh, ww, seed=10))
             yr.backward(dy)
-            dx = K.conv_bwd_data(b16(dy), wg, (2, 24, 24, cin), 2, p, 1, add=b16(skip))
+            dx = K.conv_bwd_data(b16(dy), wg, (2, hh, ww, cin), 2, p, 1, add=b16(skip))
             assert dx.dtype == torch.bfloat16
             close16(nchw(dx.float()), x2.grad + skip, ulps=1.5)
+            dx0 = K.conv_bwd_data(b16(dy), wg, (2, hh, ww, cin), 2, p, 1)      # without the fused skip gradient
+            close16(nchw(dx0.float()), x2.grad, ulps=1.5)
     finally:
         K.set_conv_precision('f32')
 
