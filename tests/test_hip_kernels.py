@@ -885,6 +885,52 @@ def test_conv_bf16_activations(K, case, route):
         assert rel(db, b2.grad) < 2e-5
 
 
+@pytest.mark.parametrize('case', [(8, 512, 48, 48, 256, 3, 6, 6), (8, 1024, 48, 48, 512, 1, 0, 1), (8, 256, 47, 49, 256, 3, 1, 1), (5, 512, 48, 48, 19, 1, 0, 1)])
+def test_conv16_on_the_48x48_maps(K, case):
+    """The LDS-DMA kernel at the shapes it carries in the step (bs=8: 18 432 rows, 576 ... 1 152 tiles of 64 x 128 on 256 CUs, a ragged last tile, the 19-column
+    fp32 logits): forward with bias / folded scale-shift / residual / ReLU and the data gradient with its fused skip, each against the fp32 formula on the same
+    bf16 values and against the register-staged kernel. (Written for the hybrid K-split of the last partial round of tiles and the 3 / 4-stage LDS ring with
+    counted vmcnt waits, both measured and dropped -- DESIGN section 7; kept as the full-size check of the kernel.)"""
+    n, cin, h, w, cout, k, p, d = case
+    r16 = lambda t: t.bfloat16().float()
+    x, wt = r16(rnd(n, cin, h, w, seed=1)), rnd(cout, cin, k, k, seed=2, scale=(2.0 / (cin * k * k)) ** 0.5)
+    logits = cout == 19
+    b = rnd(cout, seed=3)
+    sc, sh = rnd(cout, seed=6).abs() + 0.5, rnd(cout, seed=7)
+    res = r16(rnd(n, cout, h, w, seed=8))
+    y_lin = F.conv2d(x, r16(wt), None, padding=p, dilation=d)
+    dy, skip = r16(rnd(*y_lin.shape, seed=4)), r16(rnd(n, cin, h, w, seed=5))
+    K.set_conv_precision('bf16')
+    outs = {}
+    try:
+        wg = wt.permute(0, 2, 3, 1).contiguous().cuda()
+        for route in (2, 0):
+            K.set_conv16(route)
+            if logits:
+                y = K.conv_fwd(b16(x), wg, 1, p, d, bias=b.cuda(), out_dtype=torch.float32)
+                outs[route] = (y,)
+                continue
+            y0 = K.conv_fwd(b16(x), wg, 1, p, d, bias=b.cuda())
+            y1 = K.conv_fwd(b16(x), wg, 1, p, d, scale=sc.cuda(), shift=sh.cuda(), residual=b16(res), relu=True)
+            dx = K.conv_bwd_data(b16(dy), wg, (n, h, w, cin), 1, p, d, add=b16(skip))
+            outs[route] = (y0, y1, dx)
+    finally:
+        K.set_conv16(1)
+        K.set_conv_precision('f32')
+    if logits:
+        assert outs[2][0].dtype == torch.float32
+        assert rel(nchw(outs[2][0]), y_lin + b.view(1, -1, 1, 1)) < 2e-5 and rel(outs[2][0], outs[0][0]) < 2e-5
+        return
+    y0, y1, dx = outs[2]
+    close16(nchw(y0.float()), y_lin + b.view(1, -1, 1, 1), ulps=1.5)
+    close16(nchw(y1.float()), torch.relu(y_lin * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res), ulps=1.5)
+    x2 = x.clone().requires_grad_(True)
+    F.conv2d(x2, r16(wt), None, padding=p, dilation=d).backward(dy)
+    close16(nchw(dx.float()), x2.grad + skip, ulps=1.5)
+    for a, c in zip(outs[2], outs[0]):      # the two kernels differ by accumulation order only: neighbouring bf16 values at most (one spacing = 2^-7)
+        close16(a.float(), c.float(), ulps=2.5)
+
+
 def test_bf16_filter_refresh_after_optimizer_step(K):
     """bf16 tier: optim.SGD.step() rewrites the kept bf16 filters (forward copy and the rotated copy of the data gradient) of the weights it moved in one batched
     launch (pm_conv_wxf_refresh_bf16). The next convolutions must find them valid and compute exactly what a freshly derived filter gives -- for a 3x3, a 1x1,
