@@ -30,6 +30,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// one 16-byte LDS-DMA fetch through a buffer descriptor: lane l of the wave lands at dst + 16 l (dst wave-uniform -> m0), out-of-range offsets deliver zeros.
+// (A __device__ function of its own: with the builtin written into the kernel template the host pass silently drops the kernel's stub -- ROCm 7.2.)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, char* dst, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, voff, soff, 0, 0);
+}
+
 template <int BM, int BN, int WM, int WN, int NST, bool STATS>
 __global__ __launch_bounds__(256, 2) void conv16_kernel(const pm_conv16 a) {
   constexpr int A_IT = BM / 32, B_IT = BN / 32;           // 16-byte fetches per lane and K-step: a 256-thread sweep covers 32 rows x 8 chunks
@@ -44,12 +50,18 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const pm_conv16 a) {
   const int m0 = (lid / a.tiles_n) * BM, n0 = (lid % a.tiles_n) * BN;
   const int z = blockIdx.z;
   const int kt0 = z * a.ksteps_per, nk = min(a.ksteps - kt0, a.ksteps_per);      // this block's K-steps [kt0, kt0 + nk)
-  const char* zp = reinterpret_cast<const char*>(pm_zero_page16);
   const long pitchb = a.a_pitch * 2;
 
   // ---- per-lane staging constants: this lane's rows of the A and B tiles and the (swizzled) 16-byte chunk it fetches of each ----------------------------
-  const char* abase[A_IT];
-  int ay0[A_IT], ax0[A_IT];
+  // Addressing (round 4, second form): both operands are fetched through BUFFER descriptors -- a 32-bit byte offset per lane, and a lane that must read zeros
+  // (padding tap, row beyond M, column beyond N) simply presents an offset beyond the descriptor's range: the fetch returns 0 into LDS. The first form built a
+  // 64-bit source pointer per fetch and selected a zero page for such lanes: 59 VALU + 56 SALU instructions per wave and K-step around 8 MFMAs.
+  const __amdgpu_buffer_rsrc_t rA =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<pm_bf16*>(a.A), 0, (int)((long)a.N * a.H * a.W * pitchb), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<pm_bf16*>(a.B), 0, (int)((long)a.Nn * a.K * 2), 0x00020000);
+  constexpr int OOB = 0x7fffffff;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // wave-uniform by construction: the LDS destination of a fetch lives on the scalar unit
+  int aoff[A_IT], ay0[A_IT], ax0[A_IT];
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) {
     const int u = it * 256 + t, row = u >> 3, ch = (u & 7) ^ ((row >> 1) & 7);
@@ -58,44 +70,39 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const pm_conv16 a) {
       const int img = m / (a.Ho * a.Wo), rem = m - img * (a.Ho * a.Wo);
       const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
       ay0[it] = oy * a.stride - a.pad, ax0[it] = ox * a.stride - a.pad;
-      abase[it] = reinterpret_cast<const char*>(a.A) + ((long)(img * a.H + ay0[it]) * a.W + ax0[it]) * pitchb + ch * 16;
+      aoff[it] = (int)(((long)(img * a.H + ay0[it]) * a.W + ax0[it]) * pitchb) + ch * 16;      // may be negative at the image border: only used with an in-range tap added
     } else {
       ay0[it] = ax0[it] = -(1 << 28);      // never inside the image: the row reads zeros
-      abase[it] = zp;
+      aoff[it] = 0;
     }
   }
-  const char* bbase[B_IT];
+  int boff[B_IT];
 #pragma unroll
   for (int it = 0; it < B_IT; ++it) {
     const int u = it * 256 + t, row = u >> 3, ch = (u & 7) ^ ((row >> 1) & 7);
     const int n = n0 + row;
-    bbase[it] = n < a.Nn ? reinterpret_cast<const char*>(a.B) + (long)n * a.K * 2 + ch * 16 : nullptr;
+    boff[it] = n < a.Nn ? n * a.K * 2 + ch * 16 : OOB;
   }
   // wave-uniform K-state: (tap, channel chunk) of the next K-step to stage
   const int cpc = a.Cp >> 6;      // 64-channel chunks per tap
   int s_tap = kt0 / cpc, s_ch = kt0 - s_tap * cpc, s_ky = s_tap / a.kw, s_kx = s_tap - s_ky * a.kw;
   s_tap = __builtin_amdgcn_readfirstlane(s_tap), s_ch = __builtin_amdgcn_readfirstlane(s_ch);
   s_ky = __builtin_amdgcn_readfirstlane(s_ky), s_kx = __builtin_amdgcn_readfirstlane(s_kx);
-  long s_kb = (long)kt0 * BKB;      // byte offset of the K-step inside a weight row
+  int s_kb = kt0 * BKB;      // byte offset of the K-step inside a weight row (scalar offset of the B fetches)
 
   auto stage = [&](int buf) {
     char* la = lds + buf * STAGE;
     char* lb = la + A_BYTES;
     const int dy = s_ky * a.dil, dx = s_kx * a.dil;
-    const long toff = ((long)dy * a.W + dx) * pitchb + (long)s_ch * BKB;
+    const int toff = (dy * a.W + dx) * (int)pitchb + s_ch * BKB;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       const bool ok = ((unsigned)(ay0[it] + dy) < (unsigned)a.H) & ((unsigned)(ax0[it] + dx) < (unsigned)a.W);
-      const char* src = ok ? abase[it] + toff : zp;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(la + (it * 256 + wave * 64) * 16), 16, 0,
-                                       0);
+      dma16(rA, la + (it * 256 + wave_u * 64) * 16, ok ? aoff[it] + toff : OOB, 0);
     }
 #pragma unroll
-    for (int it = 0; it < B_IT; ++it) {
-      const char* src = bbase[it] ? bbase[it] + s_kb : zp;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(lb + (it * 256 + wave * 64) * 16), 16, 0,
-                                       0);
-    }
+    for (int it = 0; it < B_IT; ++it)
+      dma16(rB, lb + (it * 256 + wave_u * 64) * 16, boff[it], s_kb);
     // advance the K-state (scalar unit)
     s_kb += BKB;
     if (++s_ch == cpc) {

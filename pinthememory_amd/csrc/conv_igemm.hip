@@ -1479,7 +1479,9 @@ Bf16Plan bf16_plan(const pm_tensor* xin, const pm_tensor* yout, const pm_conv_pa
     // Where it wins (per-shape A/B, profiles/r04c_conv16_vs_regstaged.txt): 64-row tiles -- the 48 x 48 and 96 x 96 maps, 525 -> 655-700 TF on their 3x3s -- and the
     // single-K-step 1x1s (four blocks per CU). On 128 x 128 tiles the register-staged kernel's scheduled interleave is still ~10 % ahead (883 vs 982 TF on the
     // decoder's 3x3): those stay there. PM_CONV16=2 forces the LDS-DMA kernel everywhere.
-    b.c16 = c16_on == 2 || k.bm == 64 || k.ksteps_per == 1;
+    // (second form of the kernel, buffer-descriptor fetches: it also takes the long reductions the register-staged planner would run on 64-row tiles -- the
+    //  3x3 512 -> 1024-wide data gradients at 48 x 48: 596 -> 877 TF on 128 x 128 -- while the short 1x1 reductions stay with the single-stage register-staged form)
+    b.c16 = c16_on == 2 || k.bm == 64 || k.ksteps_per == 1 || (b.pl.bm == 64 && k.ksteps >= 16);
   }
   return b;
 }
