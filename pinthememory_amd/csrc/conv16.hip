@@ -62,11 +62,15 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const pm_conv16 a) {
   constexpr int OOB = 0x7fffffff;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // wave-uniform by construction: the LDS destination of a fetch lives on the scalar unit
   int aoff[A_IT], ay0[A_IT], ax0[A_IT];
+  const bool pointwise = a.kh * a.kw == 1 && a.stride == 1 && a.pad == 0 && a.Ho == a.H && a.Wo == a.W;      // block-uniform
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) {
     const int u = it * 256 + t, row = u >> 3, ch = (u & 7) ^ ((row >> 1) & 7);
     const int m = m0 + row;
-    if (m < a.M) {
+    if (m < a.M && pointwise) {      // 1x1 / stride 1 / no padding: output pixel m reads input pixel m -- no index decomposition (two integer divisions per row)
+      ay0[it] = ax0[it] = 0;
+      aoff[it] = (int)((long)m * pitchb) + ch * 16;
+    } else if (m < a.M) {
       const int img = m / (a.Ho * a.Wo), rem = m - img * (a.Ho * a.Wo);
       const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
       ay0[it] = oy * a.stride - a.pad, ax0[it] = ox * a.stride - a.pad;
