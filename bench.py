@@ -314,7 +314,9 @@ def memory_path_roofline(batch, size):
     cases = [     # (name, reference lines, algorithmic bytes per launch, launch)
         ('mem_read_fwd', 'memory.py:317-336', N * d * 4 + m * d * 4 + N * 2 * d * 4 + 2 * N * m * 4, lambda: K.mem_read_fwd(x, mem)),
         ('mem_read_bwd', 'memory.py:317-336 (autograd)', N * 2 * d * 4 + 2 * N * d * 4 + 2 * N * m * 4, lambda: K.mem_read_bwd(x, mem, pmem, dqr, dsx)),
-        ('mem_colsoftmax', 'memory.py:186', 2 * N * m * 4, lambda: K.mem_colsoftmax(score)),
+        ('mem_read_fwd_with_p_query', 'memory.py:317-336 + :186 (the step\'s form: the read kernel leaves the column partials of the softmax over all queries, a second '
+         'launch normalises)', N * d * 4 + m * d * 4 + N * 2 * d * 4 + 3 * N * m * 4, lambda: K.mem_read_fwd_pq(x, mem)),
+        ('mem_colsoftmax', 'memory.py:186 (standalone two-launch form; not on the step since round 4)', 2 * N * m * 4, lambda: K.mem_colsoftmax(score)),
         ('mem_write_accum', 'memory.py:219-231', N * d * 4 + B * 4 * h * h * 8 + (m + 1) * (d + 1) * 4, lambda: K.mem_write_accum(x, lab, m)),
         ('readloss_fwd', 'memory.py:173-176', B * H * H * 8 + N * m * 4, lambda: K.upsample_ce_fwd(lg, lab, 1.0)),
         ('readloss_bwd', 'memory.py:173-176 (autograd)', B * H * H * 8 + 2 * N * m * 4, lambda: K.upsample_ce_bwd(lg, lab, lo, None, 1.0)),

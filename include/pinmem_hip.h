@@ -281,6 +281,12 @@ int pm_mem_read_fwd(const pm_tensor* x, const float* mem, int m, const float* gu
 size_t pm_mem_colsoftmax_workspace(int64_t rows, int m);
 int pm_mem_colsoftmax(const float* score, const float* noise /*nullable*/, int64_t rows, int m, float* p_query,
                       void* ws, size_t ws_bytes, void* stream);
+/* read + softmax over all queries (memory.py:317-336 with get_score :183-189 complete) in two launches: the read kernel also leaves
+ * per-tile column (max, sum exp) partials of score + noise_q, the second launch merges them in fixed order and writes p_query [N][m].
+ * noise / noise_q: the two independent gumbel draws of F.gumbel_softmax(dim=1) / (dim=0); both nullable. */
+size_t pm_mem_read_fwd_pq_workspace(int64_t rows, int m);
+int pm_mem_read_fwd_pq(const pm_tensor* x, const float* mem, int m, const float* gumbel_noise, const float* gumbel_noise_q,
+                       const pm_tensor* qr, float* score, float* p_mem, float* p_query, void* ws, size_t ws_bytes, void* stream);
 /* backward into x (and into mem when dmem != NULL): dqr [N][2d], dscore_extra [N][m] (from the read loss; nullable) */
 size_t pm_mem_read_bwd_workspace(int64_t rows, int m, int d);
 int pm_mem_read_bwd(const pm_tensor* x, const float* mem, int m, const float* p_mem, const pm_tensor* dqr,

@@ -16,6 +16,7 @@ namespace {
 constexpr int D = 256;     // feature dim (mem_dim); one wave = one row of 64 float4
 constexpr int MAXM = 32;   // max slots (+1 for the ignore class in write)
 constexpr float EPS = 1e-12f;
+typedef float mr_f32x16 __attribute__((ext_vector_type(16)));   // one 32x32 fp32 MFMA result tile per wave
 
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
@@ -53,23 +54,57 @@ __global__ __launch_bounds__(256) void mem_colsoftmax_partial_kernel(const float
     part[((long)blockIdx.x * M + c) * 2 + 1] = acc.s;
   }
 }
-__global__ __launch_bounds__(256) void mem_colsoftmax_apply_kernel(const float* __restrict__ score, const float* __restrict__ noise, long rows, int M,
-                                                                   const float* __restrict__ part, int nb, float* __restrict__ out) {
-  __shared__ MaxSum red[8][32];
+// Apply pass (round 4 form). What bounded the older one was the chain of dependent L2 round trips per thread (one partial load + merge after the other:
+// 12 us for 144 partials, 35-44 us for the 576 32-row tiles the read kernel leaves), not arithmetic. Now a 1 024-thread block = (column c < 32) x (32 ranges
+// of partials): a thread's <= 24 partials are loaded in one go into registers (all in flight at once), the global max per column is found first, then
+// sum_b s_b exp(m_b - max) with independent terms; ranges are combined in order through LDS: deterministic. 256 rows per block.
+constexpr int CSA_T = 1024, CSA_PER = 24, CSA_ROWS = 256;
+__global__ __launch_bounds__(CSA_T) void mem_colsoftmax_apply_kernel(const float* __restrict__ score, const float* __restrict__ noise, long rows, int M,
+                                                                     const float* __restrict__ part, int nb, float* __restrict__ out) {
+  __shared__ float red[32][33];
   const int c = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  MaxSum g = {-INFINITY, 0.f};
-  if (c < M) {   // row lane rl merges partials [rl * per, (rl + 1) * per): contiguous ranges keep the overall order fixed
-    const int per = (nb + 7) / 8;
-    for (int b = rl * per; b < min(nb, (rl + 1) * per); ++b) g = cs_merge(g, MaxSum{part[((long)b * M + c) * 2], part[((long)b * M + c) * 2 + 1]});
-  }
-  red[rl][c] = g;
-  __syncthreads();
-  g = red[0][c];
+  const int per = (nb + 31) / 32, b0 = rl * per, b1 = min(nb, b0 + per);
+  const float2* p2 = reinterpret_cast<const float2*>(part);
+  const bool regs = per <= CSA_PER;
+  float2 pv[CSA_PER];
+  float gm = -INFINITY;
+  if (regs) {
 #pragma unroll
-  for (int i = 1; i < 8; ++i) g = cs_merge(g, red[i][c]);
+    for (int i = 0; i < CSA_PER; ++i) {
+      pv[i] = make_float2(-INFINITY, 0.f);
+      if (c < M && b0 + i < b1) pv[i] = p2[(long)(b0 + i) * M + c];
+    }
+#pragma unroll
+    for (int i = 0; i < CSA_PER; ++i) gm = fmaxf(gm, pv[i].x);
+  } else if (c < M) {
+    for (int b = b0; b < b1; ++b) gm = fmaxf(gm, p2[(long)b * M + c].x);
+  }
+  red[rl][c] = gm;
+  __syncthreads();
+  gm = red[0][c];
+#pragma unroll
+  for (int i = 1; i < 32; ++i) gm = fmaxf(gm, red[i][c]);
+  __syncthreads();
+  float gs = 0.f;
+  if (regs) {
+#pragma unroll
+    for (int i = 0; i < CSA_PER; ++i) gs += pv[i].x == -INFINITY ? 0.f : pv[i].y * expf(pv[i].x - gm);
+  } else if (c < M) {
+    for (int b = b0; b < b1; ++b) {
+      const float2 p = p2[(long)b * M + c];
+      gs += p.x == -INFINITY ? 0.f : p.y * expf(p.x - gm);
+    }
+  }
+  red[rl][c] = gs;
+  __syncthreads();
+  gs = red[0][c];
+#pragma unroll
+  for (int i = 1; i < 32; ++i) gs += red[i][c];
   if (c >= M) return;
-  const long r0 = (long)blockIdx.x * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
-  for (long r = r0 + rl; r < r1; r += 8) out[r * M + c] = expf(score[r * M + c] + (noise ? noise[r * M + c] : 0.f) - g.m) / g.s;
+  const long r0 = (long)blockIdx.x * CSA_ROWS, r1 = min(rows, r0 + CSA_ROWS);
+  const float rgs = 1.f / gs;
+#pragma unroll 8
+  for (long r = r0 + rl; r < r1; r += 32) out[r * M + c] = expf(score[r * M + c] + (noise ? noise[r * M + c] : 0.f) - gm) * rgs;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -232,6 +267,133 @@ __global__ __launch_bounds__(256) void mem_write_accum_kernel(const float* __res
   }
 }
 
+// The same accumulation as a split-K product on the matrix cores: nominator[c][d] = sum_r Y[r][c] * zhat[r][d] with Y the (<= 4 non-zeros per row)
+// soft-label matrix, i.e. a (32 padded classes) x (64-row chunk) x (256 channels) GEMM per chunk, K split over the blocks. What bounded the slab
+// kernel above was not bytes but its dependent chain -- 18 rows per wave, each a global round trip plus four LDS read-modify-writes (44 us for
+// 19 MB); here every row of a chunk is in flight at once (16 float4 per lane), and the scatter by class becomes the A operand:
+//   * wave w = (channel half ch = w & 1, row half rh = w >> 1); lane (l31 = lane & 31, half = lane >> 5) loads, for s = 0..15, the float4 of row
+//     32 rh + 2 s + half at channels 128 ch + 4 l31: half-waves read 512 contiguous bytes;
+//   * row norms: per-lane partial sums of squares parked in LDS, four threads per row fold the 64 partials in fixed order; the 1 / max(norm, eps)
+//     is folded into the class weights (A[c][r] = (sum of the row's tap weights of class c) / norm_r), so z itself is never rescaled;
+//   * 4 MFMAs (32x32x2 f32) per loaded float4: B = component e of the float4 (output column l31 of tile e = channel 128 ch + 4 l31 + e), so each
+//     lane ends up with float4s of consecutive channels per class -- partial rows leave as 512-byte runs;
+//   * denominators are summed outside the product (plain tap weights, fixed order); the two row halves meet in LDS (fixed order).
+// Deterministic, no atomics; partial layout = the slab kernel's, so reduce_partials_kernel finishes both.
+constexpr int AM_ROWS = 64;                 // rows per chunk
+constexpr int AM_SSP = 65;                  // padded row of partial squared norms
+__global__ __launch_bounds__(256) void mem_write_accum_mfma_kernel(const float* __restrict__ z, long zp, int n, int h, int w, const int64_t* __restrict__ lab,
+                                                                   int H, int W, int m, int normalize, float sy, float sx, float* __restrict__ part) {
+  __shared__ __align__(16) float am_ss[MAXM * D];              // partial squared norms [64][65]; afterwards the row-half exchange tile [m + 1][256]
+  __shared__ __align__(16) int am_cls[AM_ROWS][4];
+  __shared__ __align__(16) float am_w[AM_ROWS][4];
+  __shared__ float am_rn[AM_ROWS];
+  __shared__ float am_den[8][32];
+  static_assert(AM_ROWS * AM_SSP <= MAXM * D, "the squared-norm partials share the exchange tile");
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+  const int ch = wv & 1, rh = wv >> 1;
+  const long rows = (long)n * h * w;
+  const long nchunks = (rows + AM_ROWS - 1) / AM_ROWS;
+  mr_f32x16 acc[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[e][q] = 0.f;
+  float den = 0.f;                                              // thread t < 32: denominator of class t
+  for (long chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const long r0 = chunk * AM_ROWS;
+    if (chunk != (long)blockIdx.x) __syncthreads();             // the previous chunk is done with the tap tables
+    float4 v[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) v[s] = PM_LD4(z + min(r0 + 32 * rh + 2 * s + half, rows - 1) * zp + 128 * ch + 4 * l31);
+    if (threadIdx.x < AM_ROWS) {                                // the row's four label taps (rows past the end: no class)
+      const long rr = r0 + threadIdx.x;
+      Taps t;
+      if (rr < rows) {
+        const unsigned r32 = (unsigned)rr, px = r32 / (unsigned)w;                  // rows < 2^31 (checked by the launcher): 32-bit divisions
+        t = soft_label_taps(lab, (int)(px / (unsigned)h), (int)(px % (unsigned)h), (int)(r32 % (unsigned)w), H, W, h, w, sy, sx, m);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t.cls[k] = -1, t.w[k] = 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) am_cls[threadIdx.x][k] = t.cls[k], am_w[threadIdx.x][k] = t.cls[k] < 0 ? 0.f : t.w[k];
+    }
+    if (normalize) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) am_ss[(32 * rh + 2 * s + half) * AM_SSP + 32 * ch + l31] = dot4(v[s], v[s]);
+    }
+    __syncthreads();
+    {
+      const int row = threadIdx.x >> 2, pq = threadIdx.x & 3;
+      float s2 = 0.f;
+      if (normalize) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s2 += am_ss[row * AM_SSP + 16 * pq + i];
+        s2 += __shfl_xor(s2, 1, 64);
+        s2 += __shfl_xor(s2, 2, 64);
+      }
+      if (pq == 0) am_rn[row] = normalize ? 1.f / fmaxf(sqrtf(s2), EPS) : 1.f;
+      // denominators: class c = t & 31 over the 8 rows of group t >> 5, tap order
+      const int c = threadIdx.x & 31, grp = threadIdx.x >> 5;
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d += am_cls[8 * grp + i][k] == c ? am_w[8 * grp + i][k] : 0.f;
+      am_den[grp][c] = d;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      float d = am_den[0][threadIdx.x];
+#pragma unroll
+      for (int g = 1; g < 8; ++g) d += am_den[g][threadIdx.x];
+      den += d;
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int rr = 32 * rh + 2 * s + half;
+      const int4 tc = *reinterpret_cast<const int4*>(am_cls[rr]);
+      const float4 tw = *reinterpret_cast<const float4*>(am_w[rr]);
+      float a = (tc.x == l31 ? tw.x : 0.f);
+      a += (tc.y == l31 ? tw.y : 0.f);
+      a += (tc.z == l31 ? tw.z : 0.f);
+      a += (tc.w == l31 ? tw.w : 0.f);
+      a *= am_rn[rr];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v[s].x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v[s].y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v[s].z, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v[s].w, acc[3], 0, 0, 0);
+    }
+  }
+  // the two row halves meet in LDS: rh = 1 parks, rh = 0 adds and stores. Register q of a lane = class (q & 3) + 8 (q >> 2) + 4 half.
+  __syncthreads();
+  float* xch = am_ss;                                           // [m + 1][256]
+  if (rh == 1) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int c = (q & 3) + 8 * (q >> 2) + 4 * half;
+      if (c <= m) *reinterpret_cast<float4*>(xch + c * D + 128 * ch + 4 * l31) = make_float4(acc[0][q], acc[1][q], acc[2][q], acc[3][q]);
+    }
+  }
+  __syncthreads();
+  const int nout = (m + 1) * D + (m + 1);
+  float* mine = part + (long)blockIdx.x * nout;
+  if (rh == 0) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int c = (q & 3) + 8 * (q >> 2) + 4 * half;
+      if (c <= m) {
+        const float4 o = *reinterpret_cast<const float4*>(xch + c * D + 128 * ch + 4 * l31);
+        float* dst = mine + c * D + 128 * ch + 4 * l31;         // 512-byte runs per half-wave
+        const float4 r = make_float4(acc[0][q] + o.x, acc[1][q] + o.y, acc[2][q] + o.z, acc[3][q] + o.w);
+        if ((nout & 3) == 0) PM_ST4(dst, r);                    // block partials are 16-byte aligned when (m + 1) % 4 == 0 (19 classes + ignore)
+        else dst[0] = r.x, dst[1] = r.y, dst[2] = r.z, dst[3] = r.w;
+      }
+    }
+  }
+  if ((int)threadIdx.x <= m) mine[(m + 1) * D + threadIdx.x] = den;
+}
+
 __global__ __launch_bounds__(256) void mem_write_accum_bwd_kernel(const float* __restrict__ z, long zp, int n, int h, int w, const int64_t* __restrict__ lab,
                                                                   int H, int W, int m, int normalize, float sy, float sx, const float* __restrict__ dnom,
                                                                   float* __restrict__ dz, long dzp) {
@@ -314,13 +476,13 @@ __global__ __launch_bounds__(256) void mem_write_update_bwd_kernel(const float* 
 //   * qhat = x / ||x|| is produced from the LDS copy, 8 rows per wave; [agg] is transposed through the same LDS rows and leaves as
 //     whole 1 KB rows as well.
 // 50 KB of LDS per block: three blocks (12 waves) per CU, the 576 blocks of the flagship (18 432 rows) are resident at once.
-typedef float mr_f32x16 __attribute__((ext_vector_type(16)));
 constexpr int MR_LDK = D + 4;     // 1040-byte rows: conflict-free ds_read_b128 fragments (bank step 4 per row)
 constexpr int MR_SP = 17 * 64;    // per wave: 16 partial-score registers + the partial squared norm, one float per lane each
 template <int M_>
 __global__ __launch_bounds__(256, 3) void mem_read_fwd_mfma_kernel(const float* __restrict__ x, long xp, long rows, const float* __restrict__ mem, int m_rt,
                                                                 const float* __restrict__ noise, float* __restrict__ qr, long qp,
-                                                                float* __restrict__ score, float* __restrict__ pm) {
+                                                                float* __restrict__ score, float* __restrict__ pm,
+                                                                const float* __restrict__ noise_q, float* __restrict__ colpart) {
   constexpr int LDK = MR_LDK;
   constexpr int MM = M_ > 0 ? M_ : MAXM;
   const int M = M_ > 0 ? M_ : m_rt;
@@ -393,6 +555,27 @@ __global__ __launch_bounds__(256, 3) void mem_read_fwd_mfma_kernel(const float* 
         mx = fmaxf(mx, sv);
       } else {
         pr[q] = -INFINITY;
+      }
+    }
+    if (colpart) {
+      // per-slot (max, sum exp) of this tile's 32 rows for the softmax over ALL queries (memory.py:186): every wave holds the same scores, wave w takes the
+      // register quads q with (q & 3) == w (at most three), rows are the 32 lanes of a half-wave -> butterfly within the half. Replaces the first of the
+      // two column-softmax launches; the partial layout is mem_colsoftmax_partial_kernel's with 32-row instead of 128-row tiles.
+      const long tile = row0 >> 5;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        if ((q & 3) != w || (q & 3) + 8 * (q >> 2) >= MM) continue;      // wave-uniform
+        const int sl = (q & 3) + 8 * (q >> 2) + 4 * half;
+        const bool ok = sl < M;
+        float cv = -INFINITY;
+        if (ok && live) cv = acc[q] * rnrm + (noise_q ? noise_q[myrow * M + sl] : 0.f);
+        float cm = cv;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) cm = fmaxf(cm, __shfl_xor(cm, o, 64));
+        float cs = cv == -INFINITY ? 0.f : expf(cv - cm);
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) cs += __shfl_xor(cs, o, 64);
+        if (ok && l31 == 0) *reinterpret_cast<float2*>(colpart + (tile * M + sl) * 2) = make_float2(cm, cs);
       }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -578,12 +761,26 @@ __global__ __launch_bounds__(256, 2) void mem_read_bwd_mfma_kernel(const float* 
 }
 
 inline int row_blocks(long rows) { return (int)std::min<long>((rows + 3) / 4, 256 * 8); }
-inline int accum_blocks(long rows) { return (int)std::min<long>((rows + 15) / 16, 256); }   // one block (4 wave slabs in LDS) per CU
+inline int accum_blocks(long rows) { return (int)std::min<long>((rows + 15) / 16, 256); }   // slab kernel: one block (4 wave slabs in LDS) per CU
+inline int accum_mfma_blocks(long rows) { return (int)std::min<long>((rows + AM_ROWS - 1) / AM_ROWS, 512); }   // MFMA kernel: two resident blocks per CU (141 + 68 registers)
+inline bool accum_slab() {   // PM_MEM_ACCUM_SLAB=1: the round-2 LDS-slab kernel (A/B)
+  static const bool v = [] { const char* e = getenv("PM_MEM_ACCUM_SLAB"); return e && e[0] == '1'; }();
+  return v;
+}
 
 }  // namespace
 
+namespace {
+int mem_read_fwd_launch(const pm_tensor* x, const float* mem, int m, const float* noise, const float* noise_q, const pm_tensor* qr, float* score, float* p_mem,
+                        float* colpart, void* stream);
+}
 extern "C" int pm_mem_read_fwd(const pm_tensor* x, const float* mem, int m, const float* noise, const pm_tensor* qr, float* score, float* p_mem,
                                void* stream) {
+  return mem_read_fwd_launch(x, mem, m, noise, nullptr, qr, score, p_mem, nullptr, stream);
+}
+namespace {
+int mem_read_fwd_launch(const pm_tensor* x, const float* mem, int m, const float* noise, const float* noise_q, const pm_tensor* qr, float* score, float* p_mem,
+                        float* colpart, void* stream) {
   PM_REQUIRE_F32(x, "mem_read_fwd");
   PM_REQUIRE_F32(qr, "mem_read_fwd");
   PM_REQUIRE(x && qr && mem && score && p_mem && x->ptr && qr->ptr, PM_EINVAL, "mem_read_fwd: null");
@@ -595,11 +792,25 @@ extern "C" int pm_mem_read_fwd(const pm_tensor* x, const float* mem, int m, cons
   const size_t lds = (size_t)(32 * MR_LDK + 4 * MR_SP) * sizeof(float);
   if (m == 19)
     hipLaunchKernelGGL(mem_read_fwd_mfma_kernel<19>, dim3(nb), dim3(256), lds, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, noise, (float*)qr->ptr,
-                       (long)qr->pitch, score, p_mem);
+                       (long)qr->pitch, score, p_mem, noise_q, colpart);
   else
     hipLaunchKernelGGL(mem_read_fwd_mfma_kernel<0>, dim3(nb), dim3(256), lds, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, noise, (float*)qr->ptr,
-                       (long)qr->pitch, score, p_mem);
+                       (long)qr->pitch, score, p_mem, noise_q, colpart);
   return pm_check_launch("mem_read_fwd");
+}
+}  // namespace
+
+// read + the softmax over all queries in two launches: the read kernel leaves the per-tile column partials, the apply kernel merges them and normalises
+extern "C" size_t pm_mem_read_fwd_pq_workspace(int64_t rows, int m) { return pm_align_up((size_t)pm_cdiv(rows, 32) * m * 2 * sizeof(float), 256); }
+extern "C" int pm_mem_read_fwd_pq(const pm_tensor* x, const float* mem, int m, const float* noise, const float* noise_q, const pm_tensor* qr, float* score,
+                                  float* p_mem, float* p_query, void* ws, size_t ws_bytes, void* stream) {
+  PM_REQUIRE(x && p_query && m >= 1 && m <= MAXM, PM_EINVAL, "mem_read_fwd_pq: bad args");
+  const long rows = pm_pixels(x);
+  PM_REQUIRE(ws && ws_bytes >= pm_mem_read_fwd_pq_workspace(rows, m), PM_EWORKSPACE, "mem_read_fwd_pq: workspace too small");
+  if (int e = mem_read_fwd_launch(x, mem, m, noise, noise_q, qr, score, p_mem, (float*)ws, stream)) return e;
+  hipLaunchKernelGGL(mem_colsoftmax_apply_kernel, dim3(pm_cdiv(rows, CSA_ROWS)), dim3(CSA_T), 0, (hipStream_t)stream, (const float*)score, noise_q, rows, m,
+                     (const float*)ws, (int)pm_cdiv(rows, 32), p_query);
+  return pm_check_launch("mem_read_fwd_pq");
 }
 
 extern "C" size_t pm_mem_colsoftmax_workspace(int64_t rows, int m) { return pm_align_up((size_t)pm_cdiv(rows, CS_ROWS) * m * 2 * sizeof(float), 256); }
@@ -608,7 +819,8 @@ extern "C" int pm_mem_colsoftmax(const float* score, const float* noise, int64_t
   PM_REQUIRE(ws && ws_bytes >= pm_mem_colsoftmax_workspace(rows, m), PM_EWORKSPACE, "mem_colsoftmax: workspace too small");
   const int nb = pm_cdiv(rows, CS_ROWS);
   hipLaunchKernelGGL(mem_colsoftmax_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, score, noise, (long)rows, m, (float*)ws);
-  hipLaunchKernelGGL(mem_colsoftmax_apply_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, score, noise, (long)rows, m, (const float*)ws, nb, p_query);
+  hipLaunchKernelGGL(mem_colsoftmax_apply_kernel, dim3(pm_cdiv(rows, CSA_ROWS)), dim3(CSA_T), 0, (hipStream_t)stream, score, noise, (long)rows, m, (const float*)ws, nb,
+                     p_query);
   return pm_check_launch("mem_colsoftmax");
 }
 
@@ -657,7 +869,7 @@ extern "C" int pm_mem_read_bwd(const pm_tensor* x, const float* mem, int m, cons
 
 extern "C" size_t pm_mem_write_accum_workspace(const pm_tensor* z, int m) {
   if ((z && !pm_is_f32(z))) return 0;      // fp32 tensors only
-  return pm_align_up((size_t)accum_blocks(pm_pixels(z)) * ((m + 1) * (D + 1)) * sizeof(float), 256);
+  return pm_align_up((size_t)std::max(accum_blocks(pm_pixels(z)), accum_mfma_blocks(pm_pixels(z))) * ((m + 1) * (D + 1)) * sizeof(float), 256);
 }
 extern "C" int pm_mem_write_accum(const pm_tensor* z, const int64_t* labels, int H, int W, int m, int normalize, float* nomden, void* ws, size_t ws_bytes,
                                   void* stream) {
@@ -666,6 +878,15 @@ extern "C" int pm_mem_write_accum(const pm_tensor* z, const int64_t* labels, int
   PM_REQUIRE(z->c == D && pm_vec_ok(z) && m >= 1 && m + 1 <= MAXM, PM_EUNSUPPORTED, "mem_write_accum: needs d == %d and <= %d slots", D, MAXM - 1);
   PM_REQUIRE(ws && ws_bytes >= pm_mem_write_accum_workspace(z, m), PM_EWORKSPACE, "mem_write_accum: workspace too small");
   const long rows = pm_pixels(z);
+  hipStream_t st = (hipStream_t)stream;
+  const long n = (long)(m + 1) * (D + 1);
+  if (!accum_slab() && rows < (1l << 31)) {
+    const int nb = accum_mfma_blocks(rows);
+    hipLaunchKernelGGL(mem_write_accum_mfma_kernel, dim3(nb), dim3(256), 0, st, (const float*)z->ptr, (long)z->pitch, z->n, z->h, z->w, labels, H, W, m, normalize,
+                       pm_ac_scale(H, z->h), pm_ac_scale(W, z->w), (float*)ws);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(pm_cdiv(n, 16)), dim3(256), 0, st, (const float*)ws, nb, n, nomden);
+    return pm_check_launch("mem_write_accum");
+  }
   const int nb = accum_blocks(rows);
   const size_t lds = (size_t)ACC_W * ((m + 1) * D + MAXM) * sizeof(float);
   static const bool attr = [] {
@@ -673,10 +894,8 @@ extern "C" int pm_mem_write_accum(const pm_tensor* z, const int64_t* labels, int
     return true;
   }();
   (void)attr;
-  hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(mem_write_accum_kernel, dim3(nb), dim3(256), lds, st, (const float*)z->ptr, (long)z->pitch, z->n, z->h, z->w, labels, H, W, m, normalize,
                      pm_ac_scale(H, z->h), pm_ac_scale(W, z->w), (float*)ws);
-  const long n = (long)(m + 1) * (D + 1);
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(pm_cdiv(n, 16)), dim3(256), 0, st, (const float*)ws, nb, n, nomden);
   return pm_check_launch("mem_write_accum");
 }

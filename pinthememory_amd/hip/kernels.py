@@ -698,6 +698,21 @@ def mem_read_fwd(x, mem, noise=None):
     return qr, score, pmem
 
 
+def mem_read_fwd_pq(x, mem, noise=None, noise_q=None):
+    """mem_read_fwd + the softmax over all queries (p_query) from the read kernel's column partials: two launches instead of three."""
+    n, h, w, d = x.shape
+    m = mem.shape[0]
+    qr = torch.empty((n, h, w, 2 * d), dtype=torch.float32, device=x.device)
+    score = torch.empty((n * h * w, m), dtype=torch.float32, device=x.device)
+    pmem, pq = torch.empty_like(score), torch.empty_like(score)
+    lib = _lib()
+    nb = lib.pm_mem_read_fwd_pq_workspace(n * h * w, m)
+    ws = workspace(nb, x.device)
+    check(lib.pm_mem_read_fwd_pq(byref(tdesc(x)), mem.data_ptr(), m, ptr(noise), ptr(noise_q), byref(tdesc(qr)), score.data_ptr(), pmem.data_ptr(), pq.data_ptr(),
+                                 ptr(ws), nb, stream()), 'pm_mem_read_fwd_pq')
+    return qr, score, pmem, pq
+
+
 def mem_colsoftmax(score, noise=None):
     rows, m = score.shape
     out = torch.empty_like(score)

@@ -118,6 +118,8 @@ SIGNATURES = {
     'pm_upsample_ce_fwd_field': (_i, [_T, _f, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     'pm_upsample_ce_bwd_field': (_i, [_T, _f, _i, _i, _vp, _vp, _vp, _T, _vp]),
     'pm_mem_read_fwd': (_i, [_T, _vp, _i, _vp, _T, _vp, _vp, _vp]),
+    'pm_mem_read_fwd_pq_workspace': (_sz, [_i64, _i]),
+    'pm_mem_read_fwd_pq': (_i, [_T, _vp, _i, _vp, _vp, _T, _vp, _vp, _vp, _vp, _sz, _vp]),
     'pm_mem_colsoftmax_workspace': (_sz, [_i64, _i]),
     'pm_mem_colsoftmax': (_i, [_vp, _vp, _i64, _i, _vp, _vp, _sz, _vp]),
     'pm_mem_read_bwd_workspace': (_sz, [_i64, _i, _i]),

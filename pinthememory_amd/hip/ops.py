@@ -548,25 +548,33 @@ class _MemRead(torch.autograd.Function):
     """memory.py:317-336. Returns (qr [B,2d,h,w], score [B,h,w,m], p_mem [B,h,w,m])."""
 
     @staticmethod
-    def forward(ctx, x, mem, noise):
+    def forward(ctx, x, mem, noise, noise_q=None, with_pq=False):
         xv = nhwc(x)
         mem = mem.contiguous()
-        qr, score, pmem = K.mem_read_fwd(xv, mem, noise)
+        if with_pq:
+            qr, score, pmem, pq = K.mem_read_fwd_pq(xv, mem, noise, noise_q)
+        else:
+            qr, score, pmem = K.mem_read_fwd(xv, mem, noise)
         n, h, w, _ = xv.shape
         m = mem.shape[0]
         ctx.save_for_backward(xv, mem, pmem)
         score, pmem = score.view(n, h, w, m), pmem.view(n, h, w, m)
+        ctx.with_pq = with_pq
+        if with_pq:
+            pq = pq.view(n, h, w, m)
+            ctx.mark_non_differentiable(pmem, pq)
+            return nchw(qr), score, pmem, pq
         ctx.mark_non_differentiable(pmem)
         return nchw(qr), score, pmem
 
     @staticmethod
-    def backward(ctx, dqr, dscore, _dp):
+    def backward(ctx, dqr, dscore, _dp, _dq=None):
         xv, mem, pmem = ctx.saved_tensors
         n, h, w, d = xv.shape
         dq = _grad_view(dqr) if dqr is not None else torch.zeros((n, h, w, 2 * d), dtype=torch.float32, device=xv.device)
         ds = dscore.contiguous() if dscore is not None else None
         dx, dmem = K.mem_read_bwd(xv, mem, pmem, dq, ds, want_dmem=ctx.needs_input_grad[1])
-        return nchw(dx), dmem, None
+        return nchw(dx), dmem, None, None, None
 
 
 class _MemWriteAccum(torch.autograd.Function):
@@ -694,7 +702,12 @@ def upsample_ce(logits, labels, inv_temp=1.0):
 
 
 def mem_read(x, mem, noise=None):
-    return _MemRead.apply(x, mem, noise)
+    return _MemRead.apply(x, mem, noise, None, False)
+
+
+def mem_read_pq(x, mem, noise=None, noise_q=None):
+    """(qr, score, p_mem, p_query): the read with the softmax over all queries (memory.py:183-186) finished from the read kernel's column partials."""
+    return _MemRead.apply(x, mem, noise, noise_q, True)
 
 
 def mem_write_accum(z, labels, m):

@@ -148,10 +148,9 @@ class Memory_sup(nn.Module):
     def get_score(self, query, mask, mem):            # memory.py:167-189; query NHWC, normalised by the caller
         bs, h, w, d = query.size()
         g0, g1 = self._gumbel(bs * h * w, query.device)
-        _, score, pmem = ops.mem_read(ops.cast(query.permute(0, 3, 1, 2), torch.float32), mem, g1)
+        _, score, pmem, pq = ops.mem_read_pq(ops.cast(query.permute(0, 3, 1, 2), torch.float32), mem, g1, g0)
         readloss = ops.upsample_ce(score.permute(0, 3, 1, 2), mask, 1.0 / self.temperature) if mask is not None else 0
-        pq = K.mem_colsoftmax(score.detach().reshape(bs * h * w, -1), g0)
-        return pq, pmem.reshape(bs * h * w, -1), readloss
+        return pq.reshape(bs * h * w, -1), pmem.reshape(bs * h * w, -1), readloss
 
     def read(self, query, mask, memory_writing):      # memory.py:317-336
         b, d, h, w = query.size()
@@ -161,9 +160,8 @@ class Memory_sup(nn.Module):
             self.m_items = mem = mem.detach()
         self.last_read = mem.detach()
         g0, g1 = self._gumbel(b * h * w, query.device)
-        qr, score, pmem = ops.mem_read(ops.cast(query, torch.float32), mem, g1)      # the memory works in fp32 (a no-op off the bf16 tier)
+        qr, score, pmem, pq = ops.mem_read_pq(ops.cast(query, torch.float32), mem, g1, g0)      # the memory works in fp32 (a no-op off the bf16 tier)
         readloss = ops.upsample_ce(score.permute(0, 3, 1, 2), mask, 1.0 / self.temperature) if mask is not None else 0
-        pq = K.mem_colsoftmax(score.detach().reshape(b * h * w, -1), g0).view(b, h, w, self.memory_size)
         updated_query = ops.conv_bn_act(qr, self.output[0], self.output[1], relu=True)
         return updated_query, pq, pmem, readloss
 

@@ -559,6 +559,30 @@ def test_memory_read(K):
     dxn2, _ = K.mem_read_bwd(xg, memg, pg, dqr.view(n, h, w, 2 * d).cuda(), dsx.cuda())
     assert rel(nchw(dxn2)[:, :, 1:], xn.grad[:, :, 1:]) < 2e-5
     assert rel(nchw(dxn2)[:, :, 1:], xr.grad[:, :, 1:]) > 1e-3          # the noise does change the gradient: the comparison above is not vacuous
+    # read + p_query from the read kernel's column partials (pm_mem_read_fwd_pq): same q / S / P_m bits as the plain read, p_query against torch, with
+    # the two INDEPENDENT gumbel draws of memory.py:183-184 (126 rows = three full 32-row tiles + a ragged one)
+    noise_q = -torch.empty(n * h * w, m).exponential_(generator=torch.Generator().manual_seed(7)).log()
+    for nz, nq in ((None, None), (noise, noise_q), (None, noise_q)):
+        qa, sa, pa, pqa = K.mem_read_fwd_pq(xg, memg, nz.cuda() if nz is not None else None, nq.cuda() if nq is not None else None)
+        qb, sb, pb = K.mem_read_fwd(xg, memg, nz.cuda() if nz is not None else None)
+        assert torch.equal(qa, qb) and torch.equal(sa, sb) and torch.equal(pa, pb)
+        assert rel(pqa, F.softmax(s.detach() + (nq if nq is not None else 0), 0)) < 2e-6
+        assert abs(pqa.sum(0) - 1).max().item() < 1e-5
+    _, s7, _, pq7 = K.mem_read_fwd_pq(xg, m7)
+    assert rel(pq7, F.softmax(s7.cpu(), 0)) < 2e-6
+
+
+def test_memory_read_pq_at_the_flagship_row_count(K):
+    """18 432 queries (bs=8, 48 x 48): 576 tiles of column partials merged in fixed order; twice the same bits."""
+    n, h, w, d, m = 8, 48, 48, 256, 19
+    xg = torch.relu(rnd(n, h, w, d, seed=11)).cuda()
+    memg = F.normalize(rnd(m, d, seed=12), dim=1).cuda()
+    _, sc, pm_, pq = K.mem_read_fwd_pq(xg, memg)
+    ref = F.softmax(sc.double(), 0)
+    assert rel(pq.double(), ref) < 2e-6 and abs(pq.double().sum(0) - 1).max().item() < 1e-5
+    assert rel(K.mem_colsoftmax(sc), ref.float()) < 2e-6
+    _, _, _, pq2 = K.mem_read_fwd_pq(xg, memg)
+    assert torch.equal(pq, pq2)
 
 
 def test_memory_read_more_rows_than_resident_tiles(K):
@@ -614,6 +638,33 @@ def test_memory_write(K):
     dnom = K.mem_write_update_bwd(u, nomden, mu, dout.cuda())
     dz = K.mem_write_accum_bwd(zg, labg, m, dnom)
     assert rel(nchw(dz), zr.grad) < 2e-5
+
+
+@pytest.mark.parametrize('n,h,w,H,W,m', [(2, 24, 24, 192, 192, 19),      # 18 chunks of 64 rows, one per block
+                                         (8, 48, 48, 768, 768, 19),      # the flagship: 288 chunks
+                                         (4, 96, 100, 200, 333, 19),     # 600 chunks on 512 blocks: blocks that carry two chunks; ragged last chunk; odd sizes
+                                         (1, 9, 7, 30, 20, 6)])          # one ragged chunk, a slot count whose partial slab is not 16-byte sized
+def test_memory_write_accum_on_the_matrix_cores(K, n, h, w, H, W, m):
+    """pm_mem_write_accum (split-K MFMA form) against the one-hot -> F.interpolate -> matmul formulation of memory.py:219-231 in fp64."""
+    d = 256
+    z = torch.relu(rnd(n, d, h, w, seed=21))
+    z[0, :, 0, 0] = 0                                       # eps clamp
+    g = torch.Generator().manual_seed(22)
+    lab = torch.randint(0, max(2, m - 3), (n, H, W), generator=g)
+    lab[torch.rand(n, H, W, generator=g) < 0.1] = 255
+    t = lab.clone()
+    t[t == 255] = m
+    y = F.interpolate(F.one_hot(t, m + 1).permute(0, 3, 1, 2).double(), [h, w], mode='bilinear', align_corners=True).permute(0, 2, 3, 1).reshape(n, -1, m + 1)
+    zh = F.normalize(z.double(), dim=1).view(n, d, -1)
+    nom, den = torch.matmul(zh, y).sum(0).t(), y.sum(1).sum(0)
+    zg, labg = nhwc(z), lab.cuda()
+    nomden = K.mem_write_accum(zg, labg, m)
+    assert rel(nomden[:(m + 1) * d].view(m + 1, d), nom) < 3e-6
+    assert rel(nomden[(m + 1) * d:], den) < 3e-6
+    assert torch.equal(nomden, K.mem_write_accum(zg, labg, m))          # fixed-order reduce: run-to-run identical
+    raw = K.mem_write_accum(zg, labg, m, normalize=False)
+    nom_raw = torch.matmul(z.double().view(n, d, -1), y).sum(0).t()
+    assert rel(raw[:(m + 1) * d].view(m + 1, d), nom_raw) < 3e-6
 
 
 def test_sgd(K):

@@ -34,6 +34,7 @@ rec('copy_small_calibration', 2 * cal_c.numel() * 4, lambda: K.copy(cal_c.view(1
 rec('fill_calibration', cal_b.numel() * 4, lambda: cal_b.zero_())
 rec('mem_read_fwd', N * d * 4 + m * d * 4 + N * 2 * d * 4 + 2 * N * m * 4, lambda: K.mem_read_fwd(x, mem))            # 59.4 MB
 rec('mem_read_bwd', N * 2 * d * 4 + N * d * 4 + N * d * 4 + 2 * N * m * 4, lambda: K.mem_read_bwd(x, mem, pmem, dqr, dsx))   # 75.5 MB + scores
+rec('mem_read_fwd_pq', N * d * 4 + m * d * 4 + N * 2 * d * 4 + 3 * N * m * 4, lambda: K.mem_read_fwd_pq(x, mem))    # + p_query from the read kernel's column partials
 rec('mem_colsoftmax', 2 * N * m * 4, lambda: K.mem_colsoftmax(score))
 rec('mem_write_accum', N * d * 4 + B * 4 * h * h * 8 + 20 * 257 * 4, lambda: K.mem_write_accum(x, lab, m))               # 19.5 MB
 lg = score.view(B, h, h, m)
