@@ -41,6 +41,15 @@ __device__ __forceinline__ void interp_logits(const CEGeom& g, int b, const pm_l
   }
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MB L2. With block id = hi-res row, every XCD would walk ALL low-res logit rows (the four
+// hi-res rows between two low-res rows sit on four different XCDs): the 22 MB of main-loss logits were fetched 8 x per sweep (counters, round 4: 226 MB read for
+// 60 MB of inputs). Bijective remap: consecutive hi-res rows -> one XCD, so a low-res row pair is fetched into one L2 and re-used there.
+__device__ __forceinline__ int ce_xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
 template <int C_>
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const CEGeom g, float* __restrict__ part) {
   const int C = C_ > 0 ? C_ : g.C;
@@ -86,7 +95,8 @@ __global__ __launch_bounds__(256) void ce_fwd_rows_kernel(const CEGeom g, float*
   extern __shared__ float L[];
   const int C = C_ > 0 ? C_ : g.C;
   const int CP = C | 1;
-  const int Y = blockIdx.x % g.H, b = blockIdx.x / g.H;
+  const int bid = ce_xcd_remap(blockIdx.x, gridDim.x);
+  const int Y = bid % g.H, b = bid / g.H;
   const pm_lerp ly = pm_ac_lerp(g.sy, Y, g.h);
   float* L0 = L;
   float* L1 = L + (size_t)g.w * CP;
@@ -128,8 +138,8 @@ __global__ __launch_bounds__(256) void ce_fwd_rows_kernel(const CEGeom g, float*
   if ((threadIdx.x & 63) == 0) sm[0][threadIdx.x >> 6] = lsum, sm[1][threadIdx.x >> 6] = lcnt;
   __syncthreads();
   if (threadIdx.x == 0) {
-    part[blockIdx.x * 2] = sm[0][0] + sm[0][1] + sm[0][2] + sm[0][3];
-    part[blockIdx.x * 2 + 1] = sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3];
+    part[bid * 2] = sm[0][0] + sm[0][1] + sm[0][2] + sm[0][3];
+    part[bid * 2 + 1] = sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3];
   }
 }
 
@@ -172,7 +182,8 @@ __global__ __launch_bounds__(256) void ce_bwd_cols_kernel(const CEGeom g, const 
   const int C = g.C;
   const long total = (long)g.n * g.h * g.w * C;
   const float gs = (gscale ? gscale[0] : 1.f) * g.inv_temp / loss_out[1];
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+  // consecutive logical blocks (neighbouring low-res rows, which share most of their supporting field rows) on one XCD's L2
+  for (long i = (long)ce_xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = (int)(i % C);
     long q = i / C;
     const int x = (int)(q % g.w);
@@ -213,7 +224,8 @@ __global__ __launch_bounds__(256) void ce_fused_rows_kernel(const CEGeom g, floa
   const int C = C_ > 0 ? C_ : g.C;
   const int CP = C | 1;
   const int nt = (int)blockDim.x, tid = (int)threadIdx.x;
-  const int Y = blockIdx.x % g.H, b = blockIdx.x / g.H;
+  const int bid = ce_xcd_remap(blockIdx.x, gridDim.x);
+  const int Y = bid % g.H, b = bid / g.H;
   const pm_lerp ly = pm_ac_lerp(g.sy, Y, g.h);
   float* L0 = L;
   float* L1 = L + (size_t)g.w * CP;                                   // (+ C floats of slack behind it: bufB holds one column more than a round)
@@ -318,8 +330,8 @@ __global__ __launch_bounds__(256) void ce_fused_rows_kernel(const CEGeom g, floa
   if (tid == 0) {
     float a = 0.f, c = 0.f;
     for (int wv = 0; wv < (nt >> 6); ++wv) a += sm[0][wv], c += sm[1][wv];
-    part[blockIdx.x * 2] = a;
-    part[blockIdx.x * 2 + 1] = c;
+    part[bid * 2] = a;
+    part[bid * 2 + 1] = c;
   }
 }
 

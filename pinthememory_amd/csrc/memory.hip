@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void mem_write_update_bwd_kernel(const float* 
 // 50 KB of LDS per block: three blocks (12 waves) per CU, the 576 blocks of the flagship (18 432 rows) are resident at once.
 constexpr int MR_LDK = D + 4;     // 1040-byte rows: conflict-free ds_read_b128 fragments (bank step 4 per row)
 constexpr int MR_SP = 17 * 64;    // per wave: 16 partial-score registers + the partial squared norm, one float per lane each
-template <int M_>
+template <int M_, bool COLPART = false>
 __global__ __launch_bounds__(256, 3) void mem_read_fwd_mfma_kernel(const float* __restrict__ x, long xp, long rows, const float* __restrict__ mem, int m_rt,
                                                                 const float* __restrict__ noise, float* __restrict__ qr, long qp,
                                                                 float* __restrict__ score, float* __restrict__ pm,
@@ -501,12 +501,15 @@ __global__ __launch_bounds__(256, 3) void mem_read_fwd_mfma_kernel(const float* 
   }
   // ... and agg^T operand (channel = 64 w + 32 n + (lane & 31); step q multiplies slot (q&3) + 8 (q>>2) [+ 4 in the upper half-wave])
   float ma[2][16];
+  auto load_ma = [&](int opaque) {
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    if ((q & 3) + 8 * (q >> 2) >= MM) continue;             // both slots of this step are padding
-    const float* bp = mem + (long)min((q & 3) + 8 * (q >> 2) + 4 * half, M - 1) * D + 64 * w + l31;
-    ma[0][q] = bp[0], ma[1][q] = bp[32];
-  }
+    for (int q = 0; q < 16; ++q) {
+      if ((q & 3) + 8 * (q >> 2) >= MM) continue;             // both slots of this step are padding
+      const float* bp = mem + (long)min((q & 3) + 8 * (q >> 2) + 4 * half, M - 1) * D + 64 * w + l31 + opaque;
+      ma[0][q] = bp[0], ma[1][q] = bp[32];
+    }
+  };
+  if constexpr (!COLPART) load_ma(0);     // with the column partials these 32 registers are fetched after them (the kernel sits exactly at its 168-register budget)
   for (long row0 = (long)blockIdx.x * 32; row0 < rows; row0 += (long)gridDim.x * 32) {
     if (row0 != (long)blockIdx.x * 32) __syncthreads();    // the previous tile's qhat pass is done with Xs
     {
@@ -542,6 +545,33 @@ __global__ __launch_bounds__(256, 3) void mem_read_fwd_mfma_kernel(const float* 
     n2 = ((Sp[16 * 64 + lane] + Sp[MR_SP + 16 * 64 + lane]) + Sp[2 * MR_SP + 16 * 64 + lane]) + Sp[3 * MR_SP + 16 * 64 + lane];
     const float rnrm = 1.f / fmaxf(sqrtf(n2), EPS);      // one division per row; qhat and the scores multiply by it (<= 1 ulp from x / ||x||)
     // acc[q] = <x_row, m_slot> for slot s = (q & 3) + 8 (q >> 2) + 4 half of this lane's own row
+    if constexpr (COLPART) {
+      // per-slot (max, sum exp) of this tile's 32 rows for the softmax over ALL queries (memory.py:186): every wave holds the same scores, wave w takes the
+      // register quads q with (q & 3) == w (at most three), rows are the 32 lanes of a half-wave -> butterfly within the half. Replaces the first of the
+      // two column-softmax launches; the partial layout is mem_colsoftmax_partial_kernel's with 32-row instead of 128-row tiles.
+      const long tile = row0 >> 5;
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        if (8 * qq >= MM) continue;                                       // compile-time: register quads beyond the slots
+        const float a = w == 0 ? acc[4 * qq] : (w == 1 ? acc[4 * qq + 1] : (w == 2 ? acc[4 * qq + 2] : acc[4 * qq + 3]));      // wave-uniform selects
+        const int sl = w + 8 * qq + 4 * half;
+        const bool ok = sl < M;
+        float cv = -INFINITY;
+        if (ok && live) cv = a * rnrm + (noise_q ? noise_q[myrow * M + sl] : 0.f);
+        float cm = cv;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) cm = fmaxf(cm, __shfl_xor(cm, o, 64));
+        float cs = cv == -INFINITY ? 0.f : expf(cv - cm);
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) cs += __shfl_xor(cs, o, 64);
+        if (ok && l31 == 0) *reinterpret_cast<float2*>(colpart + (tile * M + sl) * 2) = make_float2(cm, cs);
+      }
+    }
+    if constexpr (COLPART) {
+      int opaque = 0;
+      asm volatile("" : "+v"(opaque));      // keeps the loads below from being hoisted back in front of the tile loop
+      load_ma(opaque);
+    }
     float pr[16];
     float mx = -INFINITY;
 #pragma unroll
@@ -555,27 +585,6 @@ __global__ __launch_bounds__(256, 3) void mem_read_fwd_mfma_kernel(const float* 
         mx = fmaxf(mx, sv);
       } else {
         pr[q] = -INFINITY;
-      }
-    }
-    if (colpart) {
-      // per-slot (max, sum exp) of this tile's 32 rows for the softmax over ALL queries (memory.py:186): every wave holds the same scores, wave w takes the
-      // register quads q with (q & 3) == w (at most three), rows are the 32 lanes of a half-wave -> butterfly within the half. Replaces the first of the
-      // two column-softmax launches; the partial layout is mem_colsoftmax_partial_kernel's with 32-row instead of 128-row tiles.
-      const long tile = row0 >> 5;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        if ((q & 3) != w || (q & 3) + 8 * (q >> 2) >= MM) continue;      // wave-uniform
-        const int sl = (q & 3) + 8 * (q >> 2) + 4 * half;
-        const bool ok = sl < M;
-        float cv = -INFINITY;
-        if (ok && live) cv = acc[q] * rnrm + (noise_q ? noise_q[myrow * M + sl] : 0.f);
-        float cm = cv;
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) cm = fmaxf(cm, __shfl_xor(cm, o, 64));
-        float cs = cv == -INFINITY ? 0.f : expf(cv - cm);
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) cs += __shfl_xor(cs, o, 64);
-        if (ok && l31 == 0) *reinterpret_cast<float2*>(colpart + (tile * M + sl) * 2) = make_float2(cm, cs);
       }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -790,12 +799,17 @@ int mem_read_fwd_launch(const pm_tensor* x, const float* mem, int m, const float
   hipStream_t st = (hipStream_t)stream;
   const int nb = (int)std::min<long>((rows + 31) / 32, 256 * 3 * 4);
   const size_t lds = (size_t)(32 * MR_LDK + 4 * MR_SP) * sizeof(float);
-  if (m == 19)
-    hipLaunchKernelGGL(mem_read_fwd_mfma_kernel<19>, dim3(nb), dim3(256), lds, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, noise, (float*)qr->ptr,
-                       (long)qr->pitch, score, p_mem, noise_q, colpart);
-  else
-    hipLaunchKernelGGL(mem_read_fwd_mfma_kernel<0>, dim3(nb), dim3(256), lds, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, noise, (float*)qr->ptr,
-                       (long)qr->pitch, score, p_mem, noise_q, colpart);
+#define PM_MR_LAUNCH(MM, CP)                                                                                                                              \
+  hipLaunchKernelGGL((mem_read_fwd_mfma_kernel<MM, CP>), dim3(nb), dim3(256), lds, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, noise, (float*)qr->ptr, \
+                     (long)qr->pitch, score, p_mem, noise_q, colpart)
+  if (m == 19) {
+    if (colpart) PM_MR_LAUNCH(19, true);
+    else PM_MR_LAUNCH(19, false);
+  } else {
+    if (colpart) PM_MR_LAUNCH(0, true);
+    else PM_MR_LAUNCH(0, false);
+  }
+#undef PM_MR_LAUNCH
   return pm_check_launch("mem_read_fwd");
 }
 }  // namespace
