@@ -448,6 +448,10 @@ def test_layout_and_labels(K):
     x = rnd(2, 3, 37, 41, seed=1).cuda()
     y = K.nchw_to_nhwc(x, c_pad=4)
     assert torch.equal(y[..., :3], x.permute(0, 2, 3, 1)) and y[..., 3].abs().max().item() == 0
+    for c, cp in ((3, 3), (1, 4), (4, 4), (2, 2), (5, 8), (3, 8)):       # thread-per-pixel image kernel (<= 4 channels) and the tiled transpose beyond
+        xs = rnd(3, c, 19, 23, seed=10 + c).cuda()
+        ys = K.nchw_to_nhwc(xs, c_pad=cp)
+        assert torch.equal(ys[..., :c], xs.permute(0, 2, 3, 1)) and (cp == c or ys[..., c:].abs().max().item() == 0)
     z = rnd(2, 19, 9, 13, seed=2)
     assert torch.equal(K.nhwc_to_nchw(nhwc(z)).cpu(), z)
     lab = torch.randint(0, 19, (2, 64, 48), generator=torch.Generator().manual_seed(3))
