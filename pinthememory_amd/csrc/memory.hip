@@ -195,6 +195,35 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   }
 }
 
+// the same sum (same association order: bit-identical) for slabs of whole float4 groups: thread = (float4 column, partial lane), 16-byte loads, four in flight
+__global__ __launch_bounds__(256) void reduce_partials_vec4_kernel(const float4* __restrict__ part, int nb, long n4, float4* __restrict__ out) {
+  __shared__ float4 red[16][16];
+  const int e = threadIdx.x & 15, z = threadIdx.x >> 4;
+  const long i = (long)blockIdx.x * 16 + e;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+#pragma unroll 4
+    for (int b = z; b < nb; b += 16) {
+      const float4 v = part[(long)b * n4 + i];
+      s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+    }
+  }
+  red[z][e] = s;
+  __syncthreads();
+  if (z == 0 && i < n4) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s.x += red[k][e].x, s.y += red[k][e].y, s.z += red[k][e].z, s.w += red[k][e].w;
+    out[i] = s;
+  }
+}
+inline void launch_reduce_partials(const float* part, int nb, long n, float* out, hipStream_t st) {
+  if ((n & 3) == 0 && pm_aligned16(part) && pm_aligned16(out))
+    hipLaunchKernelGGL(reduce_partials_vec4_kernel, dim3(pm_cdiv(n / 4, 16)), dim3(256), 0, st, reinterpret_cast<const float4*>(part), nb, n / 4,
+                       reinterpret_cast<float4*>(out));
+  else
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(pm_cdiv(n, 16)), dim3(256), 0, st, part, nb, n, out);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // write: accumulate nominator / denominator
 // ---------------------------------------------------------------------------------------------------------------
@@ -860,7 +889,7 @@ extern "C" int pm_mem_read_bwd(const pm_tensor* x, const float* mem, int m, cons
       hipLaunchKernelGGL((mem_read_bwd_kernel<0, true>), dim3(nb), dim3(256), 0, st, (const float*)x->ptr, (long)x->pitch, rows, mem, m, p_mem,
                          (const float*)dqr->ptr, (long)dqr->pitch, dsx, (float*)dx->ptr, (long)dx->pitch, (float*)ws);
     const long n = (long)m * D;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(pm_cdiv(n, 16)), dim3(256), 0, st, (const float*)ws, nb, n, dmem);
+    launch_reduce_partials((const float*)ws, nb, n, dmem, st);
   } else if (getenv("PM_MEM_BWD_ROWS") == nullptr) {
     const int nt = (int)std::min<long>((rows + 31) / 32, 256 * 3 * 4);
     const size_t lds = (size_t)(32 * MR_LDK + 4 * MR_SP) * sizeof(float);
@@ -898,7 +927,7 @@ extern "C" int pm_mem_write_accum(const pm_tensor* z, const int64_t* labels, int
     const int nb = accum_mfma_blocks(rows);
     hipLaunchKernelGGL(mem_write_accum_mfma_kernel, dim3(nb), dim3(256), 0, st, (const float*)z->ptr, (long)z->pitch, z->n, z->h, z->w, labels, H, W, m, normalize,
                        pm_ac_scale(H, z->h), pm_ac_scale(W, z->w), (float*)ws);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(pm_cdiv(n, 16)), dim3(256), 0, st, (const float*)ws, nb, n, nomden);
+    launch_reduce_partials((const float*)ws, nb, n, nomden, st);
     return pm_check_launch("mem_write_accum");
   }
   const int nb = accum_blocks(rows);
@@ -910,7 +939,7 @@ extern "C" int pm_mem_write_accum(const pm_tensor* z, const int64_t* labels, int
   (void)attr;
   hipLaunchKernelGGL(mem_write_accum_kernel, dim3(nb), dim3(256), lds, st, (const float*)z->ptr, (long)z->pitch, z->n, z->h, z->w, labels, H, W, m, normalize,
                      pm_ac_scale(H, z->h), pm_ac_scale(W, z->w), (float*)ws);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(pm_cdiv(n, 16)), dim3(256), 0, st, (const float*)ws, nb, n, nomden);
+  launch_reduce_partials((const float*)ws, nb, n, nomden, st);
   return pm_check_launch("mem_write_accum");
 }
 
