@@ -1176,11 +1176,19 @@ inline int nst1_max_steps() {
   }();
   return v;
 }
+// native-bf16 weight gradient on ONE LDS stage (PM_WGRAD_NST1=1, tuning): 40 instead of 80 KB per 128 x 128 block -> three resident blocks per CU instead of two
+inline bool wgrad_nst1() {
+  static const bool v = [] { const char* e = getenv("PM_WGRAD_NST1"); return e && e[0] == '1'; }();
+  return v;
+}
 template <int MODE, int BM, int BN, int WM, int WN, int KM, int PREC>
 void launch_prec(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
   // single-stage variant only where it is used: fast-path fwd / dgrad with a short reduction per block
   if constexpr (KM == K_FAST && MODE != MODE_WGRAD && BN >= 64) {
     if (k.kper <= nst1_max_steps() * BK) return launch_nst<MODE, BM, BN, WM, WN, KM, PREC, 1>(k, grid, smem, st);
+  }
+  if constexpr (MODE == MODE_WGRAD && PREC == 4) {
+    if (wgrad_nst1()) return launch_nst<MODE, BM, BN, WM, WN, KM, PREC, 1>(k, grid, smem, st);
   }
   launch_nst<MODE, BM, BN, WM, WN, KM, PREC, 2>(k, grid, smem, st);
 }
