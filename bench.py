@@ -321,13 +321,13 @@ def memory_path_roofline(batch, size):
         ('readloss_fwd', 'memory.py:173-176', B * H * H * 8 + N * m * 4, lambda: K.upsample_ce_fwd(lg, lab, 1.0)),
         ('readloss_bwd', 'memory.py:173-176 (autograd)', B * H * H * 8 + 2 * N * m * 4, lambda: K.upsample_ce_bwd(lg, lab, lo, None, 1.0)),
         ('readloss_fwd_with_grad_field', 'memory.py:173-176 (training forward: loss + column-reduced gradient field in one sweep)',
-         B * H * H * 8 + N * m * 4 + B * H * h * m * 4, lambda: K.upsample_ce_fwd_field(lg, lab, 1.0)),
-        ('readloss_bwd_from_field', 'memory.py:173-176 (autograd: row pass over the field)', B * H * h * m * 4 + N * m * 4,
+         B * H * H * 8 + N * m * 4 + lo_field.numel() * 4, lambda: K.upsample_ce_fwd_field(lg, lab, 1.0)),
+        ('readloss_bwd_from_field', 'memory.py:173-176 (autograd: row pass over the field)', lo_field.numel() * 4 + N * m * 4,
          lambda: K.upsample_ce_bwd_field(lg, (H, H), lo_f, lo_field, None, 1.0)),
         ('main_ce_fwd', 'deepv3plus.py:575-578', B * H * H * 8 + B * (H // 4) ** 2 * m * 4, lambda: K.upsample_ce_fwd(main, lab, 1.0)),
         ('main_ce_fwd_with_grad_field', 'deepv3plus.py:575-578 (training forward: loss + column-reduced gradient field in one sweep)',
-         B * H * H * 8 + B * (H // 4) ** 2 * m * 4 + B * H * (H // 4) * m * 4, lambda: K.upsample_ce_fwd_field(main, lab, 1.0)),
-        ('main_ce_bwd_from_field', 'deepv3plus.py:575-578 (autograd: row pass over the field)', B * H * (H // 4) * m * 4 + B * (H // 4) ** 2 * m * 4,
+         B * H * H * 8 + B * (H // 4) ** 2 * m * 4 + lo_mfield.numel() * 4, lambda: K.upsample_ce_fwd_field(main, lab, 1.0)),      # the field as the library sizes it
+        ('main_ce_bwd_from_field', 'deepv3plus.py:575-578 (autograd: row pass over the field)', lo_mfield.numel() * 4 + B * (H // 4) ** 2 * m * 4,
          lambda: K.upsample_ce_bwd_field(main, (H, H), lo_mf, lo_mfield, None, 1.0)),
         ('main_ce_bwd', 'deepv3plus.py:575-578 (autograd)', B * H * H * 8 + 2 * B * (H // 4) ** 2 * m * 4, lambda: K.upsample_ce_bwd(main, lab, lo_main, None, 1.0)),
     ]

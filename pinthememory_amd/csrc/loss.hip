@@ -335,6 +335,199 @@ __global__ __launch_bounds__(256) void ce_fused_rows_kernel(const CEGeom g, floa
   }
 }
 
+// ---- the same sweep with the ROW half of the transposed bilinear operator folded in (round 4, second session) ------------------------------------------------
+// ce_fused_rows_kernel leaves one column-reduced row per HI-RES row (T[n][H][w][C]: 89.7 MB for the main loss) and the backward gathers ~8 of them per low-res
+// pixel. Here a block owns a low-res row INTERVAL y -- every hi-res row whose upper tap is y (four of them at 192 -> 768) -- and folds their column-reduced rows with
+// the two row weights straight away: FA[b][y] = sum_Y w0(Y) T_Y (stays in low-res row y), FB[b][y] = sum_Y w1(Y) T_Y (owed to row y + 1). The field is two
+// low-res-sized rows per interval (2 x 22.4 MB) and the backward is dl[y] = (FA[y] + FB[y - 1]) x scale, elementwise.
+//   * block = RG row groups x TPR threads; group gi takes rows Ya + gi, Ya + gi + RG, ...; lane x of a group = low-res column x (the form for modest up-sampling
+//     ratios: one lane per column, PARTS == 1), walking the hi-res pixels whose left tap is x exactly as the kernel above (same expressions, same order);
+//   * the right-tap sums B go to the neighbouring lane by a one-lane shuffle (wave edges through LDS) instead of an LDS round trip of the whole row;
+//   * every round the groups fold their row into the block's LDS accumulators accA / accB in group order (one barrier per group: per-lane register accumulators
+//     for all rounds put the 1 024-thread block 27 registers over its 128-register budget and the spills into the pixel loop: 190 instead of 120 us), loss
+//     partials per block: all fixed-order, deterministic.
+__host__ __device__ __forceinline__ int ce2_rows_per_interval(int h, int H) { return (H + h - 1) / h + 1; }
+template <int C_>
+__global__ __launch_bounds__(1024) void ce_fused_rows2_kernel(const CEGeom g, float* __restrict__ part, float* __restrict__ FA, float* __restrict__ FB, int tpr, int rg, int nseg, int ws) {
+  extern __shared__ float L[];
+  __shared__ float sm2[2][16];
+  constexpr int CR = C_ > 0 ? C_ : MAXC;
+  const int C = C_ > 0 ? C_ : g.C;
+  const int CP = C | 1;
+  const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
+  const int gi = tid / tpr, x = tid - gi * tpr, lane = tid & 63, wv = x >> 6;       // group, low-res column (lane of the group), wave of the group
+  const int nwv = tpr >> 6;
+  // block = (image b, interval y, column segment seg): the segment owns the low-res columns [c0, c0 + ncol); lane x of a group is column c0 - 1 + x, i.e. lane 0 is
+  // the column LEFT of the segment -- it evaluates its hi-res pixels only for the right-tap sums B they owe to column c0 (4 % of redundant work at 96 columns per
+  // segment; its loss terms and its own row entries belong to the neighbouring segment and are dropped here). Half the columns per block = half the LDS: four
+  // resident blocks per CU instead of two.
+  const int bid = ce_xcd_remap(blockIdx.x, gridDim.x);
+  const int seg = bid % nseg, y = (bid / nseg) % g.h, b = bid / (nseg * g.h);
+  const int y1 = min(y + 1, g.h - 1);
+  const int c0 = seg * ws, ncol = min(ws, g.w - c0);
+  const int cb = max(c0 - 1, 0), ce = min(c0 + ncol, g.w - 1), nst = ce - cb + 1;   // staged low-res columns [cb, ce]: the taps of the lanes' pixels
+  const int Wp = (g.W + 15) & ~15;
+  float* L0 = L;
+  float* L1 = L + (size_t)(ws + 2) * CP;
+  float* accA = L1 + (size_t)(ws + 2) * CP;                                         // [ws][C] x 2: the block's pieces of the FA / FB rows
+  float* accB = accA + (size_t)ws * C;
+  float* edge = accB + (size_t)ws * C;                                              // [rg][nwv][CR]: B of a wave's last lane, owed to the next wave's lane 0
+  unsigned char* lab8 = reinterpret_cast<unsigned char*>(edge + (size_t)rg * nwv * CR);   // [rg][Wp]
+  for (int i = tid; i < nst * C; i += nt) {
+    const int xl = i / C, c = i - xl * C;
+    L0[xl * CP + c] = g.logits[((long)(b * g.h + y) * g.w + cb + xl) * g.lp + c] * g.inv_temp;
+    L1[xl * CP + c] = g.logits[((long)(b * g.h + y1) * g.w + cb + xl) * g.lp + c] * g.inv_temp;
+  }
+  for (int i = tid; i < ws * C; i += nt) accA[i] = 0.f, accB[i] = 0.f;
+  const int Ya = ce_first_ge(g.sy, y, g.h, g.H), Yb = ce_first_ge(g.sy, y + 1, g.h, g.H);
+  const int Xlo = ce_first_ge(g.sx, cb, g.w, g.W), Xhi = ce_first_ge(g.sx, c0 + ncol, g.w, g.W);   // hi-res columns whose left tap is one of the lanes' columns
+  const int ov = nseg > 1 ? 1 : 0;                                                  // a single segment needs no neighbour lane
+  const int xc = c0 - ov + x;                                                       // this lane's low-res column
+  const bool own = x >= ov && x < ov + ncol;                                        // a column of the segment (with segments, lane 0: the left neighbour, B only)
+  const bool colive = own || (ov && x == 0 && c0 > 0);
+  int j0 = 0, j1 = 0;
+  if (colive) j0 = ce_first_ge(g.sx, xc, g.w, g.W), j1 = ce_first_ge(g.sx, xc + 1, g.w, g.W);
+  float lsum = 0.f, lcnt = 0.f;
+  const int rounds = (Yb - Ya + rg - 1) / rg;
+  for (int rd = 0; rd < rounds; ++rd) {
+    const int Y = Ya + rd * rg + gi;
+    const bool rowlive = Y < Yb;
+    unsigned char* mylab = lab8 + (size_t)gi * Wp;
+    if (rowlive) {
+      const int64_t* lrow = g.labels + ((long)b * g.H + Y) * g.W;
+      for (int X = Xlo + x; X < Xhi; X += tpr) {
+        const int64_t l = lrow[X];
+        mylab[X - Xlo] = (l >= 0 && l < 254) ? (unsigned char)l : (l == 255 ? 255 : 254);
+      }
+    }
+    __syncthreads();                                 // labels (and, in the first round, the logit rows) are staged
+    float A[CR], B[CR];
+#pragma unroll
+    for (int c = 0; c < CR; ++c) A[c] = B[c] = 0.f;
+    pm_lerp ly = pm_ac_lerp(g.sy, rowlive ? Y : Ya, g.h);
+    if (rowlive && colive) {
+      for (int X = j0; X < j1; ++X) {
+        const int lab = mylab[X - Xlo];
+        if (lab == 255) continue;
+        const pm_lerp lx = pm_ac_lerp(g.sx, X, g.w);
+        const float *p00 = L0 + (lx.i0 - cb) * CP, *p01 = L0 + (lx.i1 - cb) * CP, *p10 = L1 + (lx.i0 - cb) * CP, *p11 = L1 + (lx.i1 - cb) * CP;
+        float v[CR];
+        float mx = -INFINITY, vl = 0.f;
+#pragma unroll
+        for (int c = 0; c < CR; ++c)
+          if (c < C) {
+            v[c] = ly.w0 * (lx.w0 * p00[c] + lx.w1 * p01[c]) + ly.w1 * (lx.w0 * p10[c] + lx.w1 * p11[c]);   // same expression as interp_logits
+            mx = fmaxf(mx, v[c]);
+            if (c == lab) vl = v[c];
+          }
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < CR; ++c)
+          if (c < C) v[c] = __expf(v[c] - mx), se += v[c];
+        if (own) lsum += (mx + logf(se)) - vl, lcnt += 1.f;      // the left-neighbour lane's pixels are counted by the segment that owns them
+        const float inv = 1.f / se;
+        const float wa = lx.i1 == lx.i0 ? lx.w0 + lx.w1 : lx.w0, wb = lx.i1 == lx.i0 ? 0.f : lx.w1;
+#pragma unroll
+        for (int c = 0; c < CR; ++c)
+          if (c < C) {
+            const float gq = v[c] * inv - (c == lab ? 1.f : 0.f);
+            A[c] += wa * gq, B[c] += wb * gq;
+          }
+      }
+    }
+    if (lane == 63) {
+#pragma unroll
+      for (int c = 0; c < CR; ++c)
+        if (c < C) edge[((size_t)gi * nwv + wv) * CR + c] = B[c];
+    }
+    __syncthreads();                                 // wave-edge values are in LDS; every lane is done with this round's labels
+    {
+      const float wA = ly.i1 == ly.i0 ? ly.w0 + ly.w1 : ly.w0, wB = ly.i1 == ly.i0 ? 0.f : ly.w1;
+#pragma unroll
+      for (int c = 0; c < CR; ++c)
+        if (c < C) {
+          float bs = __shfl_up(B[c], 1, 64);
+          if (lane == 0) bs = wv > 0 ? edge[((size_t)gi * nwv + wv - 1) * CR + c] : 0.f;
+          A[c] = bs + A[c];                           // the column-reduced row entry T[Y][x][c] of the kernel above (same two terms)
+        }
+      for (int k = 0; k < rg; ++k) {                  // fold into the block's rows, group after group
+        if (gi == k && rowlive && own) {
+#pragma unroll
+          for (int c = 0; c < CR; ++c)
+            if (c < C) accA[(x - ov) * C + c] += wA * A[c], accB[(x - ov) * C + c] += wB * A[c];
+        }
+        __syncthreads();
+      }
+    }
+  }
+  __syncthreads();                                    // (also the barrier between staging / zeroing and the stores when an interval has no row)
+  float* outA = FA + (((long)b * g.h + y) * g.w + c0) * C;
+  float* outB = FB + (((long)b * g.h + y) * g.w + c0) * C;
+  for (int i = tid; i < ncol * C; i += nt) outA[i] = accA[i], outB[i] = accB[i];
+  lsum = pm_wave_sum(lsum);
+  lcnt = pm_wave_sum(lcnt);
+  if ((tid & 63) == 0) sm2[0][tid >> 6] = lsum, sm2[1][tid >> 6] = lcnt;
+  __syncthreads();
+  if (tid == 0) {
+    float a = 0.f, c = 0.f;
+    for (int k = 0; k < (nt >> 6); ++k) a += sm2[0][k], c += sm2[1][k];
+    part[bid * 2] = a;
+    part[bid * 2 + 1] = c;
+  }
+}
+// backward of the interval form: dl[b][y][x][c] = (FA[b][y][x][c] + FB[b][y - 1][x][c]) x upstream scale / valid pixels / T
+__global__ __launch_bounds__(256) void ce_bwd_rows2_kernel(const CEGeom g, const float* __restrict__ FA, const float* __restrict__ FB, const float* __restrict__ loss_out,
+                                                           const float* __restrict__ gscale, float* __restrict__ dl, long dlp) {
+  const int C = g.C;
+  const long rowsz = (long)g.w * C, total = (long)g.n * g.h * rowsz;
+  const float gs = (gscale ? gscale[0] : 1.f) * g.inv_temp / loss_out[1];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long pix = i / C;
+    const int c = (int)(i - pix * C);
+    const int y = (int)((pix / g.w) % g.h);
+    const float v = FA[i] + (y > 0 ? FB[i - rowsz] : 0.f);
+    dl[pix * dlp + c] = v * gs;
+  }
+}
+constexpr size_t ROWS2_MAX_LDS = 120 * 1024;      // dynamic LDS of the interval form (opt-in beyond 64 KB, set per device at the first launch)
+struct Rows2Plan {
+  bool ok;
+  int tpr, rg, nseg, ws;
+  size_t lds;
+};
+inline Rows2Plan rows2_plan(const CEGeom& g) {
+  static const bool off = [] { const char* e = getenv("PM_CE_ROWS2"); return e && e[0] == '0'; }();      // PM_CE_ROWS2=0: the one-row-per-hi-res-row field (A/B)
+  Rows2Plan p{};
+  const int ratio = std::max(1, g.W / std::max(1, g.w));
+  static const int seg_cols = [] { const char* e = getenv("PM_CE_ROWS2_SEG"); const int v = e ? atoi(e) : 96; return std::max(16, v); }();
+  p.nseg = std::max(1, (g.w + seg_cols - 1) / seg_cols);      // column segments per interval (<= 96 columns each: 31 KB of LDS at 19 classes)
+  p.ws = (g.w + p.nseg - 1) / p.nseg;
+  p.nseg = (g.w + p.ws - 1) / p.ws;
+  p.tpr = std::min(320, (p.ws + (p.nseg > 1 ? 1 : 0) + 63) / 64 * 64);      // + the left-neighbour lane when there are segments
+  static const int max_threads = [] { const char* e = getenv("PM_CE_ROWS2_THREADS"); const int v = e ? atoi(e) : 256; return std::min(1024, std::max(128, v)); }();      // 256: measured best (gpu_r6_ce.sh)
+  p.rg = std::max(1, std::min(ce2_rows_per_interval(g.h, g.H), max_threads / std::max(64, p.tpr)));
+  p.lds = ((size_t)2 * (p.ws + 2) * (g.C | 1) + (size_t)2 * p.ws * g.C + (size_t)p.rg * (p.tpr / 64) * MAXC) * sizeof(float) + (size_t)p.rg * ((g.W + 15) & ~15);
+  // one lane per low-res column (modest up-sampling ratios; the 16-fold read loss keeps the PARTS form: its field is small), up-sampling only (block count <= hi-res rows:
+  // the partial workspace is sized for those), everything in 64 KB of dynamic LDS
+  p.ok = !off && g.C == 19 && g.w <= 256 && ratio < 8 && g.H >= g.h && g.h >= 1 && p.lds <= ROWS2_MAX_LDS && (long)g.n * g.h * p.nseg <= (1l << 30) && p.nseg <= 2 * std::max(1, g.H / std::max(1, g.h)) ;      // 19 classes: the
+  // specialised instantiation (2 x 19 accumulators + 3 x 19 working registers sit at the 128-register budget of a 1 024-thread block; 32 classes would not)
+  return p;
+}
+
+inline void rows2_launch(const CEGeom& g, const Rows2Plan& r, float* part, float* field, hipStream_t st) {
+  static bool attr_set[64] = {};      // > 64 KB of dynamic LDS needs the opt-in, once per device
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ce_fused_rows2_kernel<19>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ROWS2_MAX_LDS) != hipSuccess)
+      (void)hipGetLastError();        // the launch then fails with its own error for plans beyond 64 KB
+    else
+      attr_set[dev] = true;
+  }
+  const long half = (long)g.n * g.h * g.w * g.C;
+  hipLaunchKernelGGL(ce_fused_rows2_kernel<19>, dim3(g.n * g.h * r.nseg), dim3(r.tpr * r.rg), r.lds, st, g, part, field, field + half, r.tpr, r.rg, r.nseg, r.ws);
+}
+
 inline int fwd_blocks(long total) { return (int)std::min<long>((total + 255) / 256, 4096); }
 
 int fill(CEGeom& g, const pm_tensor* logits, float inv_temp, const int64_t* labels, int H, int W, const char* who) {
@@ -349,7 +542,7 @@ int fill(CEGeom& g, const pm_tensor* logits, float inv_temp, const int64_t* labe
 }  // namespace
 
 extern "C" size_t pm_upsample_ce_workspace(int n, int H, int W) {   // one (sum, count) pair per block of either forward kernel
-  return pm_align_up((size_t)std::max<long>(fwd_blocks((long)n * H * W), (long)n * H) * 2 * sizeof(float), 256);
+  return pm_align_up((size_t)std::max<long>(fwd_blocks((long)n * H * W), (long)n * H * 2) * 2 * sizeof(float), 256);      // interval form: <= 2 n H blocks (rows2_plan)
 }
 
 extern "C" int pm_upsample_ce_fwd(const pm_tensor* logits, float inv_temp, const int64_t* labels, int H, int W, float* loss_out, void* ws, size_t ws_bytes,
@@ -433,7 +626,8 @@ extern "C" size_t pm_upsample_ce_field_bytes(const pm_tensor* logits, int H, int
   // 0 also when the fused row kernel cannot take the shape -- two low-res logit rows + the label row of one hi-res row must fit LDS (159 KB: w <= ~1000 low-res
   // columns at 19 classes) -- so that a caller routes such shapes elsewhere instead of meeting PM_EUNSUPPORTED (ops.upsample_ce composes resize + CE then)
   CEGeom g{};
-  g.w = logits->w, g.W = W, g.C = logits->c;
+  g.n = logits->n, g.h = logits->h, g.w = logits->w, g.H = H, g.W = W, g.C = logits->c;
+  if (rows2_plan(g).ok) return (size_t)2 * logits->n * logits->h * logits->w * logits->c * sizeof(float);      // interval form: FA | FB
   if (fused_plan(g).lds > FUSED_MAX_LDS) return 0;
   return (size_t)logits->n * H * logits->w * logits->c * sizeof(float);
 }
@@ -444,9 +638,14 @@ extern "C" int pm_upsample_ce_fwd_field(const pm_tensor* logits, float inv_temp,
   CEGeom g;
   if (int e = fill(g, logits, inv_temp, labels, H, W, "upsample_ce_fwd_field")) return e;
   PM_REQUIRE(loss_out && field && ws && ws_bytes >= pm_upsample_ce_workspace(g.n, H, W), PM_EWORKSPACE, "upsample_ce_fwd_field: workspace too small / null field");
+  hipStream_t st = (hipStream_t)stream;
+  if (const Rows2Plan r = rows2_plan(g); r.ok) {
+    rows2_launch(g, r, (float*)ws, field, st);
+    hipLaunchKernelGGL(ce_final_kernel, dim3(1), dim3(CE_FINAL_T), 0, st, (const float*)ws, g.n * g.h * r.nseg, loss_out);
+    return pm_check_launch("upsample_ce_fwd_field");
+  }
   const FusedPlan p = fused_plan(g);
   PM_REQUIRE(p.lds <= FUSED_MAX_LDS && (long)g.n * H <= (1l << 30), PM_EUNSUPPORTED, "upsample_ce_fwd_field: logit rows of %d x %d classes do not fit LDS", g.w, g.C);
-  hipStream_t st = (hipStream_t)stream;
   if (int e = fused_launch<true>(g, p, (float*)ws, field, st)) return e;
   hipLaunchKernelGGL(ce_final_kernel, dim3(1), dim3(CE_FINAL_T), 0, st, (const float*)ws, g.n * H, loss_out);
   return pm_check_launch("upsample_ce_fwd_field");
@@ -461,6 +660,11 @@ extern "C" int pm_upsample_ce_bwd_field(const pm_tensor* logits, float inv_temp,
   if (int e = fill(g, logits, inv_temp, &dummy, H, W, "upsample_ce_bwd_field")) return e;      // the row pass reads neither labels nor logits
   PM_REQUIRE(loss_out && field && dlogits && dlogits->ptr && pm_same_shape(logits, dlogits), PM_EINVAL, "upsample_ce_bwd_field: bad args");
   const long total = (long)g.n * g.h * g.w * g.C;
+  if (rows2_plan(g).ok) {
+    hipLaunchKernelGGL(ce_bwd_rows2_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 1 << 20)), dim3(256), 0, (hipStream_t)stream, g, field, field + total,
+                       loss_out, gscale, (float*)dlogits->ptr, (long)dlogits->pitch);
+    return pm_check_launch("upsample_ce_bwd_field");
+  }
   hipLaunchKernelGGL(ce_bwd_cols_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 1 << 20)), dim3(256), 0, (hipStream_t)stream, g, field, loss_out,
                      gscale, (float*)dlogits->ptr, (long)dlogits->pitch);
   return pm_check_launch("upsample_ce_bwd_field");
@@ -481,10 +685,15 @@ extern "C" int pm_upsample_ce_bwd(const pm_tensor* logits, float inv_temp, const
   if (int e = fill(g, logits, inv_temp, labels, H, W, "upsample_ce_bwd")) return e;
   PM_REQUIRE(loss_out && dlogits && dlogits->ptr && pm_same_shape(logits, dlogits), PM_EINVAL, "upsample_ce_bwd: bad args");
   PM_REQUIRE(ws && ws_bytes >= pm_upsample_ce_bwd_workspace(logits, H, W), PM_EWORKSPACE, "upsample_ce_bwd: workspace too small");
-  const FusedPlan p = fused_plan(g);
-  PM_REQUIRE(p.lds <= FUSED_MAX_LDS, PM_EUNSUPPORTED, "upsample_ce_bwd: logit rows of %d x %d classes do not fit LDS", g.w, g.C);
   float* field = (float*)ws;
   float* part = (float*)((char*)ws + pm_align_up(pm_upsample_ce_field_bytes(logits, H, W), 256));
+  if (const Rows2Plan r = rows2_plan(g); r.ok) {
+    rows2_launch(g, r, part, field, (hipStream_t)stream);
+    if (int e = pm_check_launch("upsample_ce_bwd")) return e;
+    return pm_upsample_ce_bwd_field(logits, inv_temp, H, W, loss_out, gscale, field, dlogits, stream);
+  }
+  const FusedPlan p = fused_plan(g);
+  PM_REQUIRE(p.lds <= FUSED_MAX_LDS, PM_EUNSUPPORTED, "upsample_ce_bwd: logit rows of %d x %d classes do not fit LDS", g.w, g.C);
   if (int e = fused_launch<true>(g, p, part, field, (hipStream_t)stream)) return e;
   return pm_upsample_ce_bwd_field(logits, inv_temp, H, W, loss_out, gscale, field, dlogits, stream);
 }

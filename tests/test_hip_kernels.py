@@ -463,7 +463,11 @@ def test_layout_and_labels(K):
 
 @pytest.mark.parametrize('hw,HW,temp,C', [((12, 12), (48, 48), 1.0, 19), ((6, 6), (96, 96), 0.5, 19), ((16, 16), (16, 16), 1.0, 19), ((5, 7), (33, 29), 2.0, 19),
                                           ((1, 1), (8, 8), 1.0, 19), ((24, 24), (384, 384), 0.07, 19), ((9, 9), (4, 6), 1.0, 19), ((7, 5), (30, 41), 1.0, 8),
-                                          ((192, 48), (768, 192), 1.0, 19), ((3, 300), (7, 611), 1.0, 19), ((2, 130), (5, 2100), 1.0, 19), ((4, 4), (4, 700), 1.0, 5)])
+                                          ((192, 48), (768, 192), 1.0, 19), ((3, 300), (7, 611), 1.0, 19), ((2, 130), (5, 2100), 1.0, 19), ((4, 4), (4, 700), 1.0, 5),
+                                          # the interval form of the training forward (19 classes, <= 256 low-res columns, up-sampling ratio < 8): several waves per row group
+                                          # (B handed across wave edges), intervals with one row more than the others, ratio 1 and ~2, the flagship's 192 columns
+                                          ((48, 192), (192, 768), 1.0, 19), ((10, 70), (25, 200), 0.5, 19), ((33, 65), (65, 129), 1.0, 19), ((20, 256), (41, 520), 1.0, 19),
+                                          ((7, 100), (50, 399), 1.0, 19)])
 def test_upsample_ce(K, hw, HW, temp, C):
     n = 2
     lg = rnd(n, C, *hw, seed=1) * 3

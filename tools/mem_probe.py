@@ -41,12 +41,12 @@ lg = score.view(B, h, h, m)
 rec('readloss_fwd', B * H * H * 8 + N * m * 4, lambda: K.upsample_ce_fwd(lg, lab, 1.0))                                    # 39.2 MB
 lo = K.upsample_ce_fwd(lg, lab, 1.0)
 rec('readloss_bwd', B * H * H * 8 + 2 * N * m * 4, lambda: K.upsample_ce_bwd(lg, lab, lo, None, 1.0), iters=5)
-rec('readloss_fwd_field', B * H * H * 8 + N * m * 4 + B * H * h * m * 4, lambda: K.upsample_ce_fwd_field(lg, lab, 1.0))      # training forward: loss + gradient field
 lo_f, lo_field = K.upsample_ce_fwd_field(lg, lab, 1.0)
-rec('readloss_bwd_field', B * H * h * m * 4 + N * m * 4, lambda: K.upsample_ce_bwd_field(lg, (H, H), lo_f, lo_field, None, 1.0))
+rec('readloss_fwd_field', B * H * H * 8 + N * m * 4 + lo_field.numel() * 4, lambda: K.upsample_ce_fwd_field(lg, lab, 1.0))      # training forward: loss + gradient field
+rec('readloss_bwd_field', lo_field.numel() * 4 + N * m * 4, lambda: K.upsample_ce_bwd_field(lg, (H, H), lo_f, lo_field, None, 1.0))
 main = K.new((B, H // 4, H // 4, m), x, pitch_pad=True); main.copy_(torch.randn(B, H // 4, H // 4, m, device='cuda'))
-rec('main_ce_fwd_field', B * H * H * 8 + B * (H // 4) ** 2 * m * 4 + B * H * (H // 4) * m * 4, lambda: K.upsample_ce_fwd_field(main, lab, 1.0))
 mo_f, mo_field = K.upsample_ce_fwd_field(main, lab, 1.0)
-rec('main_ce_bwd_field', B * H * (H // 4) * m * 4 + B * (H // 4) ** 2 * m * 4, lambda: K.upsample_ce_bwd_field(main, (H, H), mo_f, mo_field, None, 1.0))
+rec('main_ce_fwd_field', B * H * H * 8 + B * (H // 4) ** 2 * m * 4 + mo_field.numel() * 4, lambda: K.upsample_ce_fwd_field(main, lab, 1.0))
+rec('main_ce_bwd_field', mo_field.numel() * 4 + B * (H // 4) ** 2 * m * 4, lambda: K.upsample_ce_bwd_field(main, (H, H), mo_f, mo_field, None, 1.0))
 os.makedirs('gpurun_out', exist_ok=True)
 json.dump(out, open('gpurun_out/mem_probe.json', 'w'), indent=1)
