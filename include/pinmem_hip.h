@@ -109,6 +109,10 @@ typedef struct pm_wxf_job {
   int32_t reserved;
 } pm_wxf_job;
 int pm_conv_wxf_refresh_bf16(const pm_wxf_job* jobs, int n, void* stream);
+/* fp32 tier: the kept Winograd forward transforms (U = G g Gt, what pm_conv_fwd writes into wxf for the wide stride-1 3x3 layers) of all jobs in one launch per
+ * 48 filters; kh = kw = 3, dgrad = 0, wxf_bytes = pm_conv_wxf_bytes of the call that owns the buffer (it tells F(4x4) from F(2x2)). Same values as the per-call
+ * transform; replaces ~20 latency-bound launches per training step (network/deepv3plus.py:72-81,398-404; Resnet.py:195). */
+int pm_conv_wxf_refresh_f32(const pm_wxf_job* jobs, int n, void* stream);
 /* bytes of pm_conv_epilogue.bn_partials for this forward call, 0 if the call cannot emit them (then run pm_bn_stats* on y as before) */
 size_t pm_conv_bn_partials_bytes(const pm_tensor* x, const pm_tensor* y, const pm_conv_params* p);
 int pm_conv_fwd(const pm_tensor* x, const float* w_krsc, const pm_tensor* y, const pm_conv_params* p,

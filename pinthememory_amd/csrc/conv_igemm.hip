@@ -1826,6 +1826,28 @@ extern "C" size_t pm_conv_wxf_bytes(const pm_tensor* x, const pm_tensor* y, cons
   return 0;
 }
 
+// fp32 tier: every kept Winograd forward transform U = G g Gt (what pm_conv_fwd writes into pm_conv_params.wxf when wxf_valid == 0) rewritten in one launch per 48
+// filters, right after the optimizer moved the weights. A job's transform size is recovered from its buffer size (pm_conv_wxf_bytes of the call that filled it:
+// (m + 2)^2 x cout x round32(cin) floats, m = 4 or 2); anything else is refused.
+extern "C" int pm_conv_wxf_refresh_f32(const pm_wxf_job* jobs, int n, void* stream) {
+  PM_REQUIRE(n >= 0 && (jobs || n == 0), PM_EINVAL, "conv_wxf_refresh_f32: bad job table");
+  std::vector<const float*> w(n);
+  std::vector<float*> U(n);
+  std::vector<int> cout(n), cin(n), kp(n), m(n);
+  for (int i = 0; i < n; ++i) {
+    const pm_wxf_job& q = jobs[i];
+    PM_REQUIRE(q.w && q.wxf && q.cout > 0 && q.cin > 0 && q.kh == 3 && q.kw == 3 && q.dgrad == 0, PM_EINVAL,
+               "conv_wxf_refresh_f32: job %d: forward transforms of 3x3 filters only", i);
+    PM_REQUIRE(pm_aligned16(q.wxf), PM_EINVAL, "conv_wxf_refresh_f32: job %d: buffer must be 16-byte aligned", i);
+    const int Kp = (q.cin + BK - 1) / BK * BK;
+    const size_t u4 = pm_align_up((size_t)36 * q.cout * Kp * sizeof(float), 256), u2 = pm_align_up((size_t)16 * q.cout * Kp * sizeof(float), 256);
+    PM_REQUIRE((size_t)q.wxf_bytes == u4 || (size_t)q.wxf_bytes == u2, PM_EINVAL, "conv_wxf_refresh_f32: job %d: %ld bytes is neither the F(4x4) nor the F(2x2) transform of %d x %d",
+               i, (long)q.wxf_bytes, q.cout, q.cin);
+    w[i] = q.w, U[i] = (float*)q.wxf, cout[i] = q.cout, cin[i] = q.cin, kp[i] = Kp, m[i] = (size_t)q.wxf_bytes == u4 ? 4 : 2;
+  }
+  return pm_wino_filter_xf_multi(w.data(), U.data(), cout.data(), cin.data(), kp.data(), m.data(), n, (hipStream_t)stream);
+}
+
 // the same for pm_conv_bwd_data: bytes of the rotated / transposed bf16 filter a stride-1 data gradient of the bf16 tier derives from w (0: none)
 extern "C" size_t pm_conv_wxf_bytes_dgrad(const pm_tensor* dy, const pm_tensor* dx, const pm_conv_params* p0) {
   if (!dy || !dx || !p0) return 0;

@@ -49,6 +49,7 @@ struct pm_wino_geom {
 pm_wino_geom pm_wino_make_geom(int n, int h, int w, int d, int m);
 int pm_wino_input_xf(const float* x, long pitch, int C, int Kp, const pm_wino_geom& g, float* V, hipStream_t st);
 int pm_wino_filter_xf(const float* w, int Cout, int Cin, int Kp, bool dgrad, int m, float* U, hipStream_t st);
+int pm_wino_filter_xf_multi(const float* const* w, float* const* U, const int* cout, const int* cin, const int* kp, const int* m, int n, hipStream_t st);
 int pm_wino_output_xf(const float* M, int Cout, const pm_wino_geom& g, float* y, long ypitch, const float* bias, const float* scale, const float* shift,
                       const float* residual, long res_pitch, int relu, hipStream_t st);
 int pm_wino_fused_f4(const float* V, const float* U, int Cout, int Kp, const pm_wino_geom& g, float* y, long ypitch, const float* bias, const float* scale,

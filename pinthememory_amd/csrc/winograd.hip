@@ -228,13 +228,13 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 //   forward   rows = Cout, k = Cin,  g(ky,kx) = w[row][ky][kx][k]
 //   data grad rows = Cin,  k = Cout, g(ky,kx) = w[k][2-ky][2-kx][row]      (180-degree rotation, channels transposed)
 template <int MT, bool DGRAD>
-__global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restrict__ w, int Cout, int Cin, int Kp, float* __restrict__ U) {
+__device__ __forceinline__ void wino_filter_block(const float* __restrict__ w, int Cout, int Cin, int Kp, float* __restrict__ U, int bx, int by,
+                                                  float (*sg)[32][33]) {   // sg: [tap][co_local][ci_local]
   constexpr int A = MT + 2;
-  __shared__ float sg[9][32][33];   // [tap][co_local][ci_local]
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int R = DGRAD ? Cin : Cout;      // GEMM rows
   const int Kr = DGRAD ? Cout : Cin;     // real K extent (zero-filled up to Kp)
-  const int r0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+  const int r0 = by * 32, k0 = bx * 32;
   const int co0 = DGRAD ? k0 : r0, ci0 = DGRAD ? r0 : k0;
   for (int j = ty; j < 32; j += 8) {   // coalesced over ci
     const int co = co0 + j, ci = ci0 + tx;
@@ -273,6 +273,33 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restric
       vstore<4>(out + (a * A + b) * plane, o[b]);
     }
   }
+}
+template <int MT, bool DGRAD>
+__global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restrict__ w, int Cout, int Cin, int Kp, float* __restrict__ U) {
+  __shared__ float sg[9][32][33];
+  wino_filter_block<MT, DGRAD>(w, Cout, Cin, Kp, U, blockIdx.x, blockIdx.y, sg);
+}
+
+// Every kept forward transform of a model rewritten in ONE launch (pm_conv_wxf_refresh_f32, called behind the optimizer step): the 17-21 per-layer launches of
+// wino_filter_kernel in front of the next forward pass are 4 ... 512 blocks each and mostly pure launch latency (17 us on average, 0.36 ms per step).
+// Same block body, same values; block -> (job, tile) through a start table carried in the kernel arguments.
+constexpr int WR_BATCH = 48;
+struct WinoRefreshJobs {
+  const float* w[WR_BATCH];
+  float* U[WR_BATCH];
+  int cout[WR_BATCH], cin[WR_BATCH], kp[WR_BATCH], m[WR_BATCH];
+  int start[WR_BATCH + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void wino_filter_multi_kernel(const WinoRefreshJobs t) {
+  __shared__ float sg[9][32][33];
+  int j = 0;
+  while (j + 1 < t.n && (int)blockIdx.x >= t.start[j + 1]) ++j;      // <= 48 jobs: a scalar walk
+  const int local = (int)blockIdx.x - t.start[j];
+  const int nbx = t.kp[j] / 32;
+  const int bx = local % nbx, by = local / nbx;
+  if (t.m[j] == 4) wino_filter_block<4, false>(t.w[j], t.cout[j], t.cin[j], t.kp[j], t.U[j], bx, by, sg);
+  else wino_filter_block<2, false>(t.w[j], t.cout[j], t.cin[j], t.kp[j], t.U[j], bx, by, sg);
 }
 
 // Weight gradient, step 1: Z = A dY At -- the m x m output-gradient tile scattered to the P transform points (pixels outside the
@@ -543,6 +570,25 @@ int pm_wino_filter_xf(const float* w, int Cout, int Cin, int Kp, bool dgrad, int
     else hipLaunchKernelGGL((wino_filter_kernel<2, false>), grid, dim3(256), 0, st, w, Cout, Cin, Kp, U);
   }
   return pm_check_launch("wino_filter");
+}
+
+// jobs: forward transforms only (w [Cout][3][3][Cin], U [P][Cout][Kp], m in {2, 4}); batches of WR_BATCH per launch
+int pm_wino_filter_xf_multi(const float* const* w, float* const* U, const int* cout, const int* cin, const int* kp, const int* m, int n, hipStream_t st) {
+  for (int i0 = 0; i0 < n; i0 += WR_BATCH) {
+    WinoRefreshJobs t;
+    t.n = std::min(WR_BATCH, n - i0);
+    long blocks = 0;
+    for (int i = 0; i < t.n; ++i) {
+      t.w[i] = w[i0 + i], t.U[i] = U[i0 + i], t.cout[i] = cout[i0 + i], t.cin[i] = cin[i0 + i], t.kp[i] = kp[i0 + i], t.m[i] = m[i0 + i];
+      t.start[i] = (int)blocks;
+      blocks += (long)(kp[i0 + i] / 32) * pm_cdiv(cout[i0 + i], 32);
+    }
+    t.start[t.n] = (int)blocks;
+    if (blocks == 0) continue;
+    hipLaunchKernelGGL(wino_filter_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, st, t);
+    if (int e = pm_check_launch("wino_filter_multi")) return e;
+  }
+  return PM_OK;
 }
 
 int pm_wino_output_xf(const float* M, int Cout, const pm_wino_geom& g, float* y, long ypitch, const float* bias, const float* scale, const float* shift,

@@ -687,6 +687,46 @@ def upsample_ce_bwd_field(logits, label_hw, loss_out, field, gscale, inv_temp=1.
     return dl
 
 
+def refresh_f32_filters():
+    """fp32 tier twin of refresh_bf16_filters(): every kept Winograd FORWARD transform (U = G g Gt of the wide stride-1 3x3 layers) that was used since the last call and
+    is now out of date, rewritten in one launch (pm_conv_wxf_refresh_f32) behind the optimizer step instead of ~20 latency-bound per-layer launches in front of the
+    next forward pass. Same kernel body, same bits. Returns the number of filters rewritten."""
+    if CONV_PREC != 0 or KEEP_WINOGRAD_U is False or not _U_CACHE or not WXF_REFRESH:
+        return 0
+    import weakref
+    dev = torch.cuda.current_device()
+    todo = []
+    for key, ent in _U_CACHE.items():
+        if key[4] != 0 or key[5] or key[3] != dev or not ent[5] or key[1][1] != 3 or key[1][2] != 3:
+            continue
+        ent[5] = False
+        owner = ent[0]() if isinstance(ent[0], weakref.ref) else ent[0]
+        if owner is None or owner.data_ptr() != key[0] or ent[1] == owner._version or not ent[2].is_cuda:
+            continue
+        todo.append((key, ent, owner))
+    if not todo:
+        return 0
+    jobs = (L.PmWxfJob * len(todo))()
+    for j, (key, ent, owner) in zip(jobs, todo):
+        cout, kh, kw, cin = key[1]
+        j.w, j.wxf, j.wxf_bytes, j.cout, j.kh, j.kw, j.cin, j.dgrad = key[0], ent[2].data_ptr(), key[2], cout, kh, kw, cin, 0
+        ent[1] = -1
+    check(_lib().pm_conv_wxf_refresh_f32(jobs, len(todo), stream()), 'pm_conv_wxf_refresh_f32')
+    cur = L.stream_obj()
+    raw = cur.cuda_stream
+    if raw not in _U_STREAMS:
+        _U_STREAMS[raw] = cur
+    ev = cur.record_event()
+    for key, ent, owner in todo:
+        ent[1], ent[3], ent[4] = owner._version, ev, raw
+    return len(todo)
+
+
+def refresh_filters():
+    """Called by the optimizer right after it moved the weights: the kept filter transforms of the active tier, rewritten in one launch."""
+    return refresh_bf16_filters() if CONV_PREC == 2 else refresh_f32_filters()
+
+
 # ---- memory ---------------------------------------------------------------------------------------------------------
 def mem_read_fwd(x, mem, noise=None):
     n, h, w, d = x.shape

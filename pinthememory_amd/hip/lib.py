@@ -64,6 +64,7 @@ SIGNATURES = {
     'pm_conv_wxf_bytes': (_sz, [_T, _T, _P]),
     'pm_conv_wxf_bytes_dgrad': (_sz, [_T, _T, _P]),
     'pm_conv_wxf_refresh_bf16': (_i, [_vp, _i, _vp]),
+    'pm_conv_wxf_refresh_f32': (_i, [_vp, _i, _vp]),
     'pm_conv_workspace': (_sz, [_T, _T, _P, _i]),
     'pm_conv_fwd': (_i, [_T, _vp, _T, _P, _E, _vp, _sz, _vp]),
     'pm_conv_bwd_data': (_i, [_T, _vp, _T, _P, _T, _vp, _sz, _vp]),

@@ -71,7 +71,7 @@ class SGD(torch.optim.SGD):
                 torch.autograd.graph.increment_version([t for p, _, buf in fused for t in (p, buf)])
             if rest:
                 self._torch_step(group, rest)
-        K.refresh_bf16_filters()      # bf16 tier: the kept bf16 copies of the weights this step moved, rewritten in one launch (no-op on the fp32 tier)
+        K.refresh_filters()           # the kept filter transforms of the weights this step moved (bf16 copies / fp32 Winograd U), rewritten in one launch
         return loss
 
     def _torch_step(self, group, params):

@@ -1042,6 +1042,51 @@ def test_bf16_filter_refresh_after_optimizer_step(K):
         K.set_conv_precision('f32')
 
 
+def test_f32_winograd_filter_refresh_after_optimizer_step(K):
+    """fp32 tier: optim.SGD.step() rewrites the kept Winograd forward transforms U = G g Gt of the weights it moved in ONE batched launch (pm_conv_wxf_refresh_f32).
+    The next forward convolutions must find them valid (no per-layer transform) and compute exactly what a freshly derived transform gives -- wide 3x3 layers on the
+    Winograd route at dilation 1 and 2, channel counts that pad K to 32; a layer off the route (1x1) keeps nothing and is unaffected."""
+    from pinthememory_amd import optim
+    K.set_conv_precision('f32')
+    was = K.KEEP_WINOGRAD_U
+    K.KEEP_WINOGRAD_U = None
+    K._U_CACHE.clear()
+    K.unregister_filter_owners()
+    try:
+        cases = [(128, 128, 3, 1, 1, 48), (256, 144, 3, 2, 2, 48), (128, 256, 3, 1, 1, 24), (64, 128, 1, 0, 1, 24)]        # (cout, cin, k, pad, dil, map)
+        ws, xs = [], []
+        for i, (co, ci, k, pad, dil, hw) in enumerate(cases):
+            ws.append(torch.nn.Parameter(rnd(co, ci, k, k, seed=30 + i).mul(0.05).cuda().contiguous(memory_format=torch.channels_last)))
+            xs.append(nhwc(rnd(2, ci, hw, hw, seed=40 + i)))
+        opt = optim.SGD(ws, lr=0.1, momentum=0.9, weight_decay=0.0)
+
+        def run():
+            return [K.conv_fwd(x, w.detach().permute(0, 2, 3, 1), 1, pad, dil) for w, x, (co, ci, k, pad, dil, hw) in zip(ws, xs, cases)]
+        first = run()
+        kept = len(K._U_CACHE)
+        assert kept >= 2                                             # the wide 3x3 layers took the Winograd route and kept their transform
+        for w in ws:
+            w.grad = torch.full_like(w, 0.01)
+        K.filter_transform_count(True)
+        n0 = K.filter_transform_count()
+        opt.step()                                                   # moves the weights, bumps the versions, refreshes the kept transforms in one launch
+        assert all(e[1] == w._version for e in K._U_CACHE.values() for w in ws if (e[0]() is w))
+        second = run()
+        assert K.filter_transform_count() == n0                      # no forward call transformed its filter again
+        K.filter_transform_count(False)
+        assert not any(torch.equal(a, b) for a, b in zip(first, second))
+        K.KEEP_WINOGRAD_U = False                                    # the same calls with transforms derived on the spot
+        for a, b in zip(second, run()):
+            assert torch.equal(a, b)
+        K.KEEP_WINOGRAD_U = None
+        assert K.refresh_f32_filters() == 0                          # nothing out of date: no launch
+    finally:
+        K.filter_transform_count(False)
+        K.KEEP_WINOGRAD_U = was
+        K.unregister_filter_owners()
+        K._U_CACHE.clear()
+
+
 def test_conv_bf16_tier_mixed_edges(K):
     """The mixed-type call sites of the tier: the stem (fp32 NHWC4 image -> bf16, weight gradient from a bf16 dy), a 19-class head (bf16 -> fp32 logits with
     bias, fp32 dy -> bf16 dx, weight / bias gradient), a stride-2 3x3 and a stride-2 1x1 data gradient (bf16 dy -> bf16 dx + bf16 skip)."""
