@@ -44,6 +44,10 @@ def parse():
                          'bf16 between layers, bf16 MFMA convolutions with fp32 accumulation, fp32 statistics / losses / memory / parameters. bf16_operands = round 2-3 '
                          'form (fp32 activations, every convolution converts its operands to bf16 in HBM). bf16_staged = the first form (fp32 tiles in LDS rounded per '
                          'fragment); both kept for A/B')
+    ap.add_argument('--graph', action='store_true',
+                    help='time harness.GraphedAggStep(pipelined=True): the step replayed as ONE hipGraph launch -- [commit forward of the previous step || training forward] '
+                         '+ backward + SGD, the eager step\'s cross-step overlap captured inside the graph; same operations per step, bit-identical results '
+                         '(tests/test_model_parity.py::test_graphed_agg_step_is_bit_identical_to_eager). Single GPU only')
     ap.add_argument('--input-edge', action='store_true',
                     help='side measurement (not the metric): every step takes a fresh uint8 [B, D, H, W, 3] batch from pinned host memory, copied and '
                          'converted on a side stream while the previous step computes (pinthememory_amd/input_edge.py)')
@@ -87,13 +91,36 @@ def config5(a):
     assert torch.isfinite(logits).all() and tuple(logits.shape) == (19, 1024, 2048)
     assert a.warmup == 0 or torch.equal(first, pred), 'sliding-window evaluation is not run-to-run deterministic'
     tf = CONFIG5_GFLOP_PER_TILE * len(tiles) * 2 / 1e3
+    roof = None
+    if not a.no_profile:
+        # dominant convolution kernel of one image, from two extra untimed images with the in-library HIP events on (one stream: no overlap to serialise)
+        from pinthememory_amd.hip import kernels as K
+        K.profile_enable(True)
+        for _ in range(2):
+            one()
+        torch.cuda.synchronize()
+        K.profile_enable(False)
+        if os.environ.get('PM_PROFILE_DUMP'):
+            K.profile_dump(os.environ['PM_PROFILE_DUMP'])
+        best = dominant_conv_kernel(K, False)
+        tot_ms, tot_fl, tot_n = K.profile_read(clear=True)
+        if best:
+            (ms, fl, n), sym, what = best
+            ach = fl / (ms * 1e-3) / 1e12
+            roof = {'bound': 'mfma', 'kernel': '%s (%s)' % (sym, what), 'achieved': round(ach, 2), 'peak': PEAK_TFLOPS_F32_MFMA, 'unit': 'TFLOP/s',
+                    'frac': round(ach / PEAK_TFLOPS_F32_MFMA, 4), 'traffic': None, 'launches_per_image': n / 2, 'avg_launch_ms': round(ms / n, 5),
+                    'gflop_per_launch': round(fl / n / 1e9, 3),
+                    'measured': '2 extra images after the timed region, every convolution launch bracketed by HIP events on its stream (pm_profile_*)',
+                    'all_conv_kernels': {'achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), 'ms_per_image': round(tot_ms / 2, 3), 'launches_per_image': tot_n / 2,
+                                         'executed_tflop_per_image': round(tot_fl / 2 / 1e12, 3)},
+                    'image': {'executed_tflop': round(tot_fl / 2 / 1e12, 3), 'mfma_frac_executed': round(tot_fl / 2 / 1e12 / (dt / a.steps) / PEAK_TFLOPS_F32_MFMA, 4)}}
     print(json.dumps({'metric': 'eval imgs/sec 1024x2048 R101-DeepLabV2 sliding window (crop 1024, 2 flips)', 'value': round(a.steps / dt, 3),
                       'unit': 'imgs/sec', 'n_gpus': 1, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
                       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                       'config': {'workload': 'configs[4]: ResNet-101 DeepLabV2 (network/deepv2.py) 1024x2048 sliding-window inference, side measurement',
                                  'tiles': [list(t) for t in tiles], 'flips': 2, 'conv_tflop_per_image': round(tf, 2),
                                  'direct_equivalent_mfma_frac': round(tf * a.steps / dt / PEAK_TFLOPS_F32_MFMA, 4)},
-                      'roofline': None, 'cpu_baseline': None}), flush=True)
+                      'roofline': roof, 'cpu_baseline': None}), flush=True)
 
 
 def meminit(a):
@@ -143,8 +170,12 @@ def mldg(a):
     x, y = x.cuda(), y.cuda()
     h = a.batch // 2
 
+    inner = [harness.INNER_LR]      # train.py:1208 default 1e-3; every pinmem script anneals it to lr / 4 after each scheduler step (train.py:625-626)
+
     def step():
-        return harness.mldg_train_step(net, u1, u2, opt, x[:h], y[:h], x[h:], y[h:], inner_lr=0.01, sched=sched)
+        out = harness.mldg_train_step(net, u1, u2, opt, x[:h], y[:h], x[h:], y[h:], inner_lr=inner[0], sched=sched, inner_lr_anneal=True)
+        inner[0] = out.pop('next_inner_lr')
+        return out
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
@@ -180,9 +211,9 @@ def mldg(a):
                       'unit': 'imgs/sec', 'n_gpus': 1, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True,
                       'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
                       'config': {'workload': 'train_memory_mldg (train.py:493-632; every pinmem script: train_GS_pinmem_DR50V3P.sh:9-10): %d meta-train + %d meta-test images %dx%d, '
-                                             'inner fwd + bwd (retain_graph), theta\' = theta - 0.01 g for two weight sets, frozen-encoder memory write, meta-test fwd + bwd '
+                                             'inner fwd + bwd (retain_graph), theta\' = theta - inner_lr g for two weight sets (inner_lr 1e-3 at the first iteration, then lr / 4 = 2.5e-3: --inner_lr_anneal), frozen-encoder memory write, meta-test fwd + bwd '
                                              'through the written memory, SGD, eval-mode memory-commit fwd; side measurement' % (h, a.batch - h, a.size, a.size),
-                                 'peak_memory_GB': round(peak_gb, 2), 'final_losses': {k: round(float(v), 5) for k, v in losses.items()},
+                                 'inner_lr_first': harness.INNER_LR, 'inner_lr_last': inner[0], 'peak_memory_GB': round(peak_gb, 2), 'final_losses': {k: round(float(v), 5) for k, v in losses.items()},
                                  'filter_transforms_per_step': xforms,
                                  'filter_transforms_note': 'Winograd U = G w G^T (fp32 tier) / bf16 filter copies (bf16 tier) computed inside one step; functional weights '
                                                            '(theta\') are not owner-registered parameters, so their transforms are never kept between calls',
@@ -406,6 +437,21 @@ def dominant_conv_kernel(K, bf16):
     return r, sym, what
 
 
+def host_enqueue_ms(step_fn, tries=2):
+    """Host time to enqueue one step from an idle GPU (tools/cpu_enqueue_time.py's method): synchronize, call, stop the clock when the call returns (the GPU is still
+    working), synchronize again. The minimum over `tries`. A step is GPU-bound while this stays below its wall time; above ~0.8 x the launch path is the bound."""
+    import torch
+    best = None
+    for _ in range(tries):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step_fn()
+        dt = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        best = dt if best is None else min(best, dt)
+    return round(best * 1e3, 3)
+
+
 def free_port():
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
@@ -551,18 +597,32 @@ def main():
     prof = not a.no_profile
     from pinthememory_amd.hip import ops as _ops
     overlap_defaults = (_ops.OVERLAP_WGRAD, harness.COMMIT_OVERLAP)
+    graphed = None
+    timed_step = step
+    if a.graph:
+        assert not multi and edge is None, '--graph: single process, resident batch'
+        graphed = harness.GraphedAggStep(net, opt, x, y, sched=sched, warmup=0 if a.warmup else 2, pipelined=True)
+        timed_step = lambda: graphed.step(x, y)
+        for _ in range(2):
+            timed_step()
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        losses = step()
+        losses = timed_step()
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    host_ms = {'timed_form': host_enqueue_ms(timed_step)}
+    if graphed is not None:
+        losses = {k: v.clone() for k, v in losses.items()}
+        graphed.close()
+        graphed = None
+        host_ms['eager'] = host_enqueue_ms(step)
     per_rank_ms, ranks_seen = [round(dt / a.steps * 1e3, 3)], 1
     if multi:
         t = torch.zeros(world, device=dev, dtype=torch.float64)
@@ -573,6 +633,12 @@ def main():
         from pinthememory_amd import rccl as _rccl
         comm = _rccl.get(None)                           # the direct communicator every SyncBN / memory / gradient exchange of the step used
         ranks_seen = comm.count() if comm is not None else dist.get_world_size()
+    # how the N > 1 exchanges travelled: the direct RCCL communicator on the compute stream, or torch.distributed's process group (and why)
+    rccl_direct, rccl_reason, coll_per_step = None, 'single process: no collectives', 0
+    if multi:
+        rccl_direct = comm is not None
+        rccl_reason = ('direct ncclComm on the compute stream (pinthememory_amd/rccl.py), %d ranks' % ranks_seen) if rccl_direct else D.direct_fallback_reason(backend)
+        coll_per_step = D.count_collectives(lambda: step())
     roof = None
     if prof:
         # Per-kernel timing brackets every conv launch with two HIP events, which costs ~1.7 ms per step (measured: 70.2 vs 68.5 ms),
@@ -629,8 +695,10 @@ def main():
     if a.dtype == 'f32' and not multi and not a.no_side and edge is None:
         # BASELINE configs[2] in the driver's own run: the SAME process, model and batch switched to the bf16 tier after the timed region -- a few untimed steps, a
         # few timed ones (barrier-free single GPU: synchronize on both sides), then two serialised steps for its dominant kernel. Never part of `value`.
+        # Any failure in here is recorded in the line, never raised: the fp32 metric has been measured and must be printed.
         _ops.OVERLAP_WGRAD, harness.COMMIT_OVERLAP = overlap_defaults
         K.set_conv_precision('bf16')
+        side = {}
         try:
             s_warm, s_steps = 3, 5
             for _ in range(s_warm):
@@ -641,10 +709,13 @@ def main():
                 l16 = step()
             torch.cuda.synchronize()
             dt16 = time.perf_counter() - t1
-            side = {'bf16': {'workload': 'configs[2]: the same model, batch and agg train step on the bf16 tier (bf16 activations and activation gradients between layers, '
-                                         'bf16-MFMA convolutions with fp32 accumulation, fp32 statistics / losses / memory / parameters)',
-                             'ms_per_step': round(dt16 / s_steps * 1e3, 3), 'value': round(a.batch * s_steps / dt16, 3), 'unit': 'imgs/sec', 'steps': s_steps, 'warmup': s_warm,
-                             'final_loss': round(float(l16['total']), 5), 'dtype': 'bf16', 'measured': 'after the timed fp32 region of this run, same process'}}
+            eager_ms = dt16 / s_steps * 1e3
+            enq16 = host_enqueue_ms(step)
+            what16 = ('configs[2]: the same model, batch and agg train step on the bf16 tier (bf16 activations and activation gradients between layers, '
+                      'bf16-MFMA convolutions with fp32 accumulation, fp32 statistics / losses / memory / parameters)')
+            side['bf16'] = {'workload': what16, 'ms_per_step': round(eager_ms, 3), 'value': round(a.batch * s_steps / dt16, 3), 'unit': 'imgs/sec', 'steps': s_steps,
+                            'warmup': s_warm, 'final_loss': round(float(l16['total']), 5), 'dtype': 'bf16', 'form': 'eager launches (commit forward of step t on its own stream under the training forward of step t + 1)',
+                            'host_enqueue_ms': enq16, 'measured': 'after the timed fp32 region of this run, same process'}
             if prof:
                 _ops.OVERLAP_WGRAD, harness.COMMIT_OVERLAP = False, False
                 torch.cuda.synchronize()
@@ -657,11 +728,42 @@ def main():
                     K.profile_dump(os.environ['PM_PROFILE_DUMP'] + '.bf16')
                 b16 = dominant_conv_kernel(K, True)
                 t16_ms, t16_fl, t16_n = K.profile_read(clear=True)
+                _ops.OVERLAP_WGRAD, harness.COMMIT_OVERLAP = overlap_defaults
                 if b16:
                     (ms, fl, n), sym, what = b16
                     side['bf16']['roofline'] = {'bound': 'mfma', 'kernel': '%s (%s)' % (sym, what), 'achieved': round(fl / (ms * 1e-3) / 1e12, 2), 'peak': PEAK_TFLOPS_BF16_MFMA,
                                                 'unit': 'TFLOP/s', 'frac': round(fl / (ms * 1e-3) / 1e12 / PEAK_TFLOPS_BF16_MFMA, 4), 'launches_per_step': n / 2,
                                                 'all_conv_kernels': {'achieved': round(t16_fl / (t16_ms * 1e-3) / 1e12, 2), 'ms_per_step': round(t16_ms / 2, 3)}}
+            # the same step as ONE hipGraph launch (harness.GraphedAggStep, pipelined: the commit forward of step t - 1 beside the training forward of step t inside the graph)
+            try:
+                g16 = harness.GraphedAggStep(net, opt, x, y, sched=sched, warmup=0, pipelined=True)
+                for _ in range(2):
+                    g16.step(x, y)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(s_steps):
+                    lg16 = g16.step(x, y)
+                torch.cuda.synchronize()
+                dtg = time.perf_counter() - t1
+                enq_g = host_enqueue_ms(lambda: g16.step(x, y))
+                final_g = round(float(lg16['total']), 5)
+                g16.close()
+                side['bf16_graphed'] = {'workload': what16, 'form': 'one hipGraph launch per step (harness.GraphedAggStep, pipelined: [commit forward of step t - 1 || training forward '
+                                        'of step t] + backward + SGD; bit-identical to eager steps: tests/test_model_parity.py::test_graphed_agg_step_is_bit_identical_to_eager)',
+                                        'ms_per_step': round(dtg / s_steps * 1e3, 3), 'value': round(a.batch * s_steps / dtg, 3), 'unit': 'imgs/sec', 'steps': s_steps, 'warmup': 2,
+                                        'final_loss': final_g, 'dtype': 'bf16', 'host_enqueue_ms': enq_g}
+                # when the eager step's host enqueue exceeds 0.8 x its wall time the launch path is (about to be) the bound: the captured step is then the form side.bf16 reports
+                if enq16 > 0.8 * eager_ms:
+                    eager_rec = {k: side['bf16'][k] for k in ('ms_per_step', 'value', 'form', 'host_enqueue_ms', 'final_loss')}
+                    side['bf16'].update({k: side['bf16_graphed'][k] for k in ('ms_per_step', 'value', 'form', 'host_enqueue_ms', 'final_loss')})
+                    side['bf16']['eager'] = eager_rec
+                    side['bf16']['form_rule'] = 'host_enqueue_ms %.1f > 0.8 x eager ms_per_step %.1f: the hipGraph form is the one reported' % (enq16, eager_ms)
+                else:
+                    side['bf16']['form_rule'] = 'host_enqueue_ms %.1f <= 0.8 x eager ms_per_step %.1f: eager launches are GPU-bound and stay the reported form' % (enq16, eager_ms)
+            except Exception as e:      # noqa: BLE001
+                side['bf16_graphed'] = {'error': repr(e)}
+        except Exception as e:      # noqa: BLE001 -- the fp32 line is always emitted
+            side.setdefault('bf16', {})['error'] = repr(e)
         finally:
             K.set_conv_precision('f32')
             _ops.OVERLAP_WGRAD, harness.COMMIT_OVERLAP = overlap_defaults
@@ -681,6 +783,11 @@ def main():
                           'ranks_seen': ranks_seen, 'ranks_seen_source': ('ncclCommCount of the direct RCCL communicator' if multi and backend == 'nccl' and ranks_seen == world and _rccl.get(None) is not None
                                                                            else ('torch.distributed world size (%s)' % backend if multi else 'single process')),
                           'ms_per_step_per_rank': per_rank_ms,
+                          'step_form': ('one hipGraph launch per step (harness.GraphedAggStep pipelined; --graph)' if a.graph else 'eager launches'),
+                          'host_enqueue_ms': host_ms['timed_form'], 'host_enqueue_ms_eager': host_ms.get('eager', host_ms['timed_form']),
+                          'host_enqueue_note': 'host time to enqueue one step from an idle GPU (min of 2); GPU-bound while below ms_per_step',
+                          'rccl_direct': rccl_direct, 'rccl_direct_reason': rccl_reason,
+                          'collectives_per_step': coll_per_step,
                           'conv_tflop_per_step': round(gf_img * a.batch / 1e3, 3),
                           'conv_flop_convention': 'direct-algorithm FLOPs (SURVEY 8d); the Winograd F(4x4,3x3) / F(2x2,3x3) layers execute 4x / 2.25x fewer on the MFMA, so step_mfma_frac is a direct-equivalent rate, not MFMA utilisation',
                           'step_mfma_frac': round(gf_img * a.batch * world * a.steps / 1e3 / dt / (peak * world), 4),

@@ -151,8 +151,9 @@ def get_updated_network(old, new, lr):
     return put_theta(new, theta)
 
 
-def mldg_train_step(net, updated_net, updated_net2, opt, x_tr, y_tr, x_te, y_te, inner_lr=0.01, sched=None):
-    """One iteration of train_memory_mldg for the memory configuration (no whitening). Returns inner/outer loss dicts."""
+def mldg_train_step(net, updated_net, updated_net2, opt, x_tr, y_tr, x_te, y_te, inner_lr=0.001, sched=None):
+    """One iteration of train_memory_mldg for the memory configuration (no whitening). Returns inner/outer loss dicts.
+    inner_lr: train.py:1208 default 0.001 (with --inner_lr_anneal the caller passes lr / 4 of the outer schedule, train.py:625-626)."""
     net.train()
     mem_t = net.memory.m_items.clone().detach()
     opt.zero_grad()

@@ -59,6 +59,10 @@ def restore_snapshot(net, optimizer, scheduler, snapshot, restore_optimizer_bool
     forgiving_state_restore(net, ckpt['state_dict'] if 'state_dict' in ckpt else ckpt)
     m = _unwrap(net)
     if 'memory' in ckpt and getattr(m, 'memory', None) is not None:
+        if getattr(m.memory, 'commit_owed', False):
+            # a restore on a SUBSET of ranks would silently drop the owed all-reduce on those ranks only and leave the others waiting in theirs
+            raise RuntimeError('restore_snapshot: the memory-slot all-reduce of the last commit forward is still pending. Call '
+                               'pinthememory_amd.harness.finish_commit(net) on EVERY rank before restoring a snapshot between steps.')
         dev = next(m.parameters()).device
         m.memory.m_items = ckpt['memory'].to(dev)
     return net, optimizer, scheduler, ckpt.get('epoch', 0), ckpt.get('mean_iu', 0.0)

@@ -22,6 +22,28 @@ SYNC_MEMORY = True          # C3 on by default (north star); set False to reprod
 FORCE = os.environ.get('PM_DIST_FORCE', '0') == '1'
 
 
+# collectives issued through this module since the last reset (bench.py: `config.collectives_per_step`): every all-reduce / all-gather of the
+# SyncBN, memory-slot and gradient-bucket paths passes one of the functions below
+COLLECTIVES = [0]
+
+
+def count_collectives(fn):
+    """Run fn() (one training step) and return how many collectives this module issued meanwhile (the same number on every rank)."""
+    n0 = COLLECTIVES[0]
+    fn()
+    return COLLECTIVES[0] - n0
+
+
+def direct_fallback_reason(backend='nccl'):
+    """Why the exchanges of this process go through torch.distributed instead of the direct same-stream RCCL communicator (rccl.py)."""
+    from . import rccl
+    if backend != 'nccl':
+        return "backend '%s' is not RCCL (CPU / one-GPU rehearsal): torch.distributed carries every exchange" % backend
+    if not rccl.ENABLED:
+        return 'PM_DIRECT_RCCL=0'
+    return rccl.FALLBACK.get(None) or 'no direct communicator was created (no GPU tensor exchanged yet)'
+
+
 def is_dist():
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE)
 
@@ -47,6 +69,7 @@ def _direct(t, group):
 
 def all_reduce_sum(t, group=None):
     if is_dist():
+        COLLECTIVES[0] += 1
         comm = _direct(t, group)
         if comm is not None:
             comm.all_reduce_sum_(t)
@@ -59,6 +82,7 @@ def all_reduce_sum_copy(t, group=None):
     """-> (sum over ranks, t untouched). Out of place on the direct communicator (no copy); a clone + in-place all-reduce otherwise."""
     if not is_dist():
         return t
+    COLLECTIVES[0] += 1
     comm = _direct(t, group)
     if comm is not None:
         return comm.all_reduce_sum_into(torch.empty_like(t), t)
@@ -80,6 +104,7 @@ def merge_moments_list(parts, c):
 def gather_moments(mom, group=None):
     """All-gather of the per-rank [3c] moments -> (flat float[world * 3c], world)."""
     world = dist.get_world_size(group)
+    COLLECTIVES[0] += 1
     flat = torch.empty(world * mom.numel(), dtype=mom.dtype, device=mom.device)
     mom = mom.contiguous()
     comm = _direct(mom, group)
@@ -94,6 +119,7 @@ def merge_moments(mom, c, group=None):
     """One all-gather of [3c] floats per BN layer, then one merge kernel (GPU) / a few torch ops (CPU tensors in the gloo tests)."""
     if not is_dist():
         return mom
+    COLLECTIVES[0] += 1
     world = dist.get_world_size(group)
     flat = torch.empty(world * mom.numel(), dtype=mom.dtype, device=mom.device)
     mom = mom.contiguous()
@@ -185,6 +211,7 @@ class GradBuckets:
     def _launch(self, b):
         start, end, _ = self.buckets[b]
         chunk = self.flat[start:end]
+        COLLECTIVES[0] += 1
         comm = _direct(chunk, self.group)
         if comm is not None:            # same communicator and stream as the BN / memory exchanges: ordered by the stream itself
             comm.all_reduce_sum_(chunk)

@@ -94,52 +94,40 @@ def save_checkpoint(path, net, optimizer=None, scheduler=None, epoch=0, mean_iu=
         checkpoint.save_snapshot(path, net, optimizer, scheduler, epoch, mean_iu)
 
 
+_TRAIN_OVERRIDES = {}      # frozenset of module classes -> does any of them override nn.Module.train()?
+
+
 def set_mode(net, training):
     """net.train(training) without nn.Module.__setattr__ on each of the ~600 modules (0.5 ms per step over the three toggles of an agg step): the flag lives in
-    each module's __dict__. The module tree is walked every time (modules may have been swapped: convert_sync_batchnorm)."""
-    for m in net.modules():
+    each module's __dict__. The module tree is walked every time (modules may have been swapped: convert_sync_batchnorm). A tree in which some class overrides
+    train() (frozen-BatchNorm variants, user wrappers that hook the mode switch) gets the real net.train(training): checked once per set of classes."""
+    mods = list(net.modules())
+    classes = frozenset(type(m) for m in mods)
+    over = _TRAIN_OVERRIDES.get(classes)
+    if over is None:
+        over = _TRAIN_OVERRIDES[classes] = any(c.train is not torch.nn.Module.train for c in classes)
+    if over:
+        return net.train(training)
+    for m in mods:
         m.__dict__['training'] = training
     return net
 
 
 def _all_syncbn(m):
-    v = m.__dict__.get('_pm_all_syncbn')
-    if v is None:
-        bns = [b for b in m.modules() if isinstance(b, torch.nn.modules.batchnorm._BatchNorm)]
-        v = m.__dict__['_pm_all_syncbn'] = all(isinstance(b, torch.nn.SyncBatchNorm) for b in bns)
-    return v
+    """Every BatchNorm of the tree is a SyncBatchNorm (train.py:95)? Walked on every call -- only multi-rank steps under the DDP wrapper ask, and a conversion or a
+    module swap after the first step must not be answered from a stale cache."""
+    bns = [b for b in m.modules() if isinstance(b, torch.nn.modules.batchnorm._BatchNorm)]
+    return all(isinstance(b, torch.nn.SyncBatchNorm) for b in bns)
 
 
-def agg_train_step(net, opt, x, gts, aux_gts=None, sched=None, buckets=None, truncate_second_forward=False):
-    """One iteration of train_memory_agg. `buckets` (dist.GradBuckets) replaces DDP's reducer for N > 1."""
-    aux_gts = gts if aux_gts is None else aux_gts
-    m = net.module if hasattr(net, 'module') else net
-    set_mode(net, True)
-    if x.is_cuda and x.shape[1] == 3:
-        # both forward passes of the step read the same batch: lay it out once as the stem's NHWC / 4-channel input
-        x = ops.nchw(K.nchw_to_nhwc(x.float(), c_pad=4))
-    if buckets is not None:
-        buckets.zero()
-    else:
-        opt.zero_grad()
-    outputs = net(x, gts=gts, aux_gts=aux_gts, memory_writing=True, writing_detach=False)
-    # train.py:312 clones the memory before the forward; it is re-assigned, never written in place (memory.py:253,256; Memory_sup.write here), so the
-    # tensor the read just used IS that clone -- taken after the forward, because with an overlapped commit forward it only becomes final at that read
-    mem_t = m.memory.last_read
-    loss = total_loss(outputs)
-    loss.backward()
-    if buckets is not None:
-        buckets.finish()
-    opt.step()
-    dist_on = D.is_dist()
-    # Under the reference's DDP wrapper (network/__init__.py:25-33) the commit forward goes through the bare module: DDP's forward would broadcast the
-    # buffers on its own communicator, from a second stream. With every BatchNorm converted to SyncBatchNorm (train.py:95) the running moments are
-    # already identical on all ranks, so that broadcast changes nothing; with local BatchNorms it does (rank 0's moments win) and the overlap stays off.
+def _commit_forward(net, m, x, gts, aux_gts, mem_t, overlap, dist_on, truncate_second_forward=False, main=None):
+    """The memory-commit forward of train.py:330-335: eval mode, no graph, post-SGD weights, starting from the memory `mem_t` the training forward read;
+    on its own stream when `overlap` (the caller's stream otherwise). Returns the event recorded at its end (overlap) or None."""
     wrapped = hasattr(net, 'module')
-    overlap = COMMIT_OVERLAP and x.is_cuda and (not dist_on or (D.SYNC_MEMORY and (not wrapped or _all_syncbn(m))))
     fwd_net = m if (overlap and wrapped) else net
-    main = torch.cuda.current_stream() if x.is_cuda else None
+    main = (torch.cuda.current_stream() if x.is_cuda else None) if main is None else main
     side = _commit_stream(x.device) if overlap else None
+    done = None
     if overlap:
         side.wait_stream(main)
         for t in (x, gts, aux_gts, mem_t):
@@ -164,33 +152,82 @@ def agg_train_step(net, opt, x, gts, aux_gts=None, sched=None, buckets=None, tru
     if overlap:
         # the next training forward rewrites the BatchNorm running moments: wait for the fold launch that read them (or, without one, for everything)
         main.wait_event(ops.last_prefold_event if (ops.last_prefold_event is not None and ops.fold_misses == 0) else done)
+    return done
+
+
+def agg_train_step(net, opt, x, gts, aux_gts=None, sched=None, buckets=None, truncate_second_forward=False, commit=True):
+    """One iteration of train_memory_agg. `buckets` (dist.GradBuckets) replaces DDP's reducer for N > 1.
+    commit=False withholds the memory-commit forward (GraphedAggStep(pipelined=True) runs it at the head of the next captured step, beside that step's
+    training forward): the returned dict then carries `mem_t`, the memory the commit forward has to start from."""
+    aux_gts = gts if aux_gts is None else aux_gts
+    m = net.module if hasattr(net, 'module') else net
+    set_mode(net, True)
+    if x.is_cuda and x.shape[1] == 3:
+        # both forward passes of the step read the same batch: lay it out once as the stem's NHWC / 4-channel input
+        x = ops.nchw(K.nchw_to_nhwc(x.float(), c_pad=4))
+    if buckets is not None:
+        buckets.zero()
+    else:
+        opt.zero_grad()
+    outputs = net(x, gts=gts, aux_gts=aux_gts, memory_writing=True, writing_detach=False)
+    # train.py:312 clones the memory before the forward; it is re-assigned, never written in place (memory.py:253,256; Memory_sup.write here), so the
+    # tensor the read just used IS that clone -- taken after the forward, because with an overlapped commit forward it only becomes final at that read
+    mem_t = m.memory.last_read
+    loss = total_loss(outputs)
+    loss.backward()
+    if buckets is not None:
+        buckets.finish()
+    opt.step()
+    out = dict(loss1=outputs[0].detach(), loss2=outputs[1].detach(), readloss=outputs[-2].detach(), div=outputs[-3][0].detach(),
+               cls=outputs[-3][1].detach(), total=loss.detach())
+    if not commit:
+        out['mem_t'] = mem_t
+        if sched is not None:
+            sched.step()
+        return out
+    dist_on = D.is_dist()
+    # Under the reference's DDP wrapper (network/__init__.py:25-33) the commit forward goes through the bare module: DDP's forward would broadcast the
+    # buffers on its own communicator, from a second stream. With every BatchNorm converted to SyncBatchNorm (train.py:95) the running moments are
+    # already identical on all ranks, so that broadcast changes nothing; with local BatchNorms it does (rank 0's moments win) and the overlap stays off.
+    wrapped = hasattr(net, 'module')
+    overlap = COMMIT_OVERLAP and x.is_cuda and (not dist_on or (D.SYNC_MEMORY and (not wrapped or _all_syncbn(m))))
+    _commit_forward(net, m, x, gts, aux_gts, mem_t, overlap, dist_on, truncate_second_forward)
     if sched is not None:
         sched.step()
-    return dict(loss1=outputs[0].detach(), loss2=outputs[1].detach(), readloss=outputs[-2].detach(), div=outputs[-3][0].detach(),
-                cls=outputs[-3][1].detach(), total=loss.detach())
+    return out
 
 
 class GraphedAggStep:
     """One agg train step (train forward + backward + SGD + memory-commit forward) captured in a hipGraph and replayed: ~1 300 kernel launches, their stream forks /
-    joins and allocations become ONE graph launch per step. For the regime where the step is launch-bound -- the bf16 tier: 28 ms of Python + HIP enqueue per step
-    against 27-29 ms of GPU time (DESIGN section 7 "Round 4"); the fp32 step is GPU-bound and gains only its ~1.5 ms of stream-join gaps.
+    joins and allocations become ONE graph launch per step. For the regime where the step is launch-bound -- the bf16 tier: 20 ms of Python + HIP enqueue per step
+    against 26 ms of GPU time (DESIGN section 7 "Round 4"), i.e. host-bound as soon as the kernels get 20 % faster.
 
     What makes the step replayable: static input buffers (`x`, `gts` are copied in before each replay), the committed memory lives in one static buffer
     (`Memory_sup.m_items` points at it; the captured step reads it first and writes it last), weights / BatchNorm buffers / momentum buffers are updated in place, the
     learning rate is read from device memory (`optim.SGD.lr_device`, pm_sgd_momentum_multi_dev), random draws (gumbel noise, Dropout2d) go through torch's graph-safe
-    generator, and the kept filter transforms are recomputed INSIDE the captured step exactly where an eager step recomputes them (commit forward, after the SGD), so the
-    cache stays consistent with the weights across replays. The commit forward runs serially inside the graph (no cross-step overlap). Single process only.
+    generator, and the kept filter transforms are recomputed INSIDE the captured step exactly where an eager step recomputes them (after the SGD), so the
+    cache stays consistent with the weights across replays. Single process only.
 
-        g = GraphedAggStep(net, opt, x, gts, sched=sched)      # warms up eagerly, then captures
+    pipelined=False: the commit forward runs serially at the END of the captured step (no cross-step overlap: a graph boundary is a join).
+    pipelined=True (round 5): the captured unit is [commit forward of step t - 1 on its own stream  ||  training forward of step t] -> backward -> SGD, i.e. the eager
+    path's cross-step overlap (worth 1.0-1.8 ms on the bf16 tier) INSIDE one graph: the commit forward of the previous batch (static copies `x_prev`, `gts_prev`, kept by
+    the replay itself) forks off at the head of the graph, the training forward joins it where it reads the memory -- the same dependencies the eager overlapped step has
+    (BatchNorm running moments: the training forward waits for the commit forward's one fold launch). Every step performs exactly the reference's operations in the
+    reference's dependency order; what shifts is only WHEN the commit of step t is executed: at the head of replay t + 1. Hence `Memory_sup.m_items` is one commit
+    behind between replays; `committed_memory()` returns the up-to-date memory (it runs the withheld commit forward eagerly into a scratch tensor, leaving the pipeline
+    untouched) and `close()` folds it in and hands the model back to eager use.
+
+        g = GraphedAggStep(net, opt, x, gts, sched=sched, pipelined=True)      # warms up eagerly, then captures
         losses = g.step(x, gts)                                  # every further step; tensors of the returned dict are overwritten by the next replay
+        g.close()                                                # model, optimizer and memory are consistent for eager code again
     """
 
-    def __init__(self, net, opt, x, gts, sched=None, warmup=3):
+    def __init__(self, net, opt, x, gts, sched=None, warmup=3, pipelined=False):
         global COMMIT_OVERLAP
         assert x.is_cuda and not D.is_dist(), 'GraphedAggStep: single-process GPU training only'
         assert len(opt.param_groups) == 1, 'GraphedAggStep: one parameter group (optimizer.py:21-25)'
-        self.net, self.opt, self.sched = net, opt, sched
-        m = net.module if hasattr(net, 'module') else net
+        self.net, self.opt, self.sched, self.pipelined, self.closed = net, opt, sched, pipelined, False
+        m = self.m = net.module if hasattr(net, 'module') else net
         self.x = ops.nchw(K.nchw_to_nhwc(x.float(), c_pad=4)) if x.shape[1] == 3 else x.clone()      # the stem's NHWC4 layout, converted once per step outside the graph
         self.gts = gts.clone()
         self.lr = torch.zeros(1, dtype=torch.float32, device=x.device)
@@ -203,20 +240,58 @@ class GraphedAggStep:
             finish_commit(net)
             self.mem = m.memory.m_items.detach().clone()
             m.memory.m_items = self.mem
+            if pipelined:
+                # one more eager step whose commit is withheld: the state every replay starts from (weights after SGD t, memory committed through t - 1, batch t in x_prev)
+                self.x_prev, self.gts_prev = self.x.clone(), self.gts.clone()
+                self.lr.fill_(float(opt.param_groups[0]['lr']))
+                agg_train_step(net, opt, self.x, self.gts, sched=sched, commit=False)
+                m.memory.m_items = self.mem
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             self.lr.fill_(float(opt.param_groups[0]['lr']))
             with torch.cuda.graph(self.graph):
-                self.out = agg_train_step(net, opt, self.x, self.gts, sched=None)
-                self.mem.copy_(m.memory.m_items)
+                if pipelined:
+                    main = torch.cuda.current_stream()
+                    side = _commit_stream(x.device)
+                    self._commit(main, overlap=True)
+                    self.out = agg_train_step(net, opt, self.x, self.gts, sched=None, commit=False)
+                    self.out.pop('mem_t')
+                    main.wait_stream(side)
+                    self.x_prev.copy_(self.x)
+                    self.gts_prev.copy_(self.gts)
+                else:
+                    self.out = agg_train_step(net, opt, self.x, self.gts, sched=None)
+                    self.mem.copy_(m.memory.m_items)
                 if ops.OVERLAP_WGRAD:      # every stream forked into the capture rejoins it (the weight-gradient stream's last event record trails its last join)
                     torch.cuda.current_stream().wait_stream(ops._side_stream())
-            m.memory.m_items = self.mem
             torch.cuda.synchronize()
+            # events recorded inside the capture mean nothing to eager code (waiting for one from a non-capturing stream is an error): everything they ordered is complete
+            m.memory.pending = None
+            m.memory.m_items = self.mem
+            ops.commit_done.pop(x.device.index, None)
+            ops.last_prefold_event = None
+            K.forget_filter_events()
         finally:
             COMMIT_OVERLAP = prev_overlap
 
+    def _commit(self, main, overlap, into=None):
+        """The withheld commit forward of the previous batch: from the static memory buffer, result copied back into it (or into `into`)."""
+        m = self.m
+        _commit_forward(self.net, m, self.x_prev, self.gts_prev, self.gts_prev, self.mem, overlap, False, main=main)
+        m.memory.pending = None            # dropped, not waited for: the event below (after the copy-back) replaces it
+        side = _commit_stream(self.x.device) if overlap else None
+        done = None
+        with torch.no_grad(), (torch.cuda.stream(side) if overlap else contextlib.nullcontext()):
+            (self.mem if into is None else into).copy_(m.memory._m_items)
+            if overlap:
+                done = side.record_event()
+        m.memory.m_items = self.mem
+        if overlap:
+            m.memory.pending = done       # the training forward's memory read (and the SGD: ops.commit_done) wait for the copy-back
+            ops.commit_done[self.x.device.index] = done
+
     def step(self, x=None, gts=None):
+        assert not self.closed, 'GraphedAggStep.step() after close()'
         if x is not None and x.data_ptr() != self.x.data_ptr():
             if x.shape[1] == 3:
                 self.x.copy_(ops.nchw(K.nchw_to_nhwc(x.float(), c_pad=4)))
@@ -229,6 +304,31 @@ class GraphedAggStep:
         if self.sched is not None:
             self.sched.step()
         return self.out
+
+    def committed_memory(self):
+        """The memory as of the last step INCLUDING its commit. pipelined: the withheld commit forward is run eagerly into a scratch tensor (the pipeline state --
+        static memory buffer, x_prev -- is left as it is, so replays may continue); otherwise the static buffer itself."""
+        if not self.pipelined or self.closed:
+            return self.m.memory.m_items
+        out = torch.empty_like(self.mem)
+        self._commit(torch.cuda.current_stream(), overlap=False, into=out)      # reads the static buffer, writes `out`; m_items points at the static buffer again
+        return out
+
+    def close(self):
+        """Hand model and optimizer back to eager code: the withheld commit (pipelined) is folded into `m_items`, the optimizer forgets the device-side learning
+        rate of the capture (an eager opt.step() after a graphed phase silently used the LR of the last replay), graph-internal events are dropped."""
+        if self.closed:
+            return
+        torch.cuda.synchronize()
+        if self.pipelined:
+            self._commit(torch.cuda.current_stream(), overlap=False)
+        self.m.memory.m_items = self.mem.clone()
+        self.m.memory.pending = None
+        ops.commit_done.pop(self.x.device.index, None)
+        if getattr(self.opt, 'lr_device', None) is self.lr:
+            self.opt.lr_device = None
+        self.closed = True
+        torch.cuda.synchronize()
 
 
 def memory_initialize(net, batches, epochs=2):
@@ -343,10 +443,21 @@ def get_updated_network(old, new, lr):
     return put_theta(new, theta)
 
 
-def mldg_train_step(net, updated_net, updated_net2, opt, x_tr, y_tr, x_te, y_te, inner_lr=0.01, sched=None):
+INNER_LR = 0.001      # train.py:1208 `--inner_lr` default
+
+
+def annealed_inner_lr(opt):
+    """train.py:625-626 (`--inner_lr_anneal`, passed by every pinmem script: train_GS_pinmem_DR50V3P.sh:18): after each scheduler step the inner
+    learning rate of the NEXT iteration is a quarter of the outer one."""
+    return opt.param_groups[-1]['lr'] / 4
+
+
+def mldg_train_step(net, updated_net, updated_net2, opt, x_tr, y_tr, x_te, y_te, inner_lr=INNER_LR, sched=None, inner_lr_anneal=False):
     """One iteration of train_memory_mldg (memory configuration, whitening off): inner step on the meta-train domains,
     frozen-encoder memory write with the stepped weights, read-only meta-test forward whose loss back-propagates through the
-    WRITTEN memory into the write graph (memory.py:323-324 only detaches when writing), outer step, memory commit."""
+    WRITTEN memory into the write graph (memory.py:323-324 only detaches when writing), outer step, memory commit.
+    inner_lr: the reference's default 1e-3 (train.py:1208); with inner_lr_anneal the returned dict carries `next_inner_lr` = lr / 4 of the
+    outer schedule after this step (train.py:625-626) for the caller to pass into the next iteration."""
     net.train()
     finish_commit(net)          # every rank is here: a memory commit deferred by a preceding agg step is finished before m_items is read
     mem_t = net.memory.m_items.clone().detach()
@@ -374,8 +485,11 @@ def mldg_train_step(net, updated_net, updated_net2, opt, x_tr, y_tr, x_te, y_te,
         net.train()
     if sched is not None:
         sched.step()
-    return dict(inner=inner.detach(), outer=outer.detach(), inner_loss1=out_in[0].detach(), outer_loss1=out_te[0].detach(),
-                outer_read=out_te[-2].detach())
+    out = dict(inner=inner.detach(), outer=outer.detach(), inner_loss1=out_in[0].detach(), outer_loss1=out_te[0].detach(),
+               outer_read=out_te[-2].detach())
+    if inner_lr_anneal:
+        out['next_inner_lr'] = annealed_inner_lr(opt)
+    return out
 
 
 # ---- pooled multi-scale / flip evaluation: inference_pool + MeanFusion (eval.py:133-145,277-337) -------------------------

@@ -182,6 +182,13 @@ def _wino_u(p, w_krsc, nbu, dgrad=False):
     return None if valid else (ent, version)
 
 
+def forget_filter_events():
+    """Drop the 'written by a launch on another stream' events of every kept transform. Call after torch.cuda.synchronize(): harness.GraphedAggStep does once its capture has
+    ended -- events recorded inside a stream capture must not be waited for from eager code, and a replay (a single launch in stream order) needs none."""
+    for ent in _U_CACHE.values():
+        ent[3] = ent[4] = None
+
+
 WXF_REFRESH = os.environ.get('PM_WXF_REFRESH', '1') != '0'      # A/B knob
 
 

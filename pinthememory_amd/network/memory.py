@@ -105,6 +105,11 @@ class Memory_sup(nn.Module):
         _DEFERRED.pop(self, None)
         self._m_items = value
 
+    @property
+    def commit_owed(self):
+        """True while the cross-rank sum of a deferred commit write is pending (more than one rank): `m_items` raises, assignment would drop it on this rank only."""
+        return self in _DEFERRED
+
     def finish_commit(self):
         """COLLECTIVE when a deferred write is pending (Memory_sup.defer_sync): all-reduce of the local nominator | denominator and the momentum update,
         on the caller's stream -- the two launches write() would have issued. Every rank must call it at the same point of its program: read() does

@@ -125,6 +125,7 @@ class DirectComm:
 
 
 _comms = {}      # group (None = WORLD) -> DirectComm, or False after an agreed fall-back
+FALLBACK = {}    # group -> why the agreed fall-back to torch.distributed was taken (bench.py quotes it as `config.rccl_direct_reason`)
 
 
 def get(group=None):
@@ -152,6 +153,7 @@ def get(group=None):
             if c is not None:
                 c.destroy()
             warnings.warn('direct RCCL communicator unavailable (%r); using torch.distributed for the BN exchanges' % (err,))
+            FALLBACK[key] = 'agreed fall-back to torch.distributed: %r on this rank (some rank failed to create or self-test the communicator)' % (err,)
             c = False
         _comms[key] = c
     return c or None

@@ -128,5 +128,36 @@ def test_m_items_never_hides_a_collective():
     with pytest.raises(RuntimeError, match='finish_commit'):
         m.m_items
     assert m in memory._DEFERRED                    # the failed read consumed nothing
+    # a restore while the sum is owed fails loudly too (on a subset of ranks it would drop the all-reduce there and strand the others: ADVICE r4)
+    from pinthememory_amd import checkpoint
+
+    class Holder(torch.nn.Module):
+        def __init__(self, mem):
+            super().__init__()
+            self.memory = mem
+    holder = Holder(m)
+    assert m.commit_owed
+    with pytest.raises(RuntimeError, match='finish_commit'):
+        checkpoint.restore_snapshot(holder, None, None, {'state_dict': {}, 'memory': t * 3})
+    assert m in memory._DEFERRED
     m.m_items = t * 1
-    assert m not in memory._DEFERRED and torch.equal(m.m_items, t)
+    assert m not in memory._DEFERRED and not m.commit_owed and torch.equal(m.m_items, t)
+
+
+def test_set_mode_respects_train_overrides():
+    """harness.set_mode writes the flag into each module's __dict__ (0.5 ms per step saved) -- unless some class of the tree overrides train(): then the real
+    net.train(mode) runs (frozen-BatchNorm variants and user wrappers rely on it)."""
+    import torch
+    from pinthememory_amd import harness
+
+    class Frozen(torch.nn.BatchNorm2d):
+        def train(self, mode=True):
+            return super().train(False)      # stays in eval mode whatever the parent says
+    plain = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 1), torch.nn.BatchNorm2d(4))
+    harness.set_mode(plain, False)
+    assert not plain.training and not plain[1].training
+    harness.set_mode(plain, True)
+    assert plain.training and plain[1].training
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 1), Frozen(4))
+    harness.set_mode(net, True)
+    assert net.training and net[0].training and not net[1].training
