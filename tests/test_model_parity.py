@@ -79,7 +79,7 @@ def test_ragged_input_size_vs_oracle(env):
     assert (net.memory.m_items.cpu() - ref.memory.m_items).abs().max().item() < 1e-4
 
 
-def _oracle(env, dtype, x, y, step):
+def _oracle(env, dtype, x, y, step, emulate_bf16=False):
     """CPU oracle in `dtype` on the same inputs: fp32 is the reference's arithmetic, fp64 the ground truth that tells how
     much of any difference is fp32 round-off. With the damped residual branches of synth.det_state_dict the reference's own fp32
     gradients sit ~1e-3 (median 8e-4, worst 3e-3 at bs=2, 128^2) from the fp64 run: the floor is ReLU units within round-off of zero
@@ -90,14 +90,21 @@ def _oracle(env, dtype, x, y, step):
     net.dsn[3].p = 0.0
     net.train()
     res = {}
-    if step:
-        opt, _ = o_h.make_optimizer(net)
-        res['losses'] = {k: v.double() for k, v in o_h.agg_train_step(net, opt, x.to(dtype), y).items()}
+    import contextlib
+    if emulate_bf16:      # the same oracle with the bf16 tier's STORAGE rounding inserted (oracle/bf16_emulation.py): what bf16 activations cost on this network, whatever the kernels
+        from oracle import bf16_emulation
+        ctx = bf16_emulation.bf16_tier(net, env['o_deeplab'])
     else:
-        out = net(x.to(dtype), gts=y, aux_gts=y, memory_writing=True, writing_detach=False)
-        res['losses'] = dict(loss1=out[0].detach().double(), loss2=out[1].detach().double(), readloss=out[-2].detach().double(),
-                             div=out[-3][0].detach().double(), cls=out[-3][1].detach().double())
-        o_h.total_loss(out).backward()
+        ctx = contextlib.nullcontext()
+    with ctx:
+        if step:
+            opt, _ = o_h.make_optimizer(net)
+            res['losses'] = {k: v.double() for k, v in o_h.agg_train_step(net, opt, x.to(dtype), y).items()}
+        else:
+            out = net(x.to(dtype), gts=y, aux_gts=y, memory_writing=True, writing_detach=False)
+            res['losses'] = dict(loss1=out[0].detach().double(), loss2=out[1].detach().double(), readloss=out[-2].detach().double(),
+                                 div=out[-3][0].detach().double(), cls=out[-3][1].detach().double())
+            o_h.total_loss(out).backward()
     res['grads'] = {k: v.grad.detach().double() for k, v in net.named_parameters()}
     res['state'] = {k: v.detach().double() for k, v in net.state_dict().items()}
     res['m_items'] = net.memory.m_items.detach().double()
@@ -230,8 +237,13 @@ def test_mldg_train_step_vs_oracle(env, INNER_LR, capsys):
     for k, t in truth['losses'].items():
         assert abs(hip['losses'][k].item() - o32['losses'][k].item()) < 5e-4 * max(1, abs(t.item())), k
         assert abs(hip['losses'][k].item() - t.item()) <= 3 * abs(o32['losses'][k].item() - t.item()) + 1e-4 * max(1, abs(t.item())), k
-    st = _grad_stats(hip, truth, 'grads')
-    assert st[0][0] < GRAD_TOL_MAX and st[len(st) // 2][0] < GRAD_TOL_MEDIAN, st[:6]          # the agg step's fixed bounds
+    st, so = _grad_stats(hip, truth, 'grads'), _grad_stats(o32, truth, 'grads')
+    with capsys.disabled():
+        print('\n[mldg 2+2 x 96^2, inner_lr %g] gradients vs f64: hip worst %s median %.2e | fp32 oracle worst %s median %.2e'
+              % (INNER_LR, [(round(e, 5), k) for e, k in st[:2]], st[len(st) // 2][0], [(round(e, 5), k) for e, k in so[:2]], so[len(so) // 2][0]))
+    # the agg step's fixed bounds at the reference's default inner step; at the annealed 2.5e-3 the meta-test gradient passes through theta' = theta - 2.5e-3 g and the
+    # layer4 BatchNorm biases sit at 1.1e-2 on the HIP path and on the reference's own fp32 arithmetic alike: there the worst-tensor bound is 2e-2, the median bound stays
+    assert st[0][0] < (GRAD_TOL_MAX if INNER_LR <= 1e-3 else 2 * GRAD_TOL_MAX) and st[len(st) // 2][0] < GRAD_TOL_MEDIAN, st[:6]
     bad = _as_good_as_fp32(hip, o32, truth, 'grads', floor=1e-4)
     assert not bad, bad[:8]
     # gradient that reaches the write path ONLY through the written memory read at meta-test time (plus the inner step's own)
@@ -615,34 +627,44 @@ def test_config3_bf16_tier_production_size_step_vs_oracle(env, capsys):
 def test_bf16_tier_assembled_gradients_vs_fp64_oracle(env, capsys):
     """The bf16 tier's BACKWARD as assembled gradients: train forward + backward of the whole network on the tier (bn16_bwd_*, the native
     bf16 weight gradient, the parity-class stride-2 data gradients, bf16 activation gradients between layers), every parameter gradient against the fp64 oracle,
-    next to the fp32 HIP path's error on the same batch. The tier rounds every activation and activation gradient to 8 mantissa bits (2^-9 relative per element,
-    averaging down over the reductions), so the bar is NOT the fp32 one: per-tensor relative error median < 1e-2, worst < 6e-2 (measured figures are printed:
-    the gate sits at ~2 x them), and the loss-fed heads (no ReLU-flip noise) within 1e-2."""
+    next to the fp32 HIP path's error on the same batch -- and next to what bf16 STORAGE inherently costs on this network: the same fp64 oracle with a bf16 rounding
+    inserted wherever the tier stores bf16 (oracle/bf16_emulation.py; float64 arithmetic, no kernel of ours involved).
+    Measured (round 5, bs=2 128^2): the tier sits at a per-tensor relative error of 0.04 (final2) / 0.10 (final1) / 0.31 (ASPP) / 0.48-0.56 (trunk), median 0.53,
+    projection coefficient <g, g64> / <g64, g64> = 0.80 in the trunk -- 1 000 x the fp32 path's 5e-4. The EMULATED oracle measures the same profile to two digits
+    (0.039 / 0.101 / 0.309 / 0.48-0.56, median 0.52, coefficient 0.79-0.82): at 8 x 8 maps and 128 samples per BatchNorm channel, rounding pre-BatchNorm activations to 8
+    mantissa bits flips enough ReLU units to decorrelate a fifth of the gradient, with any arithmetic behind it. So the gate is relative to the emulation: per tensor the
+    tier may be at most 1.3 x as far from the fp64 truth as the emulation (+ 0.02), the median at most 1.15 x; loss-fed heads within 5e-2; losses within 0.25 %."""
     from pinthememory_amd.hip import kernels as K
     x, y = env['synth'].make_batch(2, 128)
     truth = _oracle(env, torch.float64, x, y, False)
+    emul = _oracle(env, torch.float64, x, y, False, emulate_bf16=True)
     h32 = _hip(env, x, y, False)
     K.set_conv_precision('bf16')
     try:
         h16 = _hip(env, x, y, False)
     finally:
         K.set_conv_precision('f32')
-    s16, s32 = _grad_stats(h16, truth, 'grads'), _grad_stats(h32, truth, 'grads')
-    e32 = dict((k, e) for e, k in s32)
-    ratio = sorted(e / max(e32[k], 1e-7) for e, k in s16)
+    s16, s32, sem = _grad_stats(h16, truth, 'grads'), _grad_stats(h32, truth, 'grads'), _grad_stats(emul, truth, 'grads')
+    eem = dict((k, e) for e, k in sem)
+
+    def coef(res, k):
+        a, t = res['grads'][k], truth['grads'][k]
+        return (a * t).sum().item() / (t * t).sum().item()
+    probe = ('final2.0.weight', 'final1.3.weight', 'aspp.features.1.0.weight', 'layer4.2.conv3.weight', 'layer3.0.conv1.weight', 'layer1.0.conv1.weight')
+    e16 = dict((k, e) for e, k in s16)
     with capsys.disabled():
-        print('\n[bf16 tier gradients vs fp64, bs=2 128^2] per-tensor relative error: bf16 median %.2e / worst %s; fp32 HIP median %.2e / worst %.2e; '
-              'ratio bf16 / fp32 per tensor: median %.1f, 90th percentile %.1f; losses bf16 %s vs fp64 %s'
-              % (s16[len(s16) // 2][0], [(round(e, 4), k) for e, k in s16[:3]], s32[len(s32) // 2][0], s32[0][0], ratio[len(ratio) // 2], ratio[int(len(ratio) * 0.9)],
-                 {k: round(v.item(), 4) for k, v in h16['losses'].items()}, {k: round(v.item(), 4) for k, v in truth['losses'].items()}))
-    assert s16[len(s16) // 2][0] < BF16_GRAD_MEDIAN and s16[0][0] < BF16_GRAD_MAX, s16[:6]
+        print('\n[bf16 tier gradients vs fp64, bs=2 128^2] per-tensor relative error: tier median %.3f / worst %s | bf16-storage emulation of the fp64 oracle median %.3f / worst %s | '
+              'fp32 HIP median %.2e / worst %.2e' % (s16[len(s16) // 2][0], [(round(e, 3), k) for e, k in s16[:2]], sem[len(sem) // 2][0], [(round(e, 3), k) for e, k in sem[:2]],
+                                                     s32[len(s32) // 2][0], s32[0][0]))
+        print('   tensor: tier err / emulation err (projection coefficient tier / emulation): ' +
+              '; '.join('%s %.3f / %.3f (%.2f / %.2f)' % (k, e16[k], eem[k], coef(h16, k), coef(emul, k)) for k in probe))
+    assert s16[len(s16) // 2][0] <= 1.15 * sem[len(sem) // 2][0] + 1e-3, (s16[len(s16) // 2], sem[len(sem) // 2])
+    bad = [(k, e, eem[k]) for e, k in s16 if e > 1.3 * eem[k] + 0.02]
+    assert not bad, bad[:8]
     for k in ('dsn.4.weight', 'final2.0.weight', 'memory.clsfier.weight'):
-        assert _relerr(h16['grads'][k], truth['grads'][k]) < 1e-2, (k, _relerr(h16['grads'][k], truth['grads'][k]))
-    for k, t in truth['losses'].items():
-        assert abs(h16['losses'][k].item() - t.item()) < 2.5e-3 * max(1.0, abs(t.item())), k
-
-
-BF16_GRAD_MEDIAN, BF16_GRAD_MAX = 1e-2, 6e-2      # provisional until measured on the GPU (printed by the test)
+        assert _relerr(h16['grads'][k], truth['grads'][k]) < 5e-2, (k, _relerr(h16['grads'][k], truth['grads'][k]))
+    for k, t in truth['losses'].items():      # at 8 x 8 maps the emulation itself is 0.23 % off on loss1: the tier may be twice as far as it + 0.2 %
+        assert abs(h16['losses'][k].item() - t.item()) <= 2 * abs(emul['losses'][k].item() - t.item()) + 2e-3 * max(1.0, abs(t.item())), (k, h16['losses'][k].item(), emul['losses'][k].item(), t.item())
 
 
 def test_config2_production_size_eval_vs_oracle(env):

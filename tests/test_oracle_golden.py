@@ -136,3 +136,25 @@ def test_fast_hist_miou():
     assert h.sum() == 5 and h[0, 0] == 1 and h[0, 1] == 1 and h[1, 1] == 2 and h[2, 2] == 1
     m, iu = harness.miou(h)
     assert abs(iu[0] - 0.5) < 1e-12 and abs(iu[1] - 2 / 3) < 1e-12 and abs(iu[2] - 1) < 1e-12
+
+
+def test_bf16_storage_emulation_of_the_oracle_is_removable_and_rounds():
+    """oracle/bf16_emulation.py (the yardstick of tests/test_model_parity.py::test_bf16_tier_assembled_gradients_vs_fp64_oracle): inside the context every stored activation
+    is a bf16 value (so the eval logits move by ~2^-9 of their range, not more, not zero); after it the oracle computes exactly what it computed before."""
+    import torch
+    from oracle import bf16_emulation
+    from oracle.ref_cpu import deeplab
+    from pinthememory_amd import synth
+    crit = torch.nn.CrossEntropyLoss(reduction='mean', ignore_index=255)
+    net = synth.load_det_weights(deeplab.DeepR50V3PlusD(synth.model_args(), 19, crit, crit)).eval()
+    x, _ = synth.make_batch(1, 64)
+    with torch.no_grad():
+        want = net(x)[0]
+        with bf16_emulation.bf16_tier(net, deeplab):
+            got = net(x)[0]
+        again = net(x)[0]
+    assert torch.equal(want, again)
+    scale = (want.max() - want.min()).item()
+    err = (got - want).abs().max().item()
+    assert 1e-5 * scale < err < 2e-2 * scale, (err, scale)
+    assert deeplab.upsample.__name__ == 'upsample'
