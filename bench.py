@@ -196,7 +196,7 @@ def mldg(a):
         if os.environ.get('PM_PROFILE_DUMP'):
             K.profile_dump(os.environ['PM_PROFILE_DUMP'])
         fam = {}
-        for name, mode in (('forward-form kernel (fp32: forward + Winograd GEMMs; bf16: forward + stride-1 data gradients, register-staged)', 0), ('data-gradient-form kernel (fp32: direct data gradients; bf16: stride-2 only)', 1), ('weight gradients', 2), ('LDS-DMA bf16 convolutions (forward + stride-1 data gradients)', 4)):
+        for name, mode in (('forward-form kernel (fp32: forward + Winograd GEMMs; bf16: forward + stride-1 data gradients, register-staged)', 0), ('data-gradient-form kernel (fp32: direct data gradients; bf16: stride-2 only)', 1), ('weight gradients', 2), ('LDS-DMA bf16 convolutions (forward + stride-1 data gradients)', 4), ('LDS-DMA bf16 convolutions, wide 256 x 128 ring kernel', 5)):
             ms, fl, n = K.profile_read(mode=mode)
             if n:
                 fam[name] = {'ms_per_step': round(ms / 2, 3), 'launches_per_step': n / 2, 'achieved_TFLOPs': round(fl / (ms * 1e-3) / 1e12, 1)}
@@ -413,19 +413,23 @@ def dominant_conv_kernel(K, bf16):
     -> ((ms, flops, launches), symbol, description) or None. conv_igemm_kernel<mode, bm, bn, wm, wn, km, prec, nst> (csrc/conv_igemm.hip) and, on the bf16 tier,
     conv16_kernel<bm, bn, wm, wn, nst> (csrc/conv16.hip, recorded as mode 4 / prec 5)."""
     best = None
-    for mode in ((0, 1, 2) if not bf16 else (0, 1, 2, 4)):
-        for bm in (128, 64):
-            for bn in (128, 64, 32):
+    for mode in ((0, 1, 2) if not bf16 else (0, 1, 2, 4, 5)):
+        for bm in (256, 128, 64):
+            for bn in (256, 128, 64, 32):
                 for km in (0, 1, 2):
-                    for nst in (2, 1):
-                        for prec in ((0,) if not bf16 else ((5,) if mode == 4 else (2, 4, 3, 1))):
+                    for nst in (3, 2, 1):
+                        for prec in ((0,) if not bf16 else ((5,) if mode >= 4 else (2, 4, 3, 1))):
                             r = K.profile_read(mode=mode, bm=bm, bn=bn, km=km, nst=nst, prec=prec)
                             if r[2] and (best is None or r[0] > best[0][0]):
                                 best = (r, (mode, bm, bn, km, nst), prec)
     if best is None:
         return None
     r, (mode, bm, bn, km, nst), kprec = best
-    if mode == 4:
+    if mode == 5:
+        sym = 'conv16w_kernel<%d, %d, %s>' % (bm, bn, '4, 2' if bm == 256 else '2, 4')
+        what = ('forward / stride-1 data gradient on bf16 activations, wide form: %dx%dx64 tile, eight waves, one block per CU, three-stage LDS ring with counted waits, %s; '
+                'FLOPs = 2*M*N*K executed' % (bm, bn, PREC_NAMES[5]))
+    elif mode == 4:
         sym = 'conv16_kernel<%d, %d, 2, 2, %d>' % (bm, bn, nst)
         what = 'forward / stride-1 data gradient on bf16 activations, %dx%dx64 tile, %s, %s; FLOPs = 2*M*N*K executed' % (
             bm, bn, 'two LDS stages' if nst == 2 else 'one LDS stage (single-K-step reductions)', PREC_NAMES[5])

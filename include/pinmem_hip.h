@@ -125,6 +125,15 @@ int pm_conv_bwd_data(const pm_tensor* dy, const float* w_krsc, const pm_tensor* 
 int pm_conv_bwd_weight(const pm_tensor* x, const pm_tensor* dy, float* dw_krsc, float* dbias, const pm_conv_params* p,
                        void* ws, size_t ws_bytes, void* stream);
 
+/* ---- PROCESS-GLOBAL DEBUG / A-B SWITCHES (the only mutable global state of the library; SURVEY 8(b) "no global mutable state" holds for everything else) ----------
+ * pm_set_winograd, pm_set_winograd_fused, pm_set_conv16, pm_set_bf16_wgrad and pm_profile_enable flip process-wide ROUTING / MEASUREMENT switches. They exist for
+ * same-box A/B runs, kernel tests that must reach a specific kernel, and bench.py's roofline leg; they never change WHAT is computed (every route is parity-tested
+ * against the same oracle), only which kernel computes it or whether launches are timed. Contract: call them from ONE thread while no other thread is inside a
+ * pm_conv_* entry point (the switches are plain ints read at plan time: a concurrent flip is a benign race between two valid routes for an in-flight PLAN, but the
+ * workspace size a caller asked for with the old setting may not fit the new route -> PM_EWORKSPACE, never a wrong result); size queries (pm_conv_workspace,
+ * pm_conv_wxf_bytes, ...) must be repeated after a flip (pinthememory_amd/hip/kernels.py keys its size cache on a generation counter for that).
+ * A production caller leaves all of them at their defaults and the library is then re-entrant with an immutable kernel table, as the boundary contract says. ------- */
+
 /* Wide stride-1 3x3 convolutions with pad == dilation (Resnet.py:195 conv2 of layer2/3/4, deepv3plus.py:72-81 ASPP branches,
  * :398-404 final1, :455 dsn) run as Winograd convolutions in fp32: F(4x4,3x3) (4x fewer MFMA FLOPs) where the image tiles by
  * 4*dilation, else F(2x2,3x3) (2.25x fewer), else direct. Results stay within fp32 rounding of an fp64 convolution (max error
@@ -137,7 +146,9 @@ int pm_set_winograd(int mode);
 int pm_set_winograd_fused(int on);
 /* bf16 tier, forward and stride-1 data gradient: which kernel takes a call. 1 (default) = per shape: the LDS-DMA kernel (csrc/conv16.hip: global_load_lds
  * staging, swizzled LDS image) on 64-row tiles and single-K-step reductions, the register-staged kernel of rounds 2-3 on 128 x 128 tiles; 2 = LDS-DMA everywhere;
- * 0 = register-staged everywhere (A/B runs and tests). Process-wide like pm_set_winograd. */
+ * 0 = register-staged everywhere (A/B runs and tests). Round 5: the wide form of the LDS-DMA kernel (csrc/conv16w.hip: 256 x 128 / 128 x 256 tile, eight waves, one block
+ * per CU, three-stage LDS ring with counted waits) is part of "per shape" (the planner's cost model decides); 2 = LDS-DMA everywhere on the NARROW tiles only,
+ * 3 = LDS-DMA everywhere with the wide tile wherever the shape allows it (kernel tests), 4 = per shape without the wide kernel (A/B). Process-wide like pm_set_winograd. */
 int pm_set_conv16(int on);
 /* prec = 2 weight gradients on pixel-contiguous bf16 copies of x (one per tap) and dy instead of the staged-fp32 form: 0 off (default: the
  * copies cost more HBM time than the GEMM saves), 1 on. Process-wide like pm_set_winograd. */

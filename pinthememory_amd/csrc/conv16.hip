@@ -93,6 +93,40 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const pm_conv16 a) {
   s_tap = __builtin_amdgcn_readfirstlane(s_tap), s_ch = __builtin_amdgcn_readfirstlane(s_ch);
   s_ky = __builtin_amdgcn_readfirstlane(s_ky), s_kx = __builtin_amdgcn_readfirstlane(s_kx);
   int s_kb = kt0 * BKB;      // byte offset of the K-step inside a weight row (scalar offset of the B fetches)
+  // Taps no row of this tile can see (round 5): a tile of BM output pixels covers image rows oy_a ... oy_b of ONE image (else: no skipping); a filter row ky whose
+  // input rows oy * stride - pad + ky * dil lie outside the image for all of them contributes zeros only -- its K-steps are neither staged nor multiplied. On the
+  // 48 x 48 maps the dilated ASPP branches (rates 6 / 12 / 18, deepv3plus.py:58-81) lose 8 / 17 / 25 % of their K-steps this way, nothing else is affected.
+  unsigned ky_ok = ~0u;
+  if (!pointwise && a.kh > 1) {
+    const int hw = a.Ho * a.Wo, ml = min(m0 + BM, a.M) - 1;
+    const int ia = m0 / hw, ib = ml / hw;
+    if (ia == ib) {
+      const int oy_a = (m0 - ia * hw) / a.Wo, oy_b = (ml - ib * hw) / a.Wo;
+      ky_ok = 0;
+      for (int ky = 0; ky < a.kh; ++ky)
+        if (oy_b * a.stride - a.pad + ky * a.dil >= 0 && oy_a * a.stride - a.pad + ky * a.dil < a.H) ky_ok |= 1u << ky;
+    }
+  }
+  ky_ok = __builtin_amdgcn_readfirstlane(ky_ok);
+  int nk_eff = nk;      // K-steps this block really runs: its range [kt0, kt0 + nk) minus the chunks of invisible taps
+  if (ky_ok != ~0u) {
+    nk_eff = 0;
+    for (int kt = kt0; kt < kt0 + nk;) {
+      const int tap = kt / cpc, run = min(kt0 + nk, (tap + 1) * cpc) - kt;
+      if ((ky_ok >> (tap / a.kw)) & 1u) nk_eff += run;
+      kt += run;
+    }
+    nk_eff = __builtin_amdgcn_readfirstlane(nk_eff);
+  }
+  auto skip_taps = [&]() {      // move the K-state past invisible taps (whole taps: the state sits at a tap start, or at the block's first K-step)
+    while (s_ky < a.kh && !((ky_ok >> s_ky) & 1u)) {
+      s_kb += (cpc - s_ch) * BKB;
+      s_ch = 0;
+      ++s_tap;
+      if (++s_kx == a.kw) s_kx = 0, ++s_ky;
+    }
+  };
+  if (ky_ok != ~0u) skip_taps();
 
   auto stage = [&](int buf) {
     char* la = lds + buf * STAGE;
@@ -113,6 +147,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const pm_conv16 a) {
       s_ch = 0;
       ++s_tap;
       if (++s_kx == a.kw) s_kx = 0, ++s_ky;
+      if (ky_ok != ~0u) skip_taps();
     }
   };
 
@@ -148,21 +183,21 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const pm_conv16 a) {
     }
   };
 
-  if (nk > 0) {
+  if (nk_eff > 0) {
     stage(0);
     __syncthreads();
     if constexpr (NST == 1) {
-      for (int kt = 0; kt < nk; ++kt) {
+      for (int kt = 0; kt < nk_eff; ++kt) {
         compute(0);
-        if (kt + 1 < nk) {
+        if (kt + 1 < nk_eff) {
           __syncthreads();      // every wave is done reading the single buffer
           stage(0);
           __syncthreads();
         }
       }
     } else {
-      for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) stage((kt + 1) & 1);
+      for (int kt = 0; kt < nk_eff; ++kt) {
+        if (kt + 1 < nk_eff) stage((kt + 1) & 1);
         compute(kt & 1);
         __syncthreads();
       }
@@ -279,9 +314,47 @@ void launch_tile(const pm_conv16& k, dim3 grid, hipStream_t st) {
 
 // Tile / split choice. Rows in tiles of 128 (64 when that fills the 256 CUs better on the 48 x 48 maps), columns in tiles of 128 (64 for <= 64 output
 // channels); split-K (fp32 slabs, fixed-order reduce by the caller) only where the output tiles alone leave most CUs idle AND the reduction is long.
+// Round 5: the WIDE kernel (conv16w.hip: 256 x 128 / 128 x 256 tile, eight waves, ONE block per CU, three-stage ring) where a cost model of whole rounds of the 256 CUs
+// says it wins: its K-step costs ~1.45 x a 64 x 128 step of the narrow kernel for 4 x the tile, but a partly filled last round costs a whole round, so the model picks
+// the K-split that balances the tiles against the CUs. PM_C16W: 0 never, 1 by the model (default), 2 wherever the shape allows it (A/B runs, kernel tests).
+int g_c16w = getenv("PM_C16W") ? atoi(getenv("PM_C16W")) : 1;
+namespace {
+struct WidePick {
+  bool ok;
+  int bm, bn, ks;
+  double cost;      // in units of one wide K-step on a full chip
+};
+WidePick wide_pick(const pm_conv16* k) {
+  static const int force_ks = getenv("PM_C16W_KS") ? atoi(getenv("PM_C16W_KS")) : 0;
+  static const double ovh = getenv("PM_C16W_OVH") ? atof(getenv("PM_C16W_OVH")) : 10.0;      // prologue + epilogue of a block, in K-steps
+  WidePick best{false, 0, 0, 0, 1e30};
+  const bool forced = g_c16w >= 2;      // kernel tests: every shape the kernel can express, ragged rows / columns and single K-steps included
+  if (!forced && (k->Nn < 128 || k->M < 2048 || k->ksteps < 4)) return best;
+  for (int cfg = 0; cfg < 2; ++cfg) {
+    const int bm = cfg == 0 ? 256 : 128, bn = cfg == 0 ? 128 : 256;
+    if (bn > 128 && k->Nn < 256 && !(forced && cfg == 1 && k->Nn > 128)) continue;
+    const long tiles = (long)pm_cdiv(k->M, bm) * pm_cdiv(k->Nn, bn);
+    const double fill = ((double)k->M * k->Nn) / ((double)tiles * bm * bn);      // padded rows / columns are wasted work
+    for (int ks = 1; ks <= 16; ++ks) {
+      if (force_ks && ks != force_ks) continue;
+      if (ks > 1 && k->ksteps / ks < (forced ? 2 : 8)) break;
+      const int per = pm_cdiv(k->ksteps, ks);
+      const int kse = pm_cdiv(k->ksteps, per);
+      const long blocks = tiles * kse;
+      const long rounds = (blocks + 255) / 256;
+      // split-K slabs: fp32 partial tiles written and read back by the reduce (bytes / ~4 TB/s, in wide K-steps of ~1.1 us measured on this kernel)
+      const double slab = kse > 1 ? (double)kse * k->M * k->Nn * 8.0 / 4e12 / 1.1e-6 : 0.0;
+      const double cost = (double)rounds * (per + ovh) / fill * (cfg == 1 ? 1.03 : 1.0) + slab;
+      if (cost < best.cost) best = WidePick{true, bm, bn, kse, cost};
+    }
+  }
+  return best;
+}
+}  // namespace
 void pm_conv16_plan(pm_conv16* k) {
   static const int force_bm = getenv("PM_C16_BM") ? atoi(getenv("PM_C16_BM")) : 0;
   static const int force_ks = getenv("PM_C16_KS") ? atoi(getenv("PM_C16_KS")) : 0;
+  k->wide = 0;
   k->bn = k->Nn > 64 ? 128 : 64;
   k->tiles_n = pm_cdiv(k->Nn, k->bn);
   const long t128 = (long)pm_cdiv(k->M, 128) * k->tiles_n, t64 = (long)pm_cdiv(k->M, 64) * k->tiles_n;
@@ -297,14 +370,67 @@ void pm_conv16_plan(pm_conv16* k) {
   k->ksteps_per = pm_cdiv(k->ksteps, ks);
   k->ksplit = pm_cdiv(k->ksteps, k->ksteps_per);
   k->c_split = (long)k->M * k->Nn;
+  // Round 5, measured and left OFF (PM_C16_FULLN=1 | 2 enables it for A/B runs): a 64 x 256 "full-N" tile for the HBM-bound 1x1 convolutions with a short reduction and a
+  // wide output (64 -> 256 on the 192 x 192 maps, 128 -> 512 on 96 x 96, 256 -> 1024 on 48 x 48), so that the activation rows are fetched once per 256 output channels.
+  // tools/conv16_probe.py, same box, alternated: 64 -> 256 253-260 -> 243-252 TF, 128 -> 512 288-297 -> 259-260, 256 -> 1024 360-369 -> 343-347: the second fetch of
+  // the rows comes from L2 and was never the bound -- standalone the 64 -> 256 launch already moves its 189 MB in 37 us (5.1 TB/s: the output write), and the wider
+  // tile only takes resident blocks away (80 KB of LDS stages per block instead of 48). The in-step figure of that shape (60 us) is not a tiling problem.
+  static const int fulln = getenv("PM_C16_FULLN") ? atoi(getenv("PM_C16_FULLN")) : 0;
+  if (!force_bm && k->Nn >= 256 && k->Nn % 256 == 0 && ((fulln == 1 && k->ksteps <= 4 && k->kh * k->kw == 1) || fulln >= 2) && ks == 1) {
+    k->bm = 64, k->bn = 256;
+    k->tiles_m = pm_cdiv(k->M, 64), k->tiles_n = k->Nn / 256;
+    k->ksteps_per = k->ksteps, k->ksplit = 1;
+  }
+  if (g_c16w > 0) {
+    const WidePick w = wide_pick(k);
+    // Where the wide tile wins (tools/conv16_probe.py on an MI355X, round 5, profiles/r05_conv16w_probe.txt): the very wide outputs of a medium reduction (3x3
+    // 256 -> 2048 data-gradient form on the 48 x 48 maps, 4.5 rounds of tiles: 697-701 -> 754-769 TF). On the deep ASPP reduction (2048 -> 256, 288 K-steps) it was
+    // ahead of the narrow tile (690 -> 736 TF at K-split 3) until the narrow kernel learned to skip invisible filter rows (764 TF: its 64-row tiles see whole filter
+    // rows fall outside the image where a 256-row tile does not); everywhere else the 1.125-round tile counts of the 48 x 48 maps (288 tiles of 256 x 128 on 256 CUs)
+    // cost more than the tile's 2 x FLOP per staged byte buys, and on the 192 x 192 maps it is level with the 128 x 128 register-staged kernel (877 vs 847-891 TF).
+    const bool wins = k->Nn >= 2048 && k->ksteps >= 32;
+    if (w.ok && (g_c16w >= 2 || wins)) {
+      k->wide = 1, k->bm = w.bm, k->bn = w.bn;
+      k->tiles_m = pm_cdiv(k->M, k->bm), k->tiles_n = pm_cdiv(k->Nn, k->bn);
+      k->ksteps_per = pm_cdiv(k->ksteps, w.ks);
+      k->ksplit = pm_cdiv(k->ksteps, k->ksteps_per);
+    }
+  }
 }
+// Fraction of the K-steps the launch really runs: 1 minus the chunks of filter rows no row of a tile can see (the kernels' ky_ok rule, evaluated per row tile on the
+// host). The in-library profile records EXECUTED FLOPs with it, so that a roofline fraction never counts multiplications that were skipped (round 5).
+double pm_conv16_executed_fraction(const pm_conv16* k) {
+  const bool pointwise = k->kh * k->kw == 1 && k->stride == 1 && k->pad == 0 && k->Ho == k->H && k->Wo == k->W;
+  if (pointwise || k->kh <= 1) return 1.0;
+  const long hw = (long)k->Ho * k->Wo;
+  double run = 0.0;
+  for (int tm = 0; tm < k->tiles_m; ++tm) {
+    const long m0 = (long)tm * k->bm, ml = std::min<long>(m0 + k->bm, k->M) - 1;
+    const long ia = m0 / hw, ib = ml / hw;
+    int vis = k->kh;
+    if (ia == ib) {
+      const int oy_a = (int)((m0 - ia * hw) / k->Wo), oy_b = (int)((ml - ib * hw) / k->Wo);
+      vis = 0;
+      for (int ky = 0; ky < k->kh; ++ky)
+        if (oy_b * k->stride - k->pad + ky * k->dil >= 0 && oy_a * k->stride - k->pad + ky * k->dil < k->H) ++vis;
+    }
+    run += (double)vis / k->kh;
+  }
+  return k->tiles_m > 0 ? run / k->tiles_m : 1.0;
+}
+
 size_t pm_conv16_slab_bytes(const pm_conv16* k) { return k->ksplit > 1 ? pm_align_up((size_t)k->ksplit * k->M * k->Nn * sizeof(float), 256) : 0; }
 
 int pm_conv16_launch(const pm_conv16* k0, hipStream_t st) {
+  if (k0->wide) {
+    PM_REQUIRE(!k0->stats, PM_EUNSUPPORTED, "conv16w: no statistics epilogue (pm_conv_bn_partials_bytes answers 0 for this plan)");
+    return pm_conv16w_launch(k0, st);
+  }
   pm_conv16 k = *k0;
   dim3 grid(k.tiles_m * k.tiles_n, 1, k.ksplit);
   const bool one = k.ksteps_per == 1;      // a single K-step per block: one LDS stage, four blocks per CU
-  if (k.bm == 128 && k.bn == 128) one ? launch_tile<128, 128, 2, 2, 1>(k, grid, st) : launch_tile<128, 128, 2, 2, 2>(k, grid, st);
+  if (k.bm == 64 && k.bn == 256) one ? launch_tile<64, 256, 1, 4, 1>(k, grid, st) : launch_tile<64, 256, 1, 4, 2>(k, grid, st);      // full-N tile of the short 1x1 reductions
+  else if (k.bm == 128 && k.bn == 128) one ? launch_tile<128, 128, 2, 2, 1>(k, grid, st) : launch_tile<128, 128, 2, 2, 2>(k, grid, st);
   else if (k.bm == 64 && k.bn == 128) one ? launch_tile<64, 128, 2, 2, 1>(k, grid, st) : launch_tile<64, 128, 2, 2, 2>(k, grid, st);
   else if (k.bm == 128 && k.bn == 64) one ? launch_tile<128, 64, 2, 2, 1>(k, grid, st) : launch_tile<128, 64, 2, 2, 2>(k, grid, st);
   else if (k.bm == 64 && k.bn == 64) one ? launch_tile<64, 64, 2, 2, 1>(k, grid, st) : launch_tile<64, 64, 2, 2, 2>(k, grid, st);

@@ -1,0 +1,321 @@
+// BASELINE configs[2], round 5: the WIDE form of the LDS-DMA bf16 implicit-GEMM convolution (conv16.hip) -- one 256 x 128 (or 128 x 256) output tile per CU, eight
+// waves, a three-stage LDS ring filled by LDS-DMA with COUNTED waits (s_waitcnt vmcnt(N) + a bare s_barrier: the fetches of K-step k + 2 and k + 1 stay in flight while
+// K-step k is multiplied), one barrier per K-step.
+// Why: the 64 x 128 / 128 x 128 tiles of conv16.hip move 43 / 64 FLOP per byte staged from L2 into LDS; on the 48 x 48 maps (M = 18 432 rows: layer3 / layer4 / ASPP) that
+// holds them at 0.24-0.30 of the bf16 MFMA peak -- 16 TB/s of L2 -> LDS traffic at 700 TFLOP/s, LDS reads of 1.5 KB per MFMA for a 32 x 64 wave tile (DESIGN section 7
+// "Round 5"). This tile stages 85 FLOP per byte and reads 1 KB of LDS per MFMA (64 x 64 wave tiles). With ONE resident block per CU the latency hiding that conv16.hip
+// gets from three co-resident blocks has to come from the block's own pipeline: hence the ring. With one block per CU the tile count also has to be balanced against the
+// 256 CUs by the planner (split-K, conv16.hip pm_conv16_plan).
+// Same operands, same addressing (buffer descriptors, out-of-range offsets deliver zeros, source-side XOR swizzle), same epilogues as conv16.hip.
+// Replaces nn.Conv2d forward / input gradient of Resnet.py:145-150,195; deepv3plus.py:72-81 on the bf16 tier where the planner picks it.
+#include <stdlib.h>
+#include <algorithm>
+
+#include "pm_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int BKB = 128;      // bytes per row and K-step (64 bf16)
+constexpr int NT = 512;       // threads per block: eight waves
+constexpr int NST = 3;        // LDS ring depth
+
+__device__ __forceinline__ int xcd_remap_w(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+__device__ __forceinline__ void dma16w(__amdgpu_buffer_rsrc_t r, char* dst, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, voff, soff, 0, 0);
+}
+
+// s_waitcnt vmcnt(n) only (expcnt / lgkmcnt untouched): gfx9 encoding vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14]
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(NT, 2) void conv16w_kernel(const pm_conv16 a) {
+  static_assert(WM * WN == 8, "eight waves");
+  constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;      // 16-byte fetches per lane and K-step: a 512-thread sweep covers 64 rows x 8 chunks
+  constexpr int FETCH = A_IT + B_IT;                         // LDS-DMA instructions one wave issues per stage
+  constexpr int A_BYTES = BM * BKB, STAGE = (BM + BN) * BKB;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  static_assert(TM >= 1 && TN >= 1 && A_IT >= 1 && B_IT >= 1, "bad tile config");
+  extern __shared__ __align__(16) char lds[];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, half = lane >> 5;
+  const int lid = xcd_remap_w(blockIdx.x, a.tiles_m * a.tiles_n);
+  const int m0 = (lid / a.tiles_n) * BM, n0 = (lid % a.tiles_n) * BN;
+  const int z = blockIdx.z;
+  const int kt0 = z * a.ksteps_per, nk = min(a.ksteps - kt0, a.ksteps_per);
+  const long pitchb = a.a_pitch * 2;
+
+  const __amdgpu_buffer_rsrc_t rA =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<pm_bf16*>(a.A), 0, (int)((long)a.N * a.H * a.W * pitchb), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<pm_bf16*>(a.B), 0, (int)((long)a.Nn * a.K * 2), 0x00020000);
+  constexpr int OOB = 0x7fffffff;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  int aoff[A_IT], ay0[A_IT], ax0[A_IT];
+  const bool pointwise = a.kh * a.kw == 1 && a.stride == 1 && a.pad == 0 && a.Ho == a.H && a.Wo == a.W;
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    const int u = it * NT + t, row = u >> 3, ch = (u & 7) ^ ((row >> 1) & 7);
+    const int m = m0 + row;
+    if (m < a.M && pointwise) {
+      ay0[it] = ax0[it] = 0;
+      aoff[it] = (int)((long)m * pitchb) + ch * 16;
+    } else if (m < a.M) {
+      const int img = m / (a.Ho * a.Wo), rem = m - img * (a.Ho * a.Wo);
+      const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+      ay0[it] = oy * a.stride - a.pad, ax0[it] = ox * a.stride - a.pad;
+      aoff[it] = (int)(((long)(img * a.H + ay0[it]) * a.W + ax0[it]) * pitchb) + ch * 16;
+    } else {
+      ay0[it] = ax0[it] = -(1 << 28);
+      aoff[it] = 0;
+    }
+  }
+  int boff[B_IT];
+#pragma unroll
+  for (int it = 0; it < B_IT; ++it) {
+    const int u = it * NT + t, row = u >> 3, ch = (u & 7) ^ ((row >> 1) & 7);
+    const int n = n0 + row;
+    boff[it] = n < a.Nn ? n * a.K * 2 + ch * 16 : OOB;
+  }
+  const int cpc = a.Cp >> 6;
+  int s_tap = kt0 / cpc, s_ch = kt0 - s_tap * cpc, s_ky = s_tap / a.kw, s_kx = s_tap - s_ky * a.kw;
+  s_tap = __builtin_amdgcn_readfirstlane(s_tap), s_ch = __builtin_amdgcn_readfirstlane(s_ch);
+  s_ky = __builtin_amdgcn_readfirstlane(s_ky), s_kx = __builtin_amdgcn_readfirstlane(s_kx);
+  int s_kb = kt0 * BKB;
+  // taps no row of this tile can see are neither staged nor multiplied (conv16.hip: the dilated ASPP branches on the 48 x 48 maps)
+  unsigned ky_ok = ~0u;
+  if (!pointwise && a.kh > 1) {
+    const int hw = a.Ho * a.Wo, ml = min(m0 + BM, a.M) - 1;
+    const int ia = m0 / hw, ib = ml / hw;
+    if (ia == ib) {
+      const int oy_a = (m0 - ia * hw) / a.Wo, oy_b = (ml - ib * hw) / a.Wo;
+      ky_ok = 0;
+      for (int ky = 0; ky < a.kh; ++ky)
+        if (oy_b * a.stride - a.pad + ky * a.dil >= 0 && oy_a * a.stride - a.pad + ky * a.dil < a.H) ky_ok |= 1u << ky;
+    }
+  }
+  ky_ok = __builtin_amdgcn_readfirstlane(ky_ok);
+  int nk_eff = nk;
+  if (ky_ok != ~0u) {
+    nk_eff = 0;
+    for (int kt = kt0; kt < kt0 + nk;) {
+      const int tap = kt / cpc, run = min(kt0 + nk, (tap + 1) * cpc) - kt;
+      if ((ky_ok >> (tap / a.kw)) & 1u) nk_eff += run;
+      kt += run;
+    }
+    nk_eff = __builtin_amdgcn_readfirstlane(nk_eff);
+  }
+  auto skip_taps = [&]() {
+    while (s_ky < a.kh && !((ky_ok >> s_ky) & 1u)) {
+      s_kb += (cpc - s_ch) * BKB;
+      s_ch = 0;
+      ++s_tap;
+      if (++s_kx == a.kw) s_kx = 0, ++s_ky;
+    }
+  };
+  if (ky_ok != ~0u) skip_taps();
+
+  auto stage = [&](int buf) {
+    char* la = lds + buf * STAGE;
+    char* lb = la + A_BYTES;
+    const int dy = s_ky * a.dil, dx = s_kx * a.dil;
+    const int toff = (dy * a.W + dx) * (int)pitchb + s_ch * BKB;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const bool ok = ((unsigned)(ay0[it] + dy) < (unsigned)a.H) & ((unsigned)(ax0[it] + dx) < (unsigned)a.W);
+      dma16w(rA, la + (it * NT + wave_u * 64) * 16, ok ? aoff[it] + toff : OOB, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) dma16w(rB, lb + (it * NT + wave_u * 64) * 16, boff[it], s_kb);
+    s_kb += BKB;
+    if (++s_ch == cpc) {
+      s_ch = 0;
+      ++s_tap;
+      if (++s_kx == a.kw) s_kx = 0, ++s_ky;
+      if (ky_ok != ~0u) skip_taps();
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  // this lane's fragment rows and their swizzle keys are K-step invariant: byte offsets inside a stage, one per 16-k group through the XOR
+  int ra_off[TM], ra_key[TM], rb_off[TN], rb_key[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int ra = wm * (BM / WM) + i * 32 + l31;
+    ra_off[i] = ra * BKB, ra_key[i] = (ra >> 1) & 7;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int rb = wn * (BN / WN) + j * 32 + l31;
+    rb_off[j] = A_BYTES + rb * BKB, rb_key[j] = (rb >> 1) & 7;
+  }
+
+  auto compute = [&](int buf) {
+    const char* ls = lds + buf * STAGE;
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      const int c = kg * 2 + half;
+      bf16x8 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(ls + ra_off[i] + ((c ^ ra_key[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(ls + rb_off[j] + ((c ^ rb_key[j]) << 4));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // ---- the ring: stage k + 2 is issued behind the barrier of step k (its buffer was last read in step k - 1, which every wave has left); the wait in front of the
+  // barrier leaves the FETCH instructions of stage k + 1 in flight (LDS-DMA fetches of a wave retire in order), so "my part of stage k has landed" + barrier = "stage k
+  // has landed". No __syncthreads(): its fence would drain the DMA queue (vmcnt(0)) at every K-step.
+  if (nk_eff > 0) {
+    stage(0);
+    if (nk_eff > 1) stage(1);
+    int cur = 0, nxt = 2;
+    for (int kt = 0; kt < nk_eff; ++kt) {
+      if (kt + 1 < nk_eff) wait_vm<FETCH>();
+      else wait_vm<0>();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 2 < nk_eff) stage(nxt);
+      compute(cur);
+      cur = cur == NST - 1 ? 0 : cur + 1;
+      nxt = nxt == NST - 1 ? 0 : nxt + 1;
+    }
+  }
+
+  // ---- epilogue: as conv16.hip -- a wave parks 32 rows of its tile in LDS (the ring is dead) and stores whole row segments ----------------------------------
+  constexpr int WC = BN / WN, LDC = WC + 4;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  float* Ws = reinterpret_cast<float*>(lds) + wave * 32 * LDC;
+  const bool slab = a.ksplit > 1;
+  if (a.c_f32 || slab) {
+    float* Cf = reinterpret_cast<float*>(a.C) + (slab ? (long)z * a.c_split : 0);
+    const long cp = slab ? a.Nn : a.c_pitch;
+    constexpr int LPR = WC / 4, RPI = 64 / LPR;
+    const int rr0 = lane / LPR, cc = (lane % LPR) * 4;
+    const int col = n0 + wn * WC + cc;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Ws[((q & 3) + 8 * (q >> 2) + 4 * half) * LDC + n * 32 + l31] = acc[i][n][q];
+#pragma unroll
+      for (int r0 = 0; r0 < 32; r0 += RPI) {
+        const int rr = r0 + rr0;
+        const long row = m0 + wm * (BM / WM) + i * 32 + rr;
+        const float4 v = *reinterpret_cast<const float4*>(Ws + rr * LDC + cc);
+        if (row >= a.M) continue;
+        const float e[4] = {v.x, v.y, v.z, v.w};
+        if (((cp | a.Nn) & 3) == 0 && col + 4 <= a.Nn && !a.bias) PM_ST4(Cf + row * cp + col, v);
+        else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (col + k < a.Nn) Cf[row * cp + col + k] = e[k] + ((a.bias && !slab) ? a.bias[col + k] : 0.f);
+        }
+      }
+    }
+    return;
+  }
+  {
+    constexpr int LPR = WC / 8, RPI = 64 / LPR;
+    static_assert(32 % RPI == 0, "row segments must tile the 32-row slab");
+    const int rr0 = lane / LPR, cc = (lane % LPR) * 8;
+    const int col = n0 + wn * WC + cc;
+    const bool cok = col < a.Nn;
+    const bool aff = a.bias || a.scale, res = a.residual != nullptr, relu = a.relu != 0;
+    float bi[8], sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bi[e] = 0.f, sc[e] = 1.f, sh[e] = 0.f;
+    if (aff && cok) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (a.bias) bi[e] = a.bias[col + e];
+        if (a.scale) sc[e] = a.scale[col + e], sh[e] = a.shift[col + e];
+      }
+    }
+    pm_bf16* C16 = reinterpret_cast<pm_bf16*>(a.C);
+    const pm_bf16* R16 = reinterpret_cast<const pm_bf16*>(a.residual);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Ws[((q & 3) + 8 * (q >> 2) + 4 * half) * LDC + n * 32 + l31] = acc[i][n][q];
+#pragma unroll
+      for (int r0 = 0; r0 < 32; r0 += RPI) {
+        const int rr = r0 + rr0;
+        const long row = m0 + wm * (BM / WM) + i * 32 + rr;
+        const float4 v0 = *reinterpret_cast<const float4*>(Ws + rr * LDC + cc), v1 = *reinterpret_cast<const float4*>(Ws + rr * LDC + cc + 4);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        if (row < a.M && cok) {
+          if (aff) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (v[e] + bi[e]) * sc[e] + sh[e];
+          }
+          if (res) {
+            float q[8];
+            pm_ld8(R16 + row * a.res_pitch + col, q);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += q[e];
+          }
+          if (relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          pm_st8(C16 + row * a.c_pitch + col, v);
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+void launch_wide(const pm_conv16& k, dim3 grid, hipStream_t st) {
+  constexpr size_t stage_bytes = (size_t)NST * (BM + BN) * BKB, ep_bytes = (size_t)8 * 32 * (BN / WN + 4) * sizeof(float);
+  constexpr size_t smem = stage_bytes > ep_bytes ? stage_bytes : ep_bytes;
+  static_assert(smem <= 160 * 1024, "LDS budget");
+  static const bool attr_set = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv16w_kernel<BM, BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return true;
+  }();
+  (void)attr_set;
+  hipLaunchKernelGGL((conv16w_kernel<BM, BN, WM, WN>), grid, dim3(NT), smem, st, k);
+}
+
+}  // namespace
+
+int pm_conv16w_launch(const pm_conv16* k0, hipStream_t st) {
+  pm_conv16 k = *k0;
+  dim3 grid(k.tiles_m * k.tiles_n, 1, k.ksplit);
+  if (k.bm == 256 && k.bn == 128) launch_wide<256, 128, 4, 2>(k, grid, st);
+  else if (k.bm == 128 && k.bn == 256) launch_wide<128, 256, 2, 4>(k, grid, st);
+  else {
+    pm_set_error("conv16w: no %d x %d tile", k.bm, k.bn);
+    return PM_EUNSUPPORTED;
+  }
+  return pm_check_launch("conv16w");
+}

@@ -1489,7 +1489,7 @@ Bf16Plan bf16_plan(const pm_tensor* xin, const pm_tensor* yout, const pm_conv_pa
     // decoder's 3x3): those stay there. PM_CONV16=2 forces the LDS-DMA kernel everywhere.
     // (second form of the kernel, buffer-descriptor fetches: it also takes the long reductions the register-staged planner would run on 64-row tiles -- the
     //  3x3 512 -> 1024-wide data gradients at 48 x 48: 596 -> 877 TF on 128 x 128 -- while the short 1x1 reductions stay with the single-stage register-staged form)
-    b.c16 = c16_on == 2 || k.bm == 64 || k.ksteps_per == 1 || (b.pl.bm == 64 && k.ksteps >= 16);
+    b.c16 = c16_on == 2 || k.wide || k.bm == 64 || k.ksteps_per == 1 || (b.pl.bm == 64 && k.ksteps >= 16);
   }
   return b;
 }
@@ -1524,11 +1524,12 @@ int conv_bf16(const pm_tensor* xin, const float* w, int w_cout, int w_cin, bool 
     if (ok) {
       pm_conv16 k = b.k16;
       k.A = (const pm_bf16*)xb, k.B = (const pm_bf16*)wb;
-      const double fl = 2.0 * (double)b.M * (double)b.Nn * (double)T * (double)xin->c;
+      // EXECUTED FLOPs: the K-steps of filter rows that no row of a tile can see are skipped by the kernel (dilated ASPP branches) and are not counted
+      const double fl = 2.0 * (double)b.M * (double)b.Nn * (double)T * (double)xin->c * (g_prof_on ? pm_conv16_executed_fraction(&k) : 1.0);
       ProfRec rec;
       if (g_prof_on) {
         (void)hipEventCreate(&rec.a), (void)hipEventCreate(&rec.b);
-        rec.mode = 4, rec.bm = k.bm, rec.bn = k.bn, rec.km = 0, rec.prec = 5, rec.nst = k.ksteps_per == 1 ? 1 : 2, rec.M = k.M, rec.Nn = k.Nn, rec.K = k.K / 2, rec.batch = 1,
+        rec.mode = k.wide ? 5 : 4, rec.bm = k.bm, rec.bn = k.bn, rec.km = 0, rec.prec = 5, rec.nst = k.wide ? 3 : (k.ksteps_per == 1 ? 1 : 2), rec.M = k.M, rec.Nn = k.Nn, rec.K = k.K / 2, rec.batch = 1,
         rec.ksplit = k.ksplit, rec.flops = fl;
         (void)hipEventRecord(rec.a, st);
       }
@@ -1745,9 +1746,13 @@ extern "C" int pm_set_winograd(int mode) {
   g_wino_mode = mode;
   return PM_OK;
 }
+extern int g_c16w;      // conv16.hip: 0 never the wide (conv16w.hip) kernel, 1 by the planner's cost model, 2 wherever the shape allows it
 extern "C" int pm_set_conv16(int on) {
-  PM_REQUIRE(on >= 0 && on <= 2, PM_EINVAL, "pm_set_conv16: %d (0 register-staged, 1 per shape, 2 LDS-DMA everywhere)", on);
-  g_conv16 = on;
+  PM_REQUIRE(on >= 0 && on <= 4, PM_EINVAL, "pm_set_conv16: %d (0 register-staged, 1 per shape, 2 LDS-DMA everywhere / narrow tiles only, 3 LDS-DMA everywhere / wide tiles "
+             "wherever the shape allows, 4 per shape without the wide kernel)", on);
+  static const int c16w_default = g_c16w;
+  g_conv16 = on == 3 ? 2 : (on == 4 ? 1 : on);
+  g_c16w = on == 3 ? 2 : ((on == 2 || on == 4) ? 0 : c16w_default);
   return PM_OK;
 }
 extern "C" int pm_set_winograd_fused(int on) {
@@ -1868,7 +1873,7 @@ static bool bn_partials_route(const pm_tensor* x, const pm_tensor* y, const pm_c
   if (pm_is_bf16(y)) {      // bf16 tier: both bf16 kernels carry the statistics in their 8-column staged epilogue (one K split, whole 16-byte groups)
     if (!pm_vec8(y)) return false;
     const Bf16Plan b = bf16_plan(x, y, p);
-    return b.use && (b.c16 ? b.k16.ksplit == 1 : b.pl.ksplit == 1);
+    return b.use && (b.c16 ? (b.k16.ksplit == 1 && !b.k16.wide) : b.pl.ksplit == 1);
   }
   if (pm_is_bf16(x)) return false;
   if ((y->c & 3) || (y->pitch & 3) || !pm_aligned16(y->ptr)) return false;

@@ -91,6 +91,11 @@ BN_EPILOGUE = os.environ.get('PM_BN_EPILOGUE', '0') == '1'
 # left in the 256 MB infinity cache (10 us per layer), while the epilogue form adds two LDS sweeps and 48 lane exchanges per slab to an MFMA-bound kernel and
 # hands the finalize 9 216 slab partials instead of <= 288 block partials. Opt-in (PM_BN_EPILOGUE16=1), covered by test_conv_epilogue_bn_statistics_bf16.
 BN_EPILOGUE16 = os.environ.get('PM_BN_EPILOGUE16', '0') == '1'
+# Round 5: per shape. Where the PRODUCING convolution is HBM-bound and its output does not stay in the 256 MB infinity cache -- the 1x1 convolutions onto the 192 x 192
+# and 96 x 96 maps, 75-151 MB of bf16 output -- the separate statistics pass is a full HBM read (28-54 us per layer) while the epilogue's extra LDS sweeps hide under
+# the convolution's own memory time. PM_BN_EP16_MIN_MB: outputs of at least this many MB take the epilogue route (0 = never).
+BN_EP16_MIN_BYTES = int(float(os.environ.get('PM_BN_EP16_MIN_MB', '0')) * (1 << 20))
+BN_EP_MIN_BYTES = int(float(os.environ.get('PM_BN_EP_MIN_MB', '0')) * (1 << 20))      # the same per-shape rule on the fp32 tier (outputs of at least this many MB)
 
 
 # Transformed filters -- the Winograd U = G w G^T, or the bf16 copy of the weights in the bf16 tier -- kept between calls: the eval-mode forward of
@@ -284,7 +289,9 @@ def conv_fwd(x, w_krsc, stride, pad, dil, bias=None, scale=None, shift=None, res
     ws = workspace(nb, x.device) if nb else None
     part = None
     if bn_partials is not None:
-        npb = npb if ((BN_EPILOGUE16 if y.dtype == torch.bfloat16 else BN_EPILOGUE) and residual is None and not relu and scale is None) else 0
+        ep16 = BN_EPILOGUE16 or (BN_EP16_MIN_BYTES > 0 and y.numel() * 2 >= BN_EP16_MIN_BYTES)
+        ep32 = BN_EPILOGUE or (BN_EP_MIN_BYTES > 0 and y.numel() * 4 >= BN_EP_MIN_BYTES)
+        npb = npb if ((ep16 if y.dtype == torch.bfloat16 else ep32) and residual is None and not relu and scale is None) else 0
         part = torch.empty(npb // 4, dtype=torch.float32, device=x.device) if npb else None
         bn_partials.append(part)
     ep = None

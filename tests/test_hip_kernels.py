@@ -899,7 +899,7 @@ ACT16_CASES = [CONV_CASES[0], CONV_CASES[1], CONV_CASES[3], CONV_CASES[4], CONV_
                (1, 512, 12, 12, 512, 3, 1, 2, 2, False)]
 
 
-@pytest.mark.parametrize('route', ['lds_dma', 'reg_staged'])
+@pytest.mark.parametrize('route', ['lds_dma', 'lds_dma_wide', 'reg_staged'])
 @pytest.mark.parametrize('case', ACT16_CASES)
 def test_conv_bf16_activations(K, case, route):
     """BASELINE configs[2], round 4: bf16 tensors in, bf16 tensors out (x, y, dy, dx), fp32 weights / dw, fp32 accumulation. Oracle: the fp32 convolution of
@@ -912,7 +912,8 @@ def test_conv_bf16_activations(K, case, route):
     dy = r16(rnd(*y_ref.shape, seed=4))
     skip = r16(rnd(n, cin, h, w, seed=5))
     K.set_conv_precision('bf16')
-    K.set_conv16(2 if route == 'lds_dma' else 0)      # csrc/conv16.hip on every shape, or the register-staged kernel on bf16 rows (default: per shape)
+    # csrc/conv16.hip on every shape (2: its narrow tiles, 3: the wide eight-wave ring kernel of conv16w.hip, round 5), or the register-staged kernel on bf16 rows
+    K.set_conv16({'lds_dma': 2, 'lds_dma_wide': 3}.get(route, 0))
     try:
         wg = wt.permute(0, 2, 3, 1).contiguous().cuda()
         xg = K.new((n, h, w, cin), wg, dtype=torch.bfloat16)      # zero-padded + registered when cin % 64 != 0 (304): gathered in place
@@ -944,7 +945,8 @@ def test_conv_bf16_activations(K, case, route):
         assert rel(db, b2.grad) < 2e-5
 
 
-@pytest.mark.parametrize('case', [(8, 512, 48, 48, 256, 3, 6, 6), (8, 1024, 48, 48, 512, 1, 0, 1), (8, 256, 47, 49, 256, 3, 1, 1), (5, 512, 48, 48, 19, 1, 0, 1)])
+@pytest.mark.parametrize('case', [(8, 512, 48, 48, 256, 3, 6, 6), (8, 1024, 48, 48, 512, 1, 0, 1), (8, 256, 47, 49, 256, 3, 1, 1), (5, 512, 48, 48, 19, 1, 0, 1),
+                                  (3, 128, 48, 48, 256, 3, 18, 18), (2, 192, 48, 40, 128, 3, 12, 12)])      # ASPP rates 18 / 12: whole filter rows invisible to the top / bottom tiles (skipped K-steps)
 def test_conv16_on_the_48x48_maps(K, case):
     """The LDS-DMA kernel at the shapes it carries in the step (bs=8: 18 432 rows, 576 ... 1 152 tiles of 64 x 128 on 256 CUs, a ragged last tile, the 19-column
     fp32 logits): forward with bias / folded scale-shift / residual / ReLU and the data gradient with its fused skip, each against the fp32 formula on the same
@@ -963,7 +965,7 @@ def test_conv16_on_the_48x48_maps(K, case):
     outs = {}
     try:
         wg = wt.permute(0, 2, 3, 1).contiguous().cuda()
-        for route in (2, 0):
+        for route in (2, 3, 0):      # narrow LDS-DMA tiles, the wide ring kernel (conv16w.hip), the register-staged kernel
             K.set_conv16(route)
             if logits:
                 y = K.conv_fwd(b16(x), wg, 1, p, d, bias=b.cuda(), out_dtype=torch.float32)
@@ -979,6 +981,7 @@ def test_conv16_on_the_48x48_maps(K, case):
     if logits:
         assert outs[2][0].dtype == torch.float32
         assert rel(nchw(outs[2][0]), y_lin + b.view(1, -1, 1, 1)) < 2e-5 and rel(outs[2][0], outs[0][0]) < 2e-5
+        assert rel(nchw(outs[3][0]), y_lin + b.view(1, -1, 1, 1)) < 2e-5
         return
     y0, y1, dx = outs[2]
     close16(nchw(y0.float()), y_lin + b.view(1, -1, 1, 1), ulps=1.5)
@@ -987,6 +990,12 @@ def test_conv16_on_the_48x48_maps(K, case):
     F.conv2d(x2, r16(wt), None, padding=p, dilation=d).backward(dy)
     close16(nchw(dx.float()), x2.grad + skip, ulps=1.5)
     for a, c in zip(outs[2], outs[0]):      # the two kernels differ by accumulation order only: neighbouring bf16 values at most (one spacing = 2^-7)
+        close16(a.float(), c.float(), ulps=2.5)
+    y0w, y1w, dxw = outs[3]                 # the wide kernel: against the formula and against the narrow kernel
+    close16(nchw(y0w.float()), y_lin + b.view(1, -1, 1, 1), ulps=1.5)
+    close16(nchw(y1w.float()), torch.relu(y_lin * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res), ulps=1.5)
+    close16(nchw(dxw.float()), x2.grad + skip, ulps=1.5)
+    for a, c in zip(outs[3], outs[2]):
         close16(a.float(), c.float(), ulps=2.5)
 
 

@@ -13,6 +13,10 @@ SHAPES = [  # name, n, cin, h, w, cout, k, pad, dil
     ('layer3.conv3 1x1 256->1024 @48', 8, 256, 48, 48, 1024, 1, 0, 1),
     ('layer4.conv3 1x1 512->2048 @48', 8, 512, 48, 48, 2048, 1, 0, 1),
     ('aspp dgrad-like 3x3 256->2048 @48', 8, 256, 48, 48, 2048, 3, 1, 1),
+    ('dsn-like 3x3 1024->512 @48', 8, 1024, 48, 48, 512, 3, 1, 1),
+    ('layer2.conv3 1x1 128->512 @96', 8, 128, 96, 96, 512, 1, 0, 1),
+    ('layer1.conv3 1x1 64->256 @192', 8, 64, 192, 192, 256, 1, 0, 1),
+    ('final1.0 3x3 320->256 @192', 8, 320, 192, 192, 256, 3, 1, 1),
     ('layer2.conv2 3x3 128->128 @96', 8, 128, 96, 96, 128, 3, 1, 1),
     ('final1.3 3x3 256->256 @192', 8, 256, 192, 192, 256, 3, 1, 1),
 ]
