@@ -84,30 +84,29 @@ import pytest  # noqa: E402
 
 
 @pytest.mark.gpu
-def test_bench_py_gpus_2_self_launch_on_the_gpu_box(tmp_path):
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_bench_py_gpus_2_self_launch_on_the_gpu_box(tmp_path, dtype):
     """the driver's call -- `python bench.py --gpus 2`, no outer launcher -- as a FRESH child process on the GPU box: the parent starts two
     ranks of itself (gloo: both share the box's one GPU; RCCL refuses two ranks on a device), rank 0's single JSON line comes back with n_gpus 2, two ranks
     seen, one step time per rank, and a finite loss; the whole N > 1 code path (SyncBatchNorm exchanges, bucketed gradient all-reduce, memory-slot sum,
     overlapped commit forward with its deferred sum) ran inside it -- on the fp32 line and on the bf16 tier (bf16 activations under SyncBatchNorm's fp32 statistics
-    exchange, the batched refresh of the kept bf16 filters after the all-reduced step). Round 5: the two tiers run as two concurrent children (the suite's time
-    budget), and the line says how the exchanges travelled (`rccl_direct`, its reason) and how many there were (`collectives_per_step`)."""
+    exchange, the batched refresh of the kept bf16 filters after the all-reduced step). The log is kept under profiles/ by tools/gpu_round4_profiles.sh."""
     import torch
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
     env['PM_BENCH_BACKEND'] = 'gloo'
-    procs = {dtype: subprocess.Popen([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--size', '256', '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
-                                      '--dtype', dtype], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for dtype in ('f32', 'bf16')}
-    for dtype, proc in procs.items():
-        out, err = proc.communicate(timeout=900)
-        assert proc.returncode == 0, out[-2000:] + err[-4000:]
-        lines = [l for l in out.splitlines() if l.startswith('{')]
-        assert len(lines) == 1, out[-2000:]
-        d = json.loads(lines[0])
-        c = d['config']
-        assert d['n_gpus'] == 2 and c['ranks_seen'] == 2 and len(c['ms_per_step_per_rank']) == 2 and c['global_batch'] == 16 and c['parallelism'] == 'dp2'
-        assert d['scaling'] == 'weak' and d['value'] > 0 and d['cpu_baseline'] is None and d['dtype'] == dtype
-        assert abs(d['value'] - 16 / (d['ms_per_step'] * 1e-3)) < 1e-2 * d['value']                 # whole-job rate: both ranks' images over the slowest rank's time
-        assert c['final_loss'] == c['final_loss'] and abs(c['final_loss']) < 1e3                     # finite
-        assert c['rccl_direct'] is False and 'gloo' in c['rccl_direct_reason'] and c['collectives_per_step'] >= 130      # 65 + 65 SyncBN exchanges, buckets, memory slots
-        assert c['host_enqueue_ms'] > 0 and c['step_form'] == 'eager launches'
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--size', '256', '--steps', '2', '--warmup', '1', '--no-cpu-baseline',
+                        '--dtype', dtype], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    c = d['config']
+    assert d['n_gpus'] == 2 and c['ranks_seen'] == 2 and len(c['ms_per_step_per_rank']) == 2 and c['global_batch'] == 16 and c['parallelism'] == 'dp2'
+    assert d['scaling'] == 'weak' and d['value'] > 0 and d['cpu_baseline'] is None and d['dtype'] == dtype
+    assert abs(d['value'] - 16 / (d['ms_per_step'] * 1e-3)) < 1e-2 * d['value']                 # whole-job rate: both ranks' images over the slowest rank's time
+    assert c['final_loss'] == c['final_loss'] and abs(c['final_loss']) < 1e3                     # finite
+    # round 5: the line says how the exchanges travelled and how many there were, and what the host spent enqueueing one step
+    assert c['rccl_direct'] is False and 'gloo' in c['rccl_direct_reason'] and c['collectives_per_step'] >= 130      # 65 + 65 SyncBN exchanges, buckets, memory slots
+    assert c['host_enqueue_ms'] > 0 and c['step_form'] == 'eager launches'

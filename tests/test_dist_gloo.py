@@ -294,48 +294,53 @@ print('PROBE_DONE', rank)
 '''
 
 
+@pytest.fixture(scope='module')
+def single_process_reference(tmp_path_factory):
+    """ONE process running all four images of _TWO_RANK_PROBE: what every split of the two-rank test is compared with."""
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    one = str(tmp_path_factory.mktemp('two_rank') / 'one.pt')
+    r = subprocess.run([sys.executable, '-c', _TWO_RANK_PROBE, one, '1', '4'], cwd=root, capture_output=True, text=True, timeout=600)
+    assert 'PROBE_DONE 0' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    return one
+
+
 @pytest.mark.gpu
-def test_two_ranks_on_gpu_equal_single_process_big_batch(tmp_path):
-    """World size 2 for real (two processes, gloo, both on the box's one GPU; RCCL refuses two ranks on one device): rank r runs its images
-    through the HIP path with every BatchNorm converted to SyncBatchNorm (train.py:95) and the memory-slot all-reduce on. Against
+@pytest.mark.parametrize('split', ['2,2', '3,1'])         # '1,1,1,1' (four ranks) also passes, run by hand; 8 ranks x 8 images: tools/gloo_ranks_probe.py, profiles/r05_ranks_probe_8x8_256.log
+def test_two_ranks_on_gpu_equal_single_process_big_batch(tmp_path, split, single_process_reference):
+    """World size 2 for real (two processes, gloo, both on the box's one GPU; RCCL refuses two ranks on one device): rank r runs images
+    [2r, 2r + 2) through the HIP path with every BatchNorm converted to SyncBatchNorm (train.py:95) and the memory-slot all-reduce on. Against
     ONE process running all four images: the committed memory (C3), the BatchNorm running moments incl. Memory_sup's own and the 4-sample
     image-pooling BN (C2 forward), the summed loss to fp32 round-off, and the all-reduced gradients of eight parameters from stem to ASPP (C2 backward with the
-    all-reduced element count, C1) to the gradient gates of the parity tests. Two splits: 2 + 2, and 3 + 1 = the uneven last batch: rank 1's image-pooling BatchNorm
-    sees ONE value per channel locally, the merged statistics and the all-reduced count are those of the four images. ('1,1,1,1' -- four ranks -- also passes: 170 s
-    of gloo round trips, run by hand; tools/gloo_ranks_probe.py 8 8 256: profiles/r05_ranks_probe_8x8_256.log.) Round 5: the single-process run and the two
-    two-rank runs start together (five processes on the one GPU) -- the suite's time budget."""
+    all-reduced element count, C1) to the gradient gates of the parity tests. The 3 + 1 split is the uneven last batch: rank 1's image-pooling BatchNorm sees ONE
+    value per channel locally, the merged statistics and the all-reduced count are those of the four images."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    one = str(tmp_path / 'one.pt')
-    jobs = {'one': [subprocess.Popen([sys.executable, '-c', _TWO_RANK_PROBE, one, '1', '4'], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)]}
-    outs_path = {}
-    for split in ('2,2', '3,1'):
-        port = str(_free_port())
-        outs_path[split] = str(tmp_path / ('two_%s.pt' % split.replace(',', '_')))
-        world = len(split.split(','))
-        jobs[split] = []
-        for rank in range(world):
-            env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
-            jobs[split].append(subprocess.Popen([sys.executable, '-c', _TWO_RANK_PROBE, outs_path[split], str(world), split], cwd=root, env=env,
-                                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    for name, procs in jobs.items():
-        outs = [p.communicate(timeout=900) for p in procs]
-        assert all('PROBE_DONE' in o[0] for o in outs), name + ''.join(o[0][-1500:] + o[1][-3000:] for o in outs)
-    a = torch.load(one)
+    one, two = single_process_reference, str(tmp_path / 'two.pt')      # the single-process run is shared by the two splits (round 5: the suite's time budget)
+    port = str(_free_port())
+    procs = []
+    world = len(split.split(','))                                     # '1,1,1,1': four ranks, one image each
+    for rank in range(world):
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+        procs.append(subprocess.Popen([sys.executable, '-c', _TWO_RANK_PROBE, two, str(world), split], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all('PROBE_DONE' in o[0] for o in outs), ''.join(o[0][-1500:] + o[1][-3000:] for o in outs)
+    a, b = torch.load(one), torch.load(two)
 
     def rel(u, v):
         return ((u.double() - v.double()).norm() / (v.double().norm() + 1e-30)).item()
-    for split in ('2,2', '3,1'):
-        b = torch.load(outs_path[split])
-        assert rel(b['m_items'], a['m_items']) < 1e-5, split
-        assert abs(b['loss'].item() - a['loss'].item()) < 1e-4 * abs(a['loss'].item()), split
-        for n in a['running']:
-            assert rel(b['running'][n], a['running'][n]) < 1e-5, (split, n)
-        errs = sorted((rel(b['grads'][n], a['grads'][n]), n) for n in a['grads'])
-        print('two-rank (%s) vs big-batch gradient errors:' % split, [(round(e, 5), n) for e, n in errs])
-        # two fp32 evaluations of a ReLU network differ by the units that flip within round-off: the bounds of tests/test_model_parity.py
-        assert errs[-1][0] < 1e-2 and errs[0][0] < 1e-4, (split, errs)       # heads behind the last ReLU layers: round-off only; trunk: the ReLU-flip floor (~3e-3)
+    assert rel(b['m_items'], a['m_items']) < 1e-5
+    assert abs(b['loss'].item() - a['loss'].item()) < 1e-4 * abs(a['loss'].item())
+    for n in a['running']:
+        assert rel(b['running'][n], a['running'][n]) < 1e-5, n
+    errs = sorted((rel(b['grads'][n], a['grads'][n]), n) for n in a['grads'])
+    print('two-rank vs big-batch gradient errors:', [(round(e, 5), n) for e, n in errs])
+    # two fp32 evaluations of a ReLU network differ by the units that flip within round-off: the bounds of tests/test_model_parity.py
+    assert errs[-1][0] < 1e-2 and errs[0][0] < 1e-4, errs       # heads behind the last ReLU layers: round-off only; trunk: the ReLU-flip floor (~3e-3)
 
 
 # ---- GPU: two real ranks run the harness' agg step with the commit forward overlapped; the memory commit is never hidden behind an attribute read -----
