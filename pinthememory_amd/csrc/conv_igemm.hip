@@ -1514,6 +1514,24 @@ int conv_bf16(const pm_tensor* xin, const float* w, int w_cout, int w_cin, bool 
   if (!(wb_ext && wb_valid))
     if (int e = pm_bf16_cast_weights(w, w_cout, T, w_cin, b.Cp, rotate, wb, st)) return e;
   const long xpitch16 = b.inplace ? xin->pitch : b.Cp;                       // bf16 elements between pixels
+  // round 5: the HBM-bound 1x1 convolutions with a short reduction (K = 64 / 128 / 256) stream through the persistent kernel of pw16.hip
+  if (T == 1 && pe->stride == 1 && pe->pad == 0 && pm_is_bf16(yout) && !e0.bn_partials && xin->h == yout->h && xin->w == yout->w &&
+      pm_pw16_ok(b.M, (int)b.Nn, b.Cp, xpitch16, yout->pitch, e0.residual ? e0.residual_pitch : 0, xb, yout->ptr, e0.residual)) {
+    ProfRec rec;
+    if (g_prof_on) {
+      (void)hipEventCreate(&rec.a), (void)hipEventCreate(&rec.b);
+      rec.mode = 6, rec.bm = b.Cp == 256 ? 32 : 64, rec.bn = b.Cp == 256 ? 128 : 256, rec.km = 0, rec.prec = 5, rec.nst = 4, rec.M = (int)b.M, rec.Nn = (int)b.Nn, rec.K = b.Cp / 2,
+      rec.batch = 1, rec.ksplit = 1, rec.flops = 2.0 * (double)b.M * (double)b.Nn * (double)xin->c;
+      (void)hipEventRecord(rec.a, st);
+    }
+    const int e = pm_pw16_launch((const pm_bf16*)xb, xpitch16, (const pm_bf16*)wb, (pm_bf16*)yout->ptr, yout->pitch, (const pm_bf16*)e0.residual, e0.residual_pitch, b.M,
+                                 (int)b.Nn, b.Cp, e0.bias, e0.scale, e0.shift, e0.relu, st);
+    if (g_prof_on) {
+      (void)hipEventRecord(rec.b, st);
+      g_prof.push_back(rec);
+    }
+    return e;
+  }
   if (b.c16) {
     const bool o16 = pm_is_bf16(yout);
     const bool ep_any = e0.bias || e0.scale || e0.residual || e0.relu;
@@ -1747,12 +1765,14 @@ extern "C" int pm_set_winograd(int mode) {
   return PM_OK;
 }
 extern int g_c16w;      // conv16.hip: 0 never the wide (conv16w.hip) kernel, 1 by the planner's cost model, 2 wherever the shape allows it
+extern int g_pw16;      // pw16.hip: 0 never the streaming 1x1 kernel, 1 by size, 2 every eligible 1x1
 extern "C" int pm_set_conv16(int on) {
-  PM_REQUIRE(on >= 0 && on <= 4, PM_EINVAL, "pm_set_conv16: %d (0 register-staged, 1 per shape, 2 LDS-DMA everywhere / narrow tiles only, 3 LDS-DMA everywhere / wide tiles "
-             "wherever the shape allows, 4 per shape without the wide kernel)", on);
-  static const int c16w_default = g_c16w;
-  g_conv16 = on == 3 ? 2 : (on == 4 ? 1 : on);
+  PM_REQUIRE(on >= 0 && on <= 6, PM_EINVAL, "pm_set_conv16: %d (0 register-staged, 1 per shape, 2 LDS-DMA everywhere / narrow tiles only, 3 LDS-DMA everywhere / wide tiles "
+             "wherever the shape allows, 4 per shape without the wide kernel, 5 per shape with the streaming 1x1 kernel on every eligible call, 6 per shape without it)", on);
+  static const int c16w_default = g_c16w, pw16_default = g_pw16;
+  g_conv16 = on == 3 ? 2 : ((on == 4 || on == 5 || on == 6) ? 1 : on);
   g_c16w = on == 3 ? 2 : ((on == 2 || on == 4) ? 0 : c16w_default);
+  g_pw16 = on == 5 ? 2 : ((on == 0 || on == 2 || on == 3 || on == 6) ? 0 : pw16_default);
   return PM_OK;
 }
 extern "C" int pm_set_winograd_fused(int on) {
@@ -1873,6 +1893,9 @@ static bool bn_partials_route(const pm_tensor* x, const pm_tensor* y, const pm_c
   if (pm_is_bf16(y)) {      // bf16 tier: both bf16 kernels carry the statistics in their 8-column staged epilogue (one K split, whole 16-byte groups)
     if (!pm_vec8(y)) return false;
     const Bf16Plan b = bf16_plan(x, y, p);
+    if (b.use && p->kh * p->kw == 1 && p->stride == 1 && p->pad == 0 && x->h == y->h && x->w == y->w &&
+        pm_pw16_ok(b.M, (int)b.Nn, b.Cp, b.inplace ? x->pitch : b.Cp, y->pitch, 0, b.inplace ? x->ptr : y->ptr, y->ptr, nullptr))
+      return false;      // the streaming 1x1 kernel (pw16.hip) has no statistics epilogue
     return b.use && (b.c16 ? (b.k16.ksplit == 1 && !b.k16.wide) : b.pl.ksplit == 1);
   }
   if (pm_is_bf16(x)) return false;

@@ -120,6 +120,11 @@ size_t pm_conv16_slab_bytes(const pm_conv16* k);
 double pm_conv16_executed_fraction(const pm_conv16* k);
 int pm_conv16_launch(const pm_conv16* k, hipStream_t st);
 
+// ---- the streaming 1x1 convolution of the bf16 tier (pw16.hip): persistent blocks, weights resident in LDS, 16-byte stores straight from the accumulators ----------
+bool pm_pw16_ok(long M, int Nn, int K, long x_pitch, long y_pitch, long r_pitch, const void* x, const void* y, const void* r);
+int pm_pw16_launch(const pm_bf16* X, long x_pitch, const pm_bf16* W, pm_bf16* Y, long y_pitch, const pm_bf16* R, long r_pitch, long M, int Nn, int K, const float* bias,
+                   const float* scale, const float* shift, int relu, hipStream_t st);
+
 // ---- device helpers -------------------------------------------------------------------------------------------
 // eight bf16 channels (16 bytes) <-> eight floats. Round to nearest even on the way out (v_cvt_pk_bf16_f32).
 __device__ __forceinline__ void pm_ld8(const pm_bf16* p, float* v) {
