@@ -1,0 +1,42 @@
+#!/bin/bash
+# round-5 evidence set in one gpurun call. usage: gpu_round5_profiles.sh <tag> <prefix>   -> gpurun_out/<tag>/, profiles/<prefix>_* on the box (copy back from gpurun_out)
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+O=gpurun_out/$1; P=$2; mkdir -p $O
+for DT in f32 bf16; do
+  SFX=$([ $DT = bf16 ] && echo _bf16 || echo "")
+  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch$SFX -- python bench.py --dtype $DT --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-side > $O/pmc_fetch$SFX.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write$SFX -- python bench.py --dtype $DT --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-side > $O/pmc_write$SFX.log 2>&1
+  python tools/pmc_bench_summary.py $(find $O/pmc_fetch$SFX -name '*.db' | head -1) $(find $O/pmc_write$SFX -name '*.db' | head -1) $O/hbm_counters$SFX.json | head -4
+  cp $O/hbm_counters$SFX.json profiles/${P}_bench_1gpu${SFX}_hbm_counters.json
+  find $O -name '*.db' -delete
+done
+bash tools/gpu_mem_path.sh $1/mem | tail -14
+cp $O/mem/mem_path_hbm_counters.json profiles/${P}_memory_path_hbm_counters.json
+PM_PROFILE_DUMP=$O/prof_dump.txt timeout 900 python bench.py > $O/bench.log 2>&1; grep '^{' $O/bench.log > $O/bench_1gpu_full.json; cut -c1-160 $O/bench_1gpu_full.json
+python tools/conv_shapes.py $O/prof_dump.txt 2 200 > $O/conv_shapes.txt 2>&1; head -2 $O/conv_shapes.txt
+python tools/conv_shapes.py $O/prof_dump.txt.bf16 2 200 > $O/conv_shapes_bf16.txt 2>&1; head -2 $O/conv_shapes_bf16.txt
+timeout 600 python bench.py --dtype bf16 --no-cpu-baseline > $O/bench_bf16.log 2>&1; grep '^{' $O/bench_bf16.log > $O/bench_1gpu_bf16.json; cut -c1-160 $O/bench_1gpu_bf16.json
+for DT in f32 bf16; do
+  timeout 600 rocprofv3 --kernel-trace -d $O/kt_$DT -- python bench.py --dtype $DT --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-side > $O/kt_$DT.log 2>&1
+  python tools/rocpd_stats.py $(find $O/kt_$DT -name '*.db' | head -1) $O/kernel_stats_$DT.csv 4 | head -2
+  PM_OVERLAP_WGRAD=0 PM_COMMIT_OVERLAP=0 timeout 600 rocprofv3 --kernel-trace -d $O/kts_$DT -- python bench.py --dtype $DT --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-side > $O/kts_$DT.log 2>&1
+  python tools/rocpd_stats.py $(find $O/kts_$DT -name '*.db' | head -1) $O/kernel_stats_serialised_$DT.csv 4 | head -2
+  timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $O/pmc_mfma_$DT -- python bench.py --dtype $DT --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-side > $O/pmc_mfma_$DT.log 2>&1
+  python tools/pmc_mfma_summary.py $(find $O/pmc_mfma_$DT -name '*.db' | head -1) $O/mfma_util_$DT.json | head -5
+  find $O -name '*.db' -delete
+done
+timeout 600 python bench.py --workload mldg --steps 5 --warmup 2 2>/dev/null | grep '^{' > $O/bench_mldg.json; cut -c1-160 $O/bench_mldg.json
+timeout 600 python bench.py --workload mldg --dtype bf16 --steps 5 --warmup 2 2>/dev/null | grep '^{' > $O/bench_mldg_bf16.json; cut -c1-160 $O/bench_mldg_bf16.json
+timeout 600 python bench.py --workload config5 --steps 5 --warmup 2 2>/dev/null | grep '^{' > $O/bench_config5.json; cut -c1-160 $O/bench_config5.json
+timeout 600 python bench.py --workload meminit --steps 5 --warmup 2 2>/dev/null | grep '^{' > $O/bench_meminit.json; cut -c1-160 $O/bench_meminit.json
+timeout 600 python bench.py --no-cpu-baseline --no-profile --input-edge 2>/dev/null | grep '^{' > $O/bench_input_edge.json; cut -c1-160 $O/bench_input_edge.json
+PM_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --size 256 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_2rank_gloo.log 2>&1; grep '^{' $O/bench_2rank_gloo.log | cut -c1-200
+timeout 300 python tools/clock_probe_step.py bf16 10 2>&1 | grep -v amdgpu.ids > $O/clock_probe_step_bf16.txt; tail -4 $O/clock_probe_step_bf16.txt
+timeout 300 python tools/clock_probe_step.py f32 10 2>&1 | grep -v amdgpu.ids > $O/clock_probe_step_f32.txt; tail -3 $O/clock_probe_step_f32.txt
+timeout 600 python tools/soak.py 6 --deterministic 2>&1 | grep steps > $O/soak_f32.txt; timeout 600 python tools/soak.py 6 --deterministic --bf16 2>&1 | grep steps > $O/soak_bf16.txt; paste -d'\n' $O/soak_f32.txt $O/soak_bf16.txt | cut -c1-120
+timeout 900 python bench.py --steps 3 --warmup 1 --cpu-batch 8 --no-profile --no-side 2>/dev/null | grep '^{' > $O/bench_cpu_batch8.json; python -c "import json; print(json.load(open('$O/bench_cpu_batch8.json'))['cpu_baseline'])" | cut -c1-300
+# round 5 additions: the captured step on both tiers, the per-shape probe of the bf16 forward kernels (default routing / without the wide kernel / wide everywhere)
+timeout 600 python bench.py --no-cpu-baseline --graph --no-side 2>/dev/null | grep '^{' > $O/bench_graph_f32.json; cut -c1-160 $O/bench_graph_f32.json
+timeout 600 python bench.py --no-cpu-baseline --graph --dtype bf16 2>/dev/null | grep '^{' > $O/bench_graph_bf16.json; cut -c1-160 $O/bench_graph_bf16.json
+for r in 1 4 3; do echo "== pm_set_conv16($r)" >> $O/conv16w_probe.txt; PROBE_CONV16=$r timeout 300 python tools/conv16_probe.py 2>&1 | grep -v amdgpu >> $O/conv16w_probe.txt; done; tail -18 $O/conv16w_probe.txt
