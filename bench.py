@@ -621,12 +621,14 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    host_ms = {'timed_form': host_enqueue_ms(timed_step)}
+    # host-side cost of one step (two extra untimed steps from an idle GPU). Skipped with --no-profile: the counter / trace passes of tools/gpu_round*_profiles.sh count the
+    # steps of the run (warm-up + timed) and must not see extra ones
+    host_ms = {'timed_form': None if a.no_profile else host_enqueue_ms(timed_step)}
     if graphed is not None:
         losses = {k: v.clone() for k, v in losses.items()}
         graphed.close()
         graphed = None
-        host_ms['eager'] = host_enqueue_ms(step)
+        host_ms['eager'] = None if a.no_profile else host_enqueue_ms(step)
     per_rank_ms, ranks_seen = [round(dt / a.steps * 1e3, 3)], 1
     if multi:
         t = torch.zeros(world, device=dev, dtype=torch.float64)

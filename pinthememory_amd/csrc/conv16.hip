@@ -324,15 +324,18 @@ struct WidePick {
   int bm, bn, ks;
   double cost;      // in units of one wide K-step on a full chip
 };
-WidePick wide_pick(const pm_conv16* k) {
+WidePick wide_pick(const pm_conv16* k, int only_cfg = -1) {
   static const int force_ks = getenv("PM_C16W_KS") ? atoi(getenv("PM_C16W_KS")) : 0;
   static const double ovh = getenv("PM_C16W_OVH") ? atof(getenv("PM_C16W_OVH")) : 10.0;      // prologue + epilogue of a block, in K-steps
   WidePick best{false, 0, 0, 0, 1e30};
   const bool forced = g_c16w >= 2;      // kernel tests: every shape the kernel can express, ragged rows / columns and single K-steps included
   if (!forced && (k->Nn < 128 || k->M < 2048 || k->ksteps < 4)) return best;
-  for (int cfg = 0; cfg < 2; ++cfg) {
-    const int bm = cfg == 0 ? 256 : 128, bn = cfg == 0 ? 128 : 256;
-    if (bn > 128 && k->Nn < 256 && !(forced && cfg == 1 && k->Nn > 128)) continue;
+  static const int env_cfg = getenv("PM_C16W_CFG") ? atoi(getenv("PM_C16W_CFG")) : -1;      // 0: 256 x 128, 1: 128 x 256, 2: 256 x 256 (two LDS stages)
+  const int force_cfg = only_cfg >= 0 ? only_cfg : (g_c16w == 3 ? 2 : env_cfg);            // pm_set_conv16(7): the 256 x 256 tile on every shape (kernel tests)
+  for (int cfg = 0; cfg < 3; ++cfg) {
+    if (force_cfg >= 0 && cfg != force_cfg) continue;
+    const int bm = cfg == 1 ? 128 : 256, bn = cfg == 0 ? 128 : 256;
+    if (cfg == 2 && force_cfg != 2) continue;      // 256 x 256 only where asked for (the planner's rule below, PM_C16W_CFG, pm_set_conv16(7))
     const long tiles = (long)pm_cdiv(k->M, bm) * pm_cdiv(k->Nn, bn);
     const double fill = ((double)k->M * k->Nn) / ((double)tiles * bm * bn);      // padded rows / columns are wasted work
     for (int ks = 1; ks <= 16; ++ks) {
@@ -344,7 +347,8 @@ WidePick wide_pick(const pm_conv16* k) {
       const long rounds = (blocks + 255) / 256;
       // split-K slabs: fp32 partial tiles written and read back by the reduce (bytes / ~4 TB/s, in wide K-steps of ~1.1 us measured on this kernel)
       const double slab = kse > 1 ? (double)kse * k->M * k->Nn * 8.0 / 4e12 / 1.1e-6 : 0.0;
-      const double cost = (double)rounds * (per + ovh) / fill * (cfg == 1 ? 1.03 : 1.0) + slab;
+      // a 256 x 256 step covers twice the area of a 256 x 128 one at ~1.3 x its rate (128 vs 85 FLOP per staged byte)
+      const double cost = (double)rounds * (per + ovh) / fill * (cfg == 1 ? 1.03 : (cfg == 2 ? 1.5 : 1.0)) + slab;
       if (cost < best.cost) best = WidePick{true, bm, bn, kse, cost};
     }
   }
@@ -382,14 +386,14 @@ void pm_conv16_plan(pm_conv16* k) {
     k->ksteps_per = k->ksteps, k->ksplit = 1;
   }
   if (g_c16w > 0) {
-    const WidePick w = wide_pick(k);
-    // Where the wide tile wins (tools/conv16_probe.py on an MI355X, round 5, profiles/r05_conv16w_probe.txt): the very wide outputs of a medium reduction (3x3
-    // 256 -> 2048 data-gradient form on the 48 x 48 maps, 4.5 rounds of tiles: 697-701 -> 754-769 TF). On the deep ASPP reduction (2048 -> 256, 288 K-steps) it was
-    // ahead of the narrow tile (690 -> 736 TF at K-split 3) until the narrow kernel learned to skip invisible filter rows (764 TF: its 64-row tiles see whole filter
-    // rows fall outside the image where a 256-row tile does not); everywhere else the 1.125-round tile counts of the 48 x 48 maps (288 tiles of 256 x 128 on 256 CUs)
-    // cost more than the tile's 2 x FLOP per staged byte buys, and on the 192 x 192 maps it is level with the 128 x 128 register-staged kernel (877 vs 847-891 TF).
-    const bool wins = k->Nn >= 2048 && k->ksteps >= 32;
-    if (w.ok && (g_c16w >= 2 || wins)) {
+    // Where the wide tiles win (tools/conv16_probe.py on an MI355X, round 5, profiles/r05_conv16w_probe.txt), all with the 256 x 256 two-stage form (128 FLOP per staged
+    // byte, full-N for the 256-channel outputs): the DEEP reductions -- the ASPP 3x3 2048 -> 256 on the 48 x 48 maps (288 K-steps: 690 TF narrow, 764 with skipped filter
+    // rows, 733 on 256 x 128, **834-866**), the auxiliary head's 3x3 1024 -> 512 (660 -> 780) -- and the very wide outputs of a medium reduction (3x3 256 -> 2048
+    // data-gradient form: 697 narrow, 725-769 on 256 x 128, **778-785**). Not the 72-K-step 3x3 512 -> 512 of layer4 (633 vs 650-700 narrow: 144 tiles), and on the
+    // 192 x 192 maps every form sits at 915-958 TF (the decoder's 3x3s stay with the 128 x 128 register-staged kernel).
+    const bool wins = k->ksteps >= 128 || (k->Nn >= 2048 && k->ksteps >= 32);
+    const WidePick w = g_c16w >= 2 ? wide_pick(k) : (wins ? wide_pick(k, 2) : WidePick{false, 0, 0, 0, 0});
+    if (w.ok) {
       k->wide = 1, k->bm = w.bm, k->bn = w.bn;
       k->tiles_m = pm_cdiv(k->M, k->bm), k->tiles_n = pm_cdiv(k->Nn, k->bn);
       k->ksteps_per = pm_cdiv(k->ksteps, w.ks);

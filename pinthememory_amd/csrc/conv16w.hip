@@ -1,13 +1,14 @@
-// BASELINE configs[2], round 5: the WIDE form of the LDS-DMA bf16 implicit-GEMM convolution (conv16.hip) -- one 256 x 128 (or 128 x 256) output tile per CU, eight
-// waves, a three-stage LDS ring filled by LDS-DMA with COUNTED waits (s_waitcnt vmcnt(N) + a bare s_barrier: the fetches of K-step k + 2 and k + 1 stay in flight while
-// K-step k is multiplied), one barrier per K-step.
-// Why: the 64 x 128 / 128 x 128 tiles of conv16.hip move 43 / 64 FLOP per byte staged from L2 into LDS; on the 48 x 48 maps (M = 18 432 rows: layer3 / layer4 / ASPP) that
-// holds them at 0.24-0.30 of the bf16 MFMA peak -- 16 TB/s of L2 -> LDS traffic at 700 TFLOP/s, LDS reads of 1.5 KB per MFMA for a 32 x 64 wave tile (DESIGN section 7
-// "Round 5"). This tile stages 85 FLOP per byte and reads 1 KB of LDS per MFMA (64 x 64 wave tiles). With ONE resident block per CU the latency hiding that conv16.hip
-// gets from three co-resident blocks has to come from the block's own pipeline: hence the ring. With one block per CU the tile count also has to be balanced against the
-// 256 CUs by the planner (split-K, conv16.hip pm_conv16_plan).
-// Same operands, same addressing (buffer descriptors, out-of-range offsets deliver zeros, source-side XOR swizzle), same epilogues as conv16.hip.
-// Replaces nn.Conv2d forward / input gradient of Resnet.py:145-150,195; deepv3plus.py:72-81 on the bf16 tier where the planner picks it.
+// BASELINE configs[2], round 5: the WIDE forms of the LDS-DMA bf16 implicit-GEMM convolution (conv16.hip) -- ONE large output tile per CU, eight waves:
+//   * 256 x 256, two 64 KB LDS stages (128 FLOP per staged byte; wave tile 128 x 64: 0.75 KB of LDS reads per MFMA): the fetches of K-step k + 1 are issued behind the barrier
+//     of step k and fly under its 32 MFMAs per wave. THE FORM THE PLANNER USES: the deep reductions (ASPP 3x3 2048 -> 256 on the 48 x 48 maps: 690 TF on the 64 x 128 tiles,
+//     764 with skipped filter rows, 834-866 here; the auxiliary head's 3x3 1024 -> 512: 660 -> 780) and very wide outputs of a medium reduction (256 -> 2048: 697 -> 780);
+//   * 256 x 128 / 128 x 256, a three-stage LDS ring filled with COUNTED waits (s_waitcnt vmcnt(N) + a bare s_barrier: the fetches of K-steps k + 1 and k + 2 stay in flight
+//     while step k is multiplied; 85 FLOP per staged byte): 733-769 TF on the same shapes, level with the narrow tiles elsewhere -- kept for A/B (PM_C16W_CFG) and the tests.
+// Why big tiles: every kernel of this family moves ~20-30 bytes per clock and CU from L2 into LDS whatever its tile (DESIGN section 7 "Round 5"), so TFLOP/s ~ FLOP per
+// staged byte x that; the 64 x 128 / 128 x 128 tiles of conv16.hip stage 43 / 64. Why not everywhere: with one block per CU the tile count has to be balanced against the
+// 256 CUs (split-K by the planner's cost model, conv16.hip pm_conv16_plan); the 48 x 48 maps give 72 x N / 256 tiles of 256 x 256.
+// Same operands, same addressing (buffer descriptors, out-of-range offsets deliver zeros, source-side XOR swizzle), same epilogues, same invisible-filter-row skipping as
+// conv16.hip. Replaces nn.Conv2d forward / input gradient of deepv3plus.py:72-81,419-425 (ASPP, dsn) on the bf16 tier where the planner picks it.
 #include <stdlib.h>
 #include <algorithm>
 
@@ -20,7 +21,6 @@ namespace {
 
 constexpr int BKB = 128;      // bytes per row and K-step (64 bf16)
 constexpr int NT = 512;       // threads per block: eight waves
-constexpr int NST = 3;        // LDS ring depth
 
 __device__ __forceinline__ int xcd_remap_w(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
@@ -37,7 +37,9 @@ __device__ __forceinline__ void wait_vm() {
   __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
 }
 
-template <int BM, int BN, int WM, int WN>
+// NST = 3: the ring (256 x 128 / 128 x 256, 48 KB per stage). NST = 2: 256 x 256 (64 KB per stage, 128 FLOP per staged byte): the fetches of K-step k + 1 are issued behind
+// the barrier of step k and fly under its 32 MFMAs per wave; the wait in front of the next barrier is a full one (nothing younger is in flight).
+template <int BM, int BN, int WM, int WN, int NST>
 __global__ __launch_bounds__(NT, 2) void conv16w_kernel(const pm_conv16 a) {
   static_assert(WM * WN == 8, "eight waves");
   constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;      // 16-byte fetches per lane and K-step: a 512-thread sweep covers 64 rows x 8 chunks
@@ -189,20 +191,33 @@ __global__ __launch_bounds__(NT, 2) void conv16w_kernel(const pm_conv16 a) {
   // barrier leaves the FETCH instructions of stage k + 1 in flight (LDS-DMA fetches of a wave retire in order), so "my part of stage k has landed" + barrier = "stage k
   // has landed". No __syncthreads(): its fence would drain the DMA queue (vmcnt(0)) at every K-step.
   if (nk_eff > 0) {
-    stage(0);
-    if (nk_eff > 1) stage(1);
-    int cur = 0, nxt = 2;
-    for (int kt = 0; kt < nk_eff; ++kt) {
-      if (kt + 1 < nk_eff) wait_vm<FETCH>();
-      else wait_vm<0>();
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      if (kt + 2 < nk_eff) stage(nxt);
-      compute(cur);
-      cur = cur == NST - 1 ? 0 : cur + 1;
-      nxt = nxt == NST - 1 ? 0 : nxt + 1;
+    if constexpr (NST == 3) {
+      stage(0);
+      if (nk_eff > 1) stage(1);
+      int cur = 0, nxt = 2;
+      for (int kt = 0; kt < nk_eff; ++kt) {
+        if (kt + 1 < nk_eff) wait_vm<FETCH>();
+        else wait_vm<0>();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nk_eff) stage(nxt);
+        compute(cur);
+        cur = cur == NST - 1 ? 0 : cur + 1;
+        nxt = nxt == NST - 1 ? 0 : nxt + 1;
+      }
+    } else {
+      stage(0);
+      for (int kt = 0; kt < nk_eff; ++kt) {
+        wait_vm<0>();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();      // stage kt has landed everywhere, and everybody has left the buffer stage kt + 1 goes into (read in step kt - 1)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk_eff) stage((kt + 1) & 1);
+        compute(kt & 1);
+      }
     }
   }
 
@@ -295,17 +310,17 @@ __global__ __launch_bounds__(NT, 2) void conv16w_kernel(const pm_conv16 a) {
   }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NST>
 void launch_wide(const pm_conv16& k, dim3 grid, hipStream_t st) {
   constexpr size_t stage_bytes = (size_t)NST * (BM + BN) * BKB, ep_bytes = (size_t)8 * 32 * (BN / WN + 4) * sizeof(float);
   constexpr size_t smem = stage_bytes > ep_bytes ? stage_bytes : ep_bytes;
   static_assert(smem <= 160 * 1024, "LDS budget");
   static const bool attr_set = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv16w_kernel<BM, BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv16w_kernel<BM, BN, WM, WN, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     return true;
   }();
   (void)attr_set;
-  hipLaunchKernelGGL((conv16w_kernel<BM, BN, WM, WN>), grid, dim3(NT), smem, st, k);
+  hipLaunchKernelGGL((conv16w_kernel<BM, BN, WM, WN, NST>), grid, dim3(NT), smem, st, k);
 }
 
 }  // namespace
@@ -313,8 +328,9 @@ void launch_wide(const pm_conv16& k, dim3 grid, hipStream_t st) {
 int pm_conv16w_launch(const pm_conv16* k0, hipStream_t st) {
   pm_conv16 k = *k0;
   dim3 grid(k.tiles_m * k.tiles_n, 1, k.ksplit);
-  if (k.bm == 256 && k.bn == 128) launch_wide<256, 128, 4, 2>(k, grid, st);
-  else if (k.bm == 128 && k.bn == 256) launch_wide<128, 256, 2, 4>(k, grid, st);
+  if (k.bm == 256 && k.bn == 128) launch_wide<256, 128, 4, 2, 3>(k, grid, st);
+  else if (k.bm == 128 && k.bn == 256) launch_wide<128, 256, 2, 4, 3>(k, grid, st);
+  else if (k.bm == 256 && k.bn == 256) launch_wide<256, 256, 2, 4, 2>(k, grid, st);
   else {
     pm_set_error("conv16w: no %d x %d tile", k.bm, k.bn);
     return PM_EUNSUPPORTED;

@@ -1767,12 +1767,12 @@ extern "C" int pm_set_winograd(int mode) {
 extern int g_c16w;      // conv16.hip: 0 never the wide (conv16w.hip) kernel, 1 by the planner's cost model, 2 wherever the shape allows it
 extern int g_pw16;      // pw16.hip: 0 never the streaming 1x1 kernel, 1 by size, 2 every eligible 1x1
 extern "C" int pm_set_conv16(int on) {
-  PM_REQUIRE(on >= 0 && on <= 6, PM_EINVAL, "pm_set_conv16: %d (0 register-staged, 1 per shape, 2 LDS-DMA everywhere / narrow tiles only, 3 LDS-DMA everywhere / wide tiles "
-             "wherever the shape allows, 4 per shape without the wide kernel, 5 per shape with the streaming 1x1 kernel on every eligible call, 6 per shape without it)", on);
+  PM_REQUIRE(on >= 0 && on <= 7, PM_EINVAL, "pm_set_conv16: %d (0 register-staged, 1 per shape, 2 LDS-DMA everywhere / narrow tiles only, 3 LDS-DMA everywhere / wide tiles "
+             "wherever the shape allows, 4 per shape without the wide kernel, 5 per shape with the streaming 1x1 kernel on every eligible call, 6 per shape without it, 7 as 3 with the 256 x 256 tile)", on);
   static const int c16w_default = g_c16w, pw16_default = g_pw16;
-  g_conv16 = on == 3 ? 2 : ((on == 4 || on == 5 || on == 6) ? 1 : on);
-  g_c16w = on == 3 ? 2 : ((on == 2 || on == 4) ? 0 : c16w_default);
-  g_pw16 = on == 5 ? 2 : ((on == 0 || on == 2 || on == 3 || on == 6) ? 0 : pw16_default);
+  g_conv16 = (on == 3 || on == 7) ? 2 : ((on == 4 || on == 5 || on == 6) ? 1 : on);
+  g_c16w = on == 3 ? 2 : (on == 7 ? 3 : ((on == 2 || on == 4) ? 0 : c16w_default));
+  g_pw16 = on == 5 ? 2 : ((on == 0 || on == 2 || on == 3 || on == 6 || on == 7) ? 0 : pw16_default);
   return PM_OK;
 }
 extern "C" int pm_set_winograd_fused(int on) {

@@ -899,7 +899,7 @@ ACT16_CASES = [CONV_CASES[0], CONV_CASES[1], CONV_CASES[3], CONV_CASES[4], CONV_
                (1, 512, 12, 12, 512, 3, 1, 2, 2, False)]
 
 
-@pytest.mark.parametrize('route', ['lds_dma', 'lds_dma_wide', 'reg_staged'])
+@pytest.mark.parametrize('route', ['lds_dma', 'lds_dma_wide', 'lds_dma_256', 'reg_staged'])
 @pytest.mark.parametrize('case', ACT16_CASES)
 def test_conv_bf16_activations(K, case, route):
     """BASELINE configs[2], round 4: bf16 tensors in, bf16 tensors out (x, y, dy, dx), fp32 weights / dw, fp32 accumulation. Oracle: the fp32 convolution of
@@ -913,7 +913,7 @@ def test_conv_bf16_activations(K, case, route):
     skip = r16(rnd(n, cin, h, w, seed=5))
     K.set_conv_precision('bf16')
     # csrc/conv16.hip on every shape (2: its narrow tiles, 3: the wide eight-wave ring kernel of conv16w.hip, round 5), or the register-staged kernel on bf16 rows
-    K.set_conv16({'lds_dma': 2, 'lds_dma_wide': 3}.get(route, 0))
+    K.set_conv16({'lds_dma': 2, 'lds_dma_wide': 3, 'lds_dma_256': 7}.get(route, 0))
     try:
         wg = wt.permute(0, 2, 3, 1).contiguous().cuda()
         xg = K.new((n, h, w, cin), wg, dtype=torch.bfloat16)      # zero-padded + registered when cin % 64 != 0 (304): gathered in place
@@ -965,7 +965,7 @@ def test_conv16_on_the_48x48_maps(K, case):
     outs = {}
     try:
         wg = wt.permute(0, 2, 3, 1).contiguous().cuda()
-        for route in (2, 3, 0):      # narrow LDS-DMA tiles, the wide ring kernel (conv16w.hip), the register-staged kernel
+        for route in (2, 3, 7, 0):      # narrow LDS-DMA tiles, the wide ring kernel (conv16w.hip), its 256 x 256 two-stage form, the register-staged kernel
             K.set_conv16(route)
             if logits:
                 y = K.conv_fwd(b16(x), wg, 1, p, d, bias=b.cuda(), out_dtype=torch.float32)
@@ -981,7 +981,7 @@ def test_conv16_on_the_48x48_maps(K, case):
     if logits:
         assert outs[2][0].dtype == torch.float32
         assert rel(nchw(outs[2][0]), y_lin + b.view(1, -1, 1, 1)) < 2e-5 and rel(outs[2][0], outs[0][0]) < 2e-5
-        assert rel(nchw(outs[3][0]), y_lin + b.view(1, -1, 1, 1)) < 2e-5
+        assert rel(nchw(outs[3][0]), y_lin + b.view(1, -1, 1, 1)) < 2e-5 and rel(nchw(outs[7][0]), y_lin + b.view(1, -1, 1, 1)) < 2e-5
         return
     y0, y1, dx = outs[2]
     close16(nchw(y0.float()), y_lin + b.view(1, -1, 1, 1), ulps=1.5)
@@ -996,6 +996,8 @@ def test_conv16_on_the_48x48_maps(K, case):
     close16(nchw(y1w.float()), torch.relu(y_lin * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res), ulps=1.5)
     close16(nchw(dxw.float()), x2.grad + skip, ulps=1.5)
     for a, c in zip(outs[3], outs[2]):
+        close16(a.float(), c.float(), ulps=2.5)
+    for a, c in zip(outs[7], outs[2]):      # the 256 x 256 form: same sums in another order
         close16(a.float(), c.float(), ulps=2.5)
 
 

@@ -14,6 +14,10 @@ SHAPES = [  # name, n, cin, h, w, cout, k, pad, dil
     ('layer4.conv3 1x1 512->2048 @48', 8, 512, 48, 48, 2048, 1, 0, 1),
     ('aspp dgrad-like 3x3 256->2048 @48', 8, 256, 48, 48, 2048, 3, 1, 1),
     ('dsn-like 3x3 1024->512 @48', 8, 1024, 48, 48, 512, 3, 1, 1),
+    ('dsn dgrad-like 3x3 512->1024 @48', 8, 512, 48, 48, 1024, 3, 1, 1),
+    ('layer3 dgrad-like 1x1 1024->1024 @48', 8, 1024, 48, 48, 1024, 1, 0, 1),
+    ('bot_aspp 1x1 1280->256 @48', 8, 1280, 48, 48, 256, 1, 0, 1),
+    ('layer3.0.conv2-like 3x3 256->256 @96', 8, 256, 96, 96, 256, 3, 1, 1),
     ('layer2.conv3 1x1 128->512 @96', 8, 128, 96, 96, 512, 1, 0, 1),
     ('layer1.conv3 1x1 64->256 @192', 8, 64, 192, 192, 256, 1, 0, 1),
     ('final1.0 3x3 320->256 @192', 8, 320, 192, 192, 256, 3, 1, 1),
