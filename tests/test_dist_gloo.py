@@ -135,6 +135,30 @@ def test_grad_buckets_average_equals_full_batch_grad():
                 assert torch.allclose(got, p.grad, atol=1e-6, rtol=1e-4)
 
 
+def _counted(rank, world):
+    from pinthememory_amd import dist as D
+    t = torch.full((8,), float(rank + 1))
+    mom = torch.cat([torch.full((4,), float(rank)), torch.ones(4), torch.full((4,), 2.0)])
+
+    def step():
+        D.all_reduce_sum(t.clone())                                   # C3-style in-place sum
+        D.all_reduce_sum_copy(t)                                      # SyncBN backward sums (out of place)
+        D.gather_moments(mom)                                         # SyncBN forward moments
+        D.merge_moments(mom, 4)
+    n = D.count_collectives(step)
+    return n, D.direct_fallback_reason('gloo')
+
+
+def test_collectives_are_counted_identically_on_every_rank():
+    """bench.py's `config.collectives_per_step` / `rccl_direct_reason` (round 5): every exchange helper of dist.py counts itself, the count is the same on every rank,
+    and a non-RCCL backend names itself as the reason torch.distributed carries the exchanges."""
+    res = spawn(_counted)
+    assert [r[0] for r in res] == [4, 4]
+    assert all('gloo' in r[1] and 'torch.distributed' in r[1] for r in res)
+    from pinthememory_amd import dist as D
+    assert D.count_collectives(lambda: D.all_reduce_sum(torch.ones(3))) == 0      # single process: no-ops are not counted
+
+
 def test_single_process_is_a_noop():
     from pinthememory_amd import dist as D
     t = torch.arange(6.0)
