@@ -425,10 +425,14 @@ def dominant_conv_kernel(K, bf16):
     if best is None:
         return None
     r, (mode, bm, bn, km, nst), kprec = best
-    if mode == 5:
-        sym = 'conv16w_kernel<%d, %d, %s>' % (bm, bn, '4, 2' if bm == 256 else '2, 4')
-        what = ('forward / stride-1 data gradient on bf16 activations, wide form: %dx%dx64 tile, eight waves, one block per CU, three-stage LDS ring with counted waits, %s; '
-                'FLOPs = 2*M*N*K executed' % (bm, bn, PREC_NAMES[5]))
+    if mode == 5 and km == 1:
+        sym = 'conv16p_kernel<%d, %d, %s, 4>' % (bm, bn, '4, 2' if bm == 256 else '2, 4')
+        what = ('forward / stride-1 data gradient on bf16 activations, persistent form: one block per CU walks %dx%dx64 tiles, four producer waves keep a three-stage LDS '
+                'ring filled across tile boundaries (counted waits), eight waves multiply, %s; FLOPs = 2*M*N*K executed' % (bm, bn, PREC_NAMES[5]))
+    elif mode == 5:
+        sym = 'conv16w_kernel<%d, %d, %s>' % (bm, bn, '4, 2, 3' if (bm, bn) == (256, 128) else ('2, 4, 3' if (bm, bn) == (128, 256) else '2, 4, 2'))
+        what = ('forward / stride-1 data gradient on bf16 activations, wide form: %dx%dx64 tile, eight waves, one block per CU, %s, %s; '
+                'FLOPs = 2*M*N*K executed' % (bm, bn, 'two LDS stages' if (bm, bn) == (256, 256) else 'three-stage LDS ring with counted waits', PREC_NAMES[5]))
     elif mode == 4:
         sym = 'conv16_kernel<%d, %d, 2, 2, %d>' % (bm, bn, nst)
         what = 'forward / stride-1 data gradient on bf16 activations, %dx%dx64 tile, %s, %s; FLOPs = 2*M*N*K executed' % (

@@ -148,10 +148,11 @@ int pm_set_winograd_fused(int on);
  * staging, swizzled LDS image) on 64-row tiles and single-K-step reductions, the register-staged kernel of rounds 2-3 on 128 x 128 tiles; 2 = LDS-DMA everywhere;
  * 0 = register-staged everywhere (A/B runs and tests). Round 5: the wide form of the LDS-DMA kernel (csrc/conv16w.hip: 256 x 128 / 128 x 256 tile, eight waves, one block
  * per CU, three-stage LDS ring with counted waits) is part of "per shape" (the planner's cost model decides); 2 = LDS-DMA everywhere on the NARROW tiles only,
- * 3 = LDS-DMA everywhere with the wide tile wherever the shape allows it (kernel tests; 7 = the same with its 256 x 256 two-stage form), 4 = per shape without the wide
- * kernel (A/B). The HBM-bound 1x1 convolutions
+ * 3 = LDS-DMA everywhere with the wide tile wherever the shape allows it (kernel tests: the PERSISTENT ring -- one block per CU walks the tiles, four producer waves
+ * fetch ahead across tile boundaries, eight waves multiply; 7 = the same with the 256 x 256 two-stage form, 8 = the ring with one block per tile), 4 = per shape
+ * without the wide kernel (A/B). PM_C16P=0 in the environment keeps the ring out of "per shape" and runs it one block per tile. The HBM-bound 1x1 convolutions
  * with K = 64 / 128 / 256 can take the streaming kernel of csrc/pw16.hip (persistent blocks, weights resident in LDS, 16-byte stores from the accumulators): on every
- * eligible call under 5 (kernel tests), never under 0 / 2 / 3 / 6, under 1 only with PM_PW16=1 in the environment (measured level with the tile kernel: off by default).
+ * eligible call under 5 (kernel tests), never under 0 / 2 / 3 / 6 / 7 / 8, under 1 only with PM_PW16=1 in the environment (measured level with the tile kernel: off by default).
  * Process-wide like pm_set_winograd. */
 int pm_set_conv16(int on);
 /* prec = 2 weight gradients on pixel-contiguous bf16 copies of x (one per tap) and dy instead of the staged-fp32 form: 0 off (default: the

@@ -318,6 +318,7 @@ void launch_tile(const pm_conv16& k, dim3 grid, hipStream_t st) {
 // says it wins: its K-step costs ~1.45 x a 64 x 128 step of the narrow kernel for 4 x the tile, but a partly filled last round costs a whole round, so the model picks
 // the K-split that balances the tiles against the CUs. PM_C16W: 0 never, 1 by the model (default), 2 wherever the shape allows it (A/B runs, kernel tests).
 int g_c16w = getenv("PM_C16W") ? atoi(getenv("PM_C16W")) : 1;
+int g_c16p = getenv("PM_C16P") ? atoi(getenv("PM_C16P")) : 1;      // 1: the ring tiles of conv16w.hip run persistent (producer / consumer waves), and the planner hands them the shapes they win; 0: round-5 first-session routing
 namespace {
 struct WidePick {
   bool ok;
@@ -392,7 +393,12 @@ void pm_conv16_plan(pm_conv16* k) {
     // data-gradient form: 697 narrow, 725-769 on 256 x 128, **778-785**). Not the 72-K-step 3x3 512 -> 512 of layer4 (633 vs 650-700 narrow: 144 tiles), and on the
     // 192 x 192 maps every form sits at 915-958 TF (the decoder's 3x3s stay with the 128 x 128 register-staged kernel).
     const bool wins = k->ksteps >= 128 || (k->Nn >= 2048 && k->ksteps >= 32);
-    const WidePick w = g_c16w >= 2 ? wide_pick(k) : (wins ? wide_pick(k, 2) : WidePick{false, 0, 0, 0, 0});
+    // Second session: the PERSISTENT ring form (conv16w.hip conv16p_kernel: producer waves fetch ahead across tile boundaries). Same box, default routing -> persistent
+    // (profiles/r05_conv16p_probe.txt): decoder 3x3 320 -> 256 @192 0.490 -> 0.423-0.438 ms (1030 TF), 256 -> 256 0.380 -> 0.348-0.355; ASPP 3x3 2048 -> 256 (256 x 256
+    // form) 0.205 -> 0.191; its data-gradient form 256 -> 2048 0.225 -> 0.205. Not the 1024 -> 512 3x3 of the auxiliary head (0.222 on 256 x 256 vs 0.229-0.241), the
+    // 72-K-step 3x3 512 -> 512 (0.126 narrow vs 0.138-0.145) or the short 1x1 reductions (the epilogue of a tile is not overlapped with anything).
+    const bool ring_wins = g_c16p && ((k->M >= 200000 && k->ksteps >= 32 && k->Nn >= 256) || (k->ksteps >= 128 && k->Nn <= 256) || (k->Nn >= 2048 && k->ksteps >= 32));
+    const WidePick w = g_c16w >= 2 ? wide_pick(k) : (ring_wins ? wide_pick(k) : (wins ? wide_pick(k, 2) : WidePick{false, 0, 0, 0, 0}));
     if (w.ok) {
       k->wide = 1, k->bm = w.bm, k->bn = w.bn;
       k->tiles_m = pm_cdiv(k->M, k->bm), k->tiles_n = pm_cdiv(k->Nn, k->bn);

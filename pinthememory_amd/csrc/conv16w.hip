@@ -17,6 +17,8 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+extern int g_c16p;      // conv16.hip (PM_C16P): the ring tiles run in their persistent producer / consumer form
+
 namespace {
 
 constexpr int BKB = 128;      // bytes per row and K-step (64 bf16)
@@ -310,6 +312,331 @@ __global__ __launch_bounds__(NT, 2) void conv16w_kernel(const pm_conv16 a) {
   }
 }
 
+// ---- the PERSISTENT form (round 5, second session) ------------------------------------------------------------------------------------------------------------
+// One block per CU walks a sequence of output tiles; four PRODUCER waves do nothing but issue the LDS-DMA fetches of a three-stage ring that runs on across tile
+// boundaries (and own the index arithmetic of the A rows); the eight multiplying waves read fragments, issue MFMAs and write the tile out.
+// Why (profiles/r05_decoder3x3_ta_tcp_sq_counters.txt): with one 144 KB block per CU nothing hides a tile's prologue -- every block asks for its first 96 KB at the
+// same moment and waits ~9 k clocks for them, 18 % of the kernel on the decoder's 3x3 -- and a 1 KB fetch instruction holds its wave's issue for 60-185 clocks beside
+// the MFMAs of the same wave. Here the first stages of tile i + 1 are in flight while tile i is multiplied and written out, and a stalled fetch blocks nobody else.
+// Synchronisation is ONE s_barrier per K-step for all twelve waves, plus one per tile in front of the epilogue (which parks accumulators in the ring slot that was
+// read last -- the producers refill it only behind the NEXT step's barrier):
+//   step g:  producers wait until their part of stage g has landed (counted vmcnt: stage g + 1 stays in flight) | barrier | producers issue stage g + 2 into the slot
+//            of stage g - 1, consumers multiply stage g.
+// Same operands, addressing, tap skipping and epilogue arithmetic as the kernels above; split-K slabs and fp32 outputs included.
+__device__ __forceinline__ int tile_ksteps(const pm_conv16& a, int m0, int BM, int kt0, int nk, int cpc, bool pointwise, unsigned& ky_ok) {
+  ky_ok = ~0u;
+  if (!pointwise && a.kh > 1) {
+    const int hw = a.Ho * a.Wo, ml = min(m0 + BM, a.M) - 1;
+    const int ia = m0 / hw, ib = ml / hw;
+    if (ia == ib) {
+      const int oy_a = (m0 - ia * hw) / a.Wo, oy_b = (ml - ib * hw) / a.Wo;
+      ky_ok = 0;
+      for (int ky = 0; ky < a.kh; ++ky)
+        if (oy_b * a.stride - a.pad + ky * a.dil >= 0 && oy_a * a.stride - a.pad + ky * a.dil < a.H) ky_ok |= 1u << ky;
+    }
+  }
+  ky_ok = __builtin_amdgcn_readfirstlane(ky_ok);
+  int nk_eff = nk;
+  if (ky_ok != ~0u) {
+    nk_eff = 0;
+    for (int kt = kt0; kt < kt0 + nk;) {
+      const int tap = kt / cpc, run = min(kt0 + nk, (tap + 1) * cpc) - kt;
+      if ((ky_ok >> (tap / a.kw)) & 1u) nk_eff += run;
+      kt += run;
+    }
+  }
+  return __builtin_amdgcn_readfirstlane(nk_eff);
+}
+
+__device__ __forceinline__ void ring_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int BM, int BN, int WM, int WN, int NP>
+__global__ __launch_bounds__((8 + NP) * 64, (8 + NP) / 4) void conv16p_kernel(const pm_conv16 a) {
+  static_assert(WM * WN == 8, "eight multiplying waves");
+  constexpr int FT = NP * 64;                                // fetching threads
+  constexpr int A_IT = BM * 8 / FT, B_IT = BN * 8 / FT;      // 16-byte fetches per producer lane and K-step
+  constexpr int FETCH = A_IT + B_IT;
+  constexpr int A_BYTES = BM * BKB, STAGE = (BM + BN) * BKB;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int LDS_SUB = 36;                                // floats per row of a 32 x 32 epilogue slab
+  static_assert(8 * 32 * LDS_SUB * 4 <= STAGE, "the epilogue slabs of the eight waves live in one ring slot");
+  extern __shared__ __align__(16) char lds[];
+
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int ntiles = a.tiles_m * a.tiles_n, total = ntiles * a.ksplit, G = gridDim.x;
+  const long pitchb = a.a_pitch * 2;
+  const int cpc = a.Cp >> 6;
+  const bool pointwise = a.kh * a.kw == 1 && a.stride == 1 && a.pad == 0 && a.Ho == a.H && a.Wo == a.W;
+  auto decode = [&](int v, int& m0, int& n0, int& z, int& kt0, int& nk) {
+    z = v / ntiles;
+    const int lid = xcd_remap_w(v - z * ntiles, ntiles);
+    m0 = (lid / a.tiles_n) * BM, n0 = (lid % a.tiles_n) * BN;
+    kt0 = z * a.ksteps_per, nk = min(a.ksteps - kt0, a.ksteps_per);
+  };
+
+  if (wave >= 8) {
+    // ================================================== producer waves ==================================================
+    const int wave_u = wave - 8, t = wave_u * 64 + lane;
+    const __amdgpu_buffer_rsrc_t rA =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<pm_bf16*>(a.A), 0, (int)((long)a.N * a.H * a.W * pitchb), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<pm_bf16*>(a.B), 0, (int)((long)a.Nn * a.K * 2), 0x00020000);
+    constexpr int OOB = 0x7fffffff;
+    int aoff[A_IT], ay0[A_IT], ax0[A_IT], cur[A_IT], boff[B_IT];
+    int s_ch = 0, s_ky = 0, s_kx = 0, s_kb = 0, s_fresh = 1, left = 0;
+    unsigned ky_ok = ~0u;
+    int vf = blockIdx.x;      // the tile being fetched (runs ahead of the tile being multiplied)
+    auto skip_taps = [&]() {
+      while (s_ky < a.kh && !((ky_ok >> s_ky) & 1u)) {
+        s_kb += (cpc - s_ch) * BKB;
+        s_ch = 0;
+        if (++s_kx == a.kw) s_kx = 0, ++s_ky;
+      }
+    };
+    auto open_tile = [&]() {      // fetch state of tile vf, or of the next one with something to fetch; left == 0 afterwards: no tile is left
+      for (; vf < total; vf += G) {
+        int m0, n0, z, kt0, nk;
+        decode(vf, m0, n0, z, kt0, nk);
+        left = tile_ksteps(a, m0, BM, kt0, nk, cpc, pointwise, ky_ok);
+        if (left == 0) continue;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+          const int u = it * FT + t, row = u >> 3, ch = (u & 7) ^ ((row >> 1) & 7);
+          const int m = m0 + row;
+          if (m < a.M && pointwise) {
+            ay0[it] = ax0[it] = 0;
+            aoff[it] = (int)((long)m * pitchb) + ch * 16;
+          } else if (m < a.M) {
+            const int img = m / (a.Ho * a.Wo), rem = m - img * (a.Ho * a.Wo);
+            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            ay0[it] = oy * a.stride - a.pad, ax0[it] = ox * a.stride - a.pad;
+            aoff[it] = (int)(((long)(img * a.H + ay0[it]) * a.W + ax0[it]) * pitchb) + ch * 16;      // may be negative at the border: only used with an in-range tap added
+          } else {
+            ay0[it] = ax0[it] = -(1 << 28);      // never inside the image: the row reads zeros
+            aoff[it] = 0;
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+          const int u = it * FT + t, row = u >> 3, ch = (u & 7) ^ ((row >> 1) & 7);
+          const int n = n0 + row;
+          boff[it] = n < a.Nn ? n * a.K * 2 + ch * 16 : OOB;
+        }
+        const int tap0 = kt0 / cpc;
+        s_ch = __builtin_amdgcn_readfirstlane(kt0 - tap0 * cpc);
+        s_ky = __builtin_amdgcn_readfirstlane(tap0 / a.kw);
+        s_kx = __builtin_amdgcn_readfirstlane(tap0 - s_ky * a.kw);
+        s_kb = kt0 * BKB;
+        if (ky_ok != ~0u) skip_taps();
+        s_fresh = 1;
+        return;
+      }
+      left = 0;
+    };
+    int slot = 0;      // ring slot of the next stage
+    auto issue = [&]() -> int {      // one more stage of the flat (tile, K-step) sequence; 0 when the sequence is over
+      if (left == 0) {
+        if (vf >= total) return 0;
+        vf += G;
+        open_tile();
+        if (left == 0) return 0;
+      }
+      char* la = lds + slot * STAGE;
+      char* lb = la + A_BYTES;
+      if (s_fresh) {      // border test and pixel offset of the tap: once per tap; the 64-channel chunk rides in the scalar offset of the fetch
+        const int dy = s_ky * a.dil, dx = s_kx * a.dil;
+        const int toff = (dy * a.W + dx) * (int)pitchb;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+          const bool ok = ((unsigned)(ay0[it] + dy) < (unsigned)a.H) & ((unsigned)(ax0[it] + dx) < (unsigned)a.W);
+          cur[it] = ok ? aoff[it] + toff : OOB;
+        }
+        s_fresh = 0;
+      }
+      const int s_cb = s_ch * BKB;
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it) dma16w(rA, la + (it * FT + wave_u * 64) * 16, cur[it], s_cb);
+#pragma unroll
+      for (int it = 0; it < B_IT; ++it) dma16w(rB, lb + (it * FT + wave_u * 64) * 16, boff[it], s_kb);
+      s_kb += BKB;
+      if (++s_ch == cpc) {
+        s_ch = 0;
+        if (++s_kx == a.kw) s_kx = 0, ++s_ky;
+        if (ky_ok != ~0u) skip_taps();
+        s_fresh = 1;
+      }
+      --left;
+      slot = slot == 2 ? 0 : slot + 1;
+      return 1;
+    };
+    open_tile();
+    int ahead = issue();      // stages issued and not yet handed over
+    ahead += issue();
+    for (int vc = blockIdx.x; vc < total; vc += G) {      // mirror of the multiplying waves' barrier sequence
+      int m0, n0, z, kt0, nk;
+      unsigned dummy;
+      decode(vc, m0, n0, z, kt0, nk);
+      const int nk_c = tile_ksteps(a, m0, BM, kt0, nk, cpc, pointwise, dummy);
+      for (int kt = 0; kt < nk_c; ++kt) {
+        if (ahead >= 2) wait_vm<FETCH>();      // the oldest stage in flight has landed, the younger one may still fly
+        else wait_vm<0>();
+        ring_barrier();
+        ahead += issue() - 1;
+      }
+      ring_barrier();      // the tile's epilogue barrier
+    }
+    return;
+  }
+
+  // ================================================== multiplying waves ==================================================
+  const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, half = lane >> 5;
+  int ra_off[TM], ra_key[TM], rb_off[TN], rb_key[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int ra = wm * (BM / WM) + i * 32 + l31;
+    ra_off[i] = ra * BKB, ra_key[i] = (ra >> 1) & 7;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int rb = wn * (BN / WN) + j * 32 + l31;
+    rb_off[j] = A_BYTES + rb * BKB, rb_key[j] = (rb >> 1) & 7;
+  }
+  int rd = 0;      // ring slot of the next stage to multiply
+  for (int vc = blockIdx.x; vc < total; vc += G) {
+    int m0, n0, z, kt0, nk;
+    unsigned dummy;
+    decode(vc, m0, n0, z, kt0, nk);
+    const int nk_c = tile_ksteps(a, m0, BM, kt0, nk, cpc, pointwise, dummy);
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    for (int kt = 0; kt < nk_c; ++kt) {
+      ring_barrier();
+      const char* ls = lds + rd * STAGE;
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg) {
+        const int c = kg * 2 + half;
+        bf16x8 fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(ls + ra_off[i] + ((c ^ ra_key[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(ls + rb_off[j] + ((c ^ rb_key[j]) << 4));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+      rd = rd == 2 ? 0 : rd + 1;
+    }
+    // ---- epilogue: 32 x 32 slabs of the wave's tile through the ring slot read last (free until the producers pass the next step's barrier) ----
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    ring_barrier();
+    float* Ws = reinterpret_cast<float*>(lds + (rd == 0 ? 2 : rd - 1) * STAGE) + wave * 32 * LDS_SUB;
+    const bool slab = a.ksplit > 1;
+    if (a.c_f32 || slab) {      // fp32 rows: split-K slabs (no epilogue arithmetic) or class logits (bias only)
+      float* Cf = reinterpret_cast<float*>(a.C) + (slab ? (long)z * a.c_split : 0);
+      const long cp = slab ? a.Nn : a.c_pitch;
+      const int rr0 = lane >> 3, cc = (lane & 7) * 4;      // eight lanes per 32-column row, eight rows per sweep
+#pragma unroll
+      for (int n = 0; n < TN; ++n) {
+        const int col = n0 + wn * (BN / WN) + n * 32 + cc;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) Ws[((q & 3) + 8 * (q >> 2) + 4 * half) * LDS_SUB + l31] = acc[i][n][q];
+#pragma unroll
+          for (int r0 = 0; r0 < 32; r0 += 8) {
+            const int rr = r0 + rr0;
+            const long row = m0 + wm * (BM / WM) + i * 32 + rr;
+            const float4 v = *reinterpret_cast<const float4*>(Ws + rr * LDS_SUB + cc);
+            if (row >= a.M) continue;
+            const float e[4] = {v.x, v.y, v.z, v.w};
+            if (((cp | a.Nn) & 3) == 0 && col + 4 <= a.Nn && !a.bias) PM_ST4(Cf + row * cp + col, v);
+            else {
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                if (col + k < a.Nn) Cf[row * cp + col + k] = e[k] + ((a.bias && !slab) ? a.bias[col + k] : 0.f);
+            }
+          }
+        }
+      }
+      continue;
+    }
+    {
+      const int rr0 = lane >> 2, cc = (lane & 3) * 8;      // four lanes per 32-column row (8 channels = 16 bytes each), sixteen rows per sweep
+      const bool aff = a.bias || a.scale, res = a.residual != nullptr, relu = a.relu != 0;
+      pm_bf16* C16 = reinterpret_cast<pm_bf16*>(a.C);
+      const pm_bf16* R16 = reinterpret_cast<const pm_bf16*>(a.residual);
+#pragma unroll
+      for (int n = 0; n < TN; ++n) {
+        const int col = n0 + wn * (BN / WN) + n * 32 + cc;
+        const bool cok = col < a.Nn;
+        float bi[8], sc[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bi[e] = 0.f, sc[e] = 1.f, sh[e] = 0.f;
+        if (aff && cok) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if (a.bias) bi[e] = a.bias[col + e];
+            if (a.scale) sc[e] = a.scale[col + e], sh[e] = a.shift[col + e];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) Ws[((q & 3) + 8 * (q >> 2) + 4 * half) * LDS_SUB + l31] = acc[i][n][q];
+#pragma unroll
+          for (int r0 = 0; r0 < 32; r0 += 16) {
+            const int rr = r0 + rr0;
+            const long row = m0 + wm * (BM / WM) + i * 32 + rr;
+            const float4 v0 = *reinterpret_cast<const float4*>(Ws + rr * LDS_SUB + cc), v1 = *reinterpret_cast<const float4*>(Ws + rr * LDS_SUB + cc + 4);
+            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            if (row < a.M && cok) {
+              if (aff) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (v[e] + bi[e]) * sc[e] + sh[e];
+              }
+              if (res) {
+                float q[8];
+                pm_ld8(R16 + row * a.res_pitch + col, q);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += q[e];
+              }
+              if (relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+              }
+              pm_st8(C16 + row * a.c_pitch + col, v);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int NP>
+void launch_persistent(const pm_conv16& k, hipStream_t st) {
+  constexpr size_t smem = (size_t)3 * (BM + BN) * BKB;
+  static_assert(smem <= 160 * 1024, "LDS budget");
+  static const int ncu = [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv16p_kernel<BM, BN, WM, WN, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  const int total = k.tiles_m * k.tiles_n * k.ksplit;
+  hipLaunchKernelGGL((conv16p_kernel<BM, BN, WM, WN, NP>), dim3(std::min(total, ncu)), dim3((8 + NP) * 64), smem, st, k);
+}
+
 template <int BM, int BN, int WM, int WN, int NST>
 void launch_wide(const pm_conv16& k, dim3 grid, hipStream_t st) {
   constexpr size_t stage_bytes = (size_t)NST * (BM + BN) * BKB, ep_bytes = (size_t)8 * 32 * (BN / WN + 4) * sizeof(float);
@@ -325,10 +652,15 @@ void launch_wide(const pm_conv16& k, dim3 grid, hipStream_t st) {
 
 }  // namespace
 
+// 1 when pm_conv16w_launch runs this plan in the persistent producer / consumer form (the ring tiles with PM_C16P != 0), 0 for one block per tile
+int pm_conv16w_persistent(const pm_conv16* k) { return g_c16p && k->wide && ((k->bm == 256 && k->bn == 128) || (k->bm == 128 && k->bn == 256)) ? 1 : 0; }
+
 int pm_conv16w_launch(const pm_conv16* k0, hipStream_t st) {
   pm_conv16 k = *k0;
   dim3 grid(k.tiles_m * k.tiles_n, 1, k.ksplit);
-  if (k.bm == 256 && k.bn == 128) launch_wide<256, 128, 4, 2, 3>(k, grid, st);
+  if (k.bm == 256 && k.bn == 128 && g_c16p) launch_persistent<256, 128, 4, 2, 4>(k, st);
+  else if (k.bm == 128 && k.bn == 256 && g_c16p) launch_persistent<128, 256, 2, 4, 4>(k, st);
+  else if (k.bm == 256 && k.bn == 128) launch_wide<256, 128, 4, 2, 3>(k, grid, st);
   else if (k.bm == 128 && k.bn == 256) launch_wide<128, 256, 2, 4, 3>(k, grid, st);
   else if (k.bm == 256 && k.bn == 256) launch_wide<256, 256, 2, 4, 2>(k, grid, st);
   else {

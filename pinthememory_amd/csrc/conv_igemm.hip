@@ -1547,7 +1547,7 @@ int conv_bf16(const pm_tensor* xin, const float* w, int w_cout, int w_cin, bool 
       ProfRec rec;
       if (g_prof_on) {
         (void)hipEventCreate(&rec.a), (void)hipEventCreate(&rec.b);
-        rec.mode = k.wide ? 5 : 4, rec.bm = k.bm, rec.bn = k.bn, rec.km = 0, rec.prec = 5, rec.nst = k.wide ? 3 : (k.ksteps_per == 1 ? 1 : 2), rec.M = k.M, rec.Nn = k.Nn, rec.K = k.K / 2, rec.batch = 1,
+        rec.mode = k.wide ? 5 : 4, rec.bm = k.bm, rec.bn = k.bn, rec.km = pm_conv16w_persistent(&k), rec.prec = 5, rec.nst = k.wide ? 3 : (k.ksteps_per == 1 ? 1 : 2), rec.M = k.M, rec.Nn = k.Nn, rec.K = k.K / 2, rec.batch = 1,
         rec.ksplit = k.ksplit, rec.flops = fl;
         (void)hipEventRecord(rec.a, st);
       }
@@ -1766,13 +1766,16 @@ extern "C" int pm_set_winograd(int mode) {
 }
 extern int g_c16w;      // conv16.hip: 0 never the wide (conv16w.hip) kernel, 1 by the planner's cost model, 2 wherever the shape allows it
 extern int g_pw16;      // pw16.hip: 0 never the streaming 1x1 kernel, 1 by size, 2 every eligible 1x1
+extern int g_c16p;      // conv16.hip: 1 the ring tiles of conv16w.hip run persistent (producer / consumer waves), 0 one block per tile
 extern "C" int pm_set_conv16(int on) {
-  PM_REQUIRE(on >= 0 && on <= 7, PM_EINVAL, "pm_set_conv16: %d (0 register-staged, 1 per shape, 2 LDS-DMA everywhere / narrow tiles only, 3 LDS-DMA everywhere / wide tiles "
-             "wherever the shape allows, 4 per shape without the wide kernel, 5 per shape with the streaming 1x1 kernel on every eligible call, 6 per shape without it, 7 as 3 with the 256 x 256 tile)", on);
-  static const int c16w_default = g_c16w, pw16_default = g_pw16;
-  g_conv16 = (on == 3 || on == 7) ? 2 : ((on == 4 || on == 5 || on == 6) ? 1 : on);
-  g_c16w = on == 3 ? 2 : (on == 7 ? 3 : ((on == 2 || on == 4) ? 0 : c16w_default));
-  g_pw16 = on == 5 ? 2 : ((on == 0 || on == 2 || on == 3 || on == 6 || on == 7) ? 0 : pw16_default);
+  PM_REQUIRE(on >= 0 && on <= 8, PM_EINVAL, "pm_set_conv16: %d (0 register-staged, 1 per shape, 2 LDS-DMA everywhere / narrow tiles only, 3 LDS-DMA everywhere / wide tiles "
+             "wherever the shape allows, 4 per shape without the wide kernel, 5 per shape with the streaming 1x1 kernel on every eligible call, 6 per shape without it, 7 as 3 with the 256 x 256 tile, "
+             "8 as 3 with one block per tile instead of the persistent ring)", on);
+  static const int c16w_default = g_c16w, pw16_default = g_pw16, c16p_default = g_c16p;
+  g_conv16 = (on == 3 || on == 7 || on == 8) ? 2 : ((on == 4 || on == 5 || on == 6) ? 1 : on);
+  g_c16w = (on == 3 || on == 8) ? 2 : (on == 7 ? 3 : ((on == 2 || on == 4) ? 0 : c16w_default));
+  g_c16p = on == 8 ? 0 : (on == 3 ? 1 : c16p_default);
+  g_pw16 = on == 5 ? 2 : ((on == 0 || on == 2 || on == 3 || on == 6 || on == 7 || on == 8) ? 0 : pw16_default);
   return PM_OK;
 }
 extern "C" int pm_set_winograd_fused(int on) {

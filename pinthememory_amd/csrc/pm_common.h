@@ -112,10 +112,11 @@ struct pm_conv16 {
   float* stats;              // train-mode BatchNorm statistics of the bf16 output: (mean, M2) per 32-row slab and channel (pm_conv_epilogue.bn_partials), or null
   int bm, bn, tiles_m, tiles_n, ksplit, ksteps_per;      // pm_conv16_plan
   long c_split;
-  int wide;                  // pm_conv16_plan: 1 = the eight-wave 256 x 128 / 128 x 256 ring kernel of conv16w.hip takes the call (one block per CU)
+  int wide;                  // pm_conv16_plan: 1 = a kernel of conv16w.hip takes the call (one block per CU): 256 x 256 two-stage, or the 256 x 128 / 128 x 256 ring (persistent)
 };
 void pm_conv16_plan(pm_conv16* k);
 int pm_conv16w_launch(const pm_conv16* k, hipStream_t st);
+int pm_conv16w_persistent(const pm_conv16* k);      // 1: the plan runs in the persistent producer / consumer form of conv16w.hip
 size_t pm_conv16_slab_bytes(const pm_conv16* k);
 double pm_conv16_executed_fraction(const pm_conv16* k);
 int pm_conv16_launch(const pm_conv16* k, hipStream_t st);

@@ -853,7 +853,9 @@ def set_winograd_fused(on):
 
 
 def set_conv16(on):
-    """bf16 tier, forward / stride-1 data gradient: 1 = per shape (default: the LDS-DMA kernel where it wins), 2 = LDS-DMA everywhere, 0 = register-staged everywhere."""
+    """bf16 tier, forward / stride-1 data gradient: 1 = per shape (default: the LDS-DMA kernels where they win), 2 = LDS-DMA everywhere on the narrow tiles,
+    0 = register-staged everywhere; 3 / 7 / 8 = the wide kernels wherever the shape allows (persistent ring / 256 x 256 / ring with one block per tile), 4-6 A/B
+    routes (include/pinmem_hip.h pm_set_conv16)."""
     check(_lib().pm_set_conv16(int(on)), 'pm_set_conv16')
     _GEN[0] += 1
 

@@ -899,7 +899,7 @@ ACT16_CASES = [CONV_CASES[0], CONV_CASES[1], CONV_CASES[3], CONV_CASES[4], CONV_
                (1, 512, 12, 12, 512, 3, 1, 2, 2, False)]
 
 
-@pytest.mark.parametrize('route', ['lds_dma', 'lds_dma_wide', 'lds_dma_256', 'reg_staged'])
+@pytest.mark.parametrize('route', ['lds_dma', 'lds_dma_wide', 'lds_dma_ring', 'lds_dma_256', 'reg_staged'])
 @pytest.mark.parametrize('case', ACT16_CASES)
 def test_conv_bf16_activations(K, case, route):
     """BASELINE configs[2], round 4: bf16 tensors in, bf16 tensors out (x, y, dy, dx), fp32 weights / dw, fp32 accumulation. Oracle: the fp32 convolution of
@@ -912,8 +912,9 @@ def test_conv_bf16_activations(K, case, route):
     dy = r16(rnd(*y_ref.shape, seed=4))
     skip = r16(rnd(n, cin, h, w, seed=5))
     K.set_conv_precision('bf16')
-    # csrc/conv16.hip on every shape (2: its narrow tiles, 3: the wide eight-wave ring kernel of conv16w.hip, round 5), or the register-staged kernel on bf16 rows
-    K.set_conv16({'lds_dma': 2, 'lds_dma_wide': 3, 'lds_dma_256': 7}.get(route, 0))
+    # csrc/conv16.hip on every shape (2: its narrow tiles; conv16w.hip: 3 the persistent producer / consumer ring, 8 the ring with one block per tile, 7 the 256 x 256
+    # two-stage form), or the register-staged kernel on bf16 rows
+    K.set_conv16({'lds_dma': 2, 'lds_dma_wide': 3, 'lds_dma_ring': 8, 'lds_dma_256': 7}.get(route, 0))
     try:
         wg = wt.permute(0, 2, 3, 1).contiguous().cuda()
         xg = K.new((n, h, w, cin), wg, dtype=torch.bfloat16)      # zero-padded + registered when cin % 64 != 0 (304): gathered in place
@@ -965,7 +966,7 @@ def test_conv16_on_the_48x48_maps(K, case):
     outs = {}
     try:
         wg = wt.permute(0, 2, 3, 1).contiguous().cuda()
-        for route in (2, 3, 7, 0):      # narrow LDS-DMA tiles, the wide ring kernel (conv16w.hip), its 256 x 256 two-stage form, the register-staged kernel
+        for route in (2, 3, 8, 7, 0):      # narrow LDS-DMA tiles; conv16w.hip: persistent ring, ring with one block per tile, 256 x 256 two-stage form; the register-staged kernel
             K.set_conv16(route)
             if logits:
                 y = K.conv_fwd(b16(x), wg, 1, p, d, bias=b.cuda(), out_dtype=torch.float32)
@@ -981,7 +982,8 @@ def test_conv16_on_the_48x48_maps(K, case):
     if logits:
         assert outs[2][0].dtype == torch.float32
         assert rel(nchw(outs[2][0]), y_lin + b.view(1, -1, 1, 1)) < 2e-5 and rel(outs[2][0], outs[0][0]) < 2e-5
-        assert rel(nchw(outs[3][0]), y_lin + b.view(1, -1, 1, 1)) < 2e-5 and rel(nchw(outs[7][0]), y_lin + b.view(1, -1, 1, 1)) < 2e-5
+        for r in (3, 8, 7):
+            assert rel(nchw(outs[r][0]), y_lin + b.view(1, -1, 1, 1)) < 2e-5, r
         return
     y0, y1, dx = outs[2]
     close16(nchw(y0.float()), y_lin + b.view(1, -1, 1, 1), ulps=1.5)
@@ -999,6 +1001,8 @@ def test_conv16_on_the_48x48_maps(K, case):
         close16(a.float(), c.float(), ulps=2.5)
     for a, c in zip(outs[7], outs[2]):      # the 256 x 256 form: same sums in another order
         close16(a.float(), c.float(), ulps=2.5)
+    for a, c in zip(outs[8], outs[3]):      # the ring with one block per tile against its persistent form: same tiles, same K order, same epilogue arithmetic
+        assert torch.equal(a, c)
 
 
 PW16_CASES = [  # n, cin, h, w, cout: pointwise, K = 64 / 128 / 256 after padding

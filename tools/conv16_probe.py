@@ -23,6 +23,9 @@ SHAPES = [  # name, n, cin, h, w, cout, k, pad, dil
     ('final1.0 3x3 320->256 @192', 8, 320, 192, 192, 256, 3, 1, 1),
     ('layer2.conv2 3x3 128->128 @96', 8, 128, 96, 96, 128, 3, 1, 1),
     ('final1.3 3x3 256->256 @192', 8, 256, 192, 192, 256, 3, 1, 1),
+    ('final1.0 dgrad-like 3x3 256->320 @192', 8, 256, 192, 192, 320, 3, 1, 1),
+    ('aspp d6 3x3 2048->256 @48', 8, 2048, 48, 48, 256, 3, 6, 6),
+    ('aspp d18 3x3 2048->256 @48', 8, 2048, 48, 48, 256, 3, 18, 18),
 ]
 K.set_conv_precision('bf16')
 if os.environ.get('PROBE_CONV16'):
