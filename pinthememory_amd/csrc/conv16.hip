@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const pm_conv16 a) {
         if (oy_b * a.stride - a.pad + ky * a.dil >= 0 && oy_a * a.stride - a.pad + ky * a.dil < a.H) ky_ok |= 1u << ky;
     }
   }
+  if (ky_ok == (1u << a.kh) - 1u) ky_ok = ~0u;      // every filter row is visible (all interior tiles): no skipping, none of its per-tap bookkeeping, no K-step recount
   ky_ok = __builtin_amdgcn_readfirstlane(ky_ok);
   int nk_eff = nk;      // K-steps this block really runs: its range [kt0, kt0 + nk) minus the chunks of invisible taps
   if (ky_ok != ~0u) {

@@ -107,6 +107,7 @@ __global__ __launch_bounds__(NT, 2) void conv16w_kernel(const pm_conv16 a) {
         if (oy_b * a.stride - a.pad + ky * a.dil >= 0 && oy_a * a.stride - a.pad + ky * a.dil < a.H) ky_ok |= 1u << ky;
     }
   }
+  if (ky_ok == (1u << a.kh) - 1u) ky_ok = ~0u;      // every filter row is visible (all interior tiles): no skipping, none of its per-tap bookkeeping, no K-step recount
   ky_ok = __builtin_amdgcn_readfirstlane(ky_ok);
   int nk_eff = nk;
   if (ky_ok != ~0u) {
@@ -335,6 +336,7 @@ __device__ __forceinline__ int tile_ksteps(const pm_conv16& a, int m0, int BM, i
         if (oy_b * a.stride - a.pad + ky * a.dil >= 0 && oy_a * a.stride - a.pad + ky * a.dil < a.H) ky_ok |= 1u << ky;
     }
   }
+  if (ky_ok == (1u << a.kh) - 1u) ky_ok = ~0u;      // every filter row is visible (all interior tiles): no skipping, none of its per-tap bookkeeping, no K-step recount
   ky_ok = __builtin_amdgcn_readfirstlane(ky_ok);
   int nk_eff = nk;
   if (ky_ok != ~0u) {
@@ -346,6 +348,18 @@ __device__ __forceinline__ int tile_ksteps(const pm_conv16& a, int m0, int BM, i
     }
   }
   return __builtin_amdgcn_readfirstlane(nk_eff);
+}
+
+// 16-byte stores the compiler's wait bookkeeping does not see. Beside LDS-DMA hipcc puts s_waitcnt vmcnt(0) in front of an LDS read while ANY vector-memory operation of
+// the wave is pending: with ordinary stores the first fragment read of the NEXT tile waits until this tile's output has been acknowledged by L2 (1-2 us per tile).
+// Nothing reads these addresses again inside the kernel, and a wave's stores complete whatever it does next.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st16_untracked(void* p, u32x4 q) { asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(q) : "memory"); }
+__device__ __forceinline__ void st4_untracked(float* p, float v) { asm volatile("global_store_dword %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st8_bf16_untracked(pm_bf16* p, const float* v) {
+  u32x4 q;
+  q.x = pm_pack_bf16(v[0], v[1]), q.y = pm_pack_bf16(v[2], v[3]), q.z = pm_pack_bf16(v[4], v[5]), q.w = pm_pack_bf16(v[6], v[7]);
+  st16_untracked(p, q);
 }
 
 __device__ __forceinline__ void ring_barrier() {
@@ -403,21 +417,34 @@ __global__ __launch_bounds__((8 + NP) * 64, (8 + NP) / 4) void conv16p_kernel(co
         decode(vf, m0, n0, z, kt0, nk);
         left = tile_ksteps(a, m0, BM, kt0, nk, cpc, pointwise, ky_ok);
         if (left == 0) continue;
+        // this lane's rows: piece `it` is row it * FT / 8 + (t >> 3) of the tile. ONE index decomposition (two integer divisions) per tile; the other pieces step on from it
+        constexpr int RSTEP = FT / 8;
+        int m = m0 + (t >> 3), img = 0, oy = 0, ox = 0;
+        if (!pointwise) {
+          img = m / (a.Ho * a.Wo);
+          const int rem = m - img * (a.Ho * a.Wo);
+          oy = rem / a.Wo, ox = rem - oy * a.Wo;
+        }
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-          const int u = it * FT + t, row = u >> 3, ch = (u & 7) ^ ((row >> 1) & 7);
-          const int m = m0 + row;
+          const int row = it * RSTEP + (t >> 3), ch = (t & 7) ^ ((row >> 1) & 7);
           if (m < a.M && pointwise) {
             ay0[it] = ax0[it] = 0;
             aoff[it] = (int)((long)m * pitchb) + ch * 16;
           } else if (m < a.M) {
-            const int img = m / (a.Ho * a.Wo), rem = m - img * (a.Ho * a.Wo);
-            const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
             ay0[it] = oy * a.stride - a.pad, ax0[it] = ox * a.stride - a.pad;
             aoff[it] = (int)(((long)(img * a.H + ay0[it]) * a.W + ax0[it]) * pitchb) + ch * 16;      // may be negative at the border: only used with an in-range tap added
           } else {
             ay0[it] = ax0[it] = -(1 << 28);      // never inside the image: the row reads zeros
             aoff[it] = 0;
+          }
+          m += RSTEP;
+          if (!pointwise) {
+            ox += RSTEP;
+            while (ox >= a.Wo) {
+              ox -= a.Wo;
+              if (++oy == a.Ho) oy = 0, ++img;
+            }
           }
         }
 #pragma unroll
@@ -559,11 +586,11 @@ __global__ __launch_bounds__((8 + NP) * 64, (8 + NP) / 4) void conv16p_kernel(co
             const float4 v = *reinterpret_cast<const float4*>(Ws + rr * LDS_SUB + cc);
             if (row >= a.M) continue;
             const float e[4] = {v.x, v.y, v.z, v.w};
-            if (((cp | a.Nn) & 3) == 0 && col + 4 <= a.Nn && !a.bias) PM_ST4(Cf + row * cp + col, v);
+            if (((cp | a.Nn) & 3) == 0 && col + 4 <= a.Nn && !a.bias) st16_untracked(Cf + row * cp + col, u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)});
             else {
 #pragma unroll
               for (int k = 0; k < 4; ++k)
-                if (col + k < a.Nn) Cf[row * cp + col + k] = e[k] + ((a.bias && !slab) ? a.bias[col + k] : 0.f);
+                if (col + k < a.Nn) st4_untracked(Cf + row * cp + col + k, e[k] + ((a.bias && !slab) ? a.bias[col + k] : 0.f));
             }
           }
         }
@@ -575,20 +602,25 @@ __global__ __launch_bounds__((8 + NP) * 64, (8 + NP) / 4) void conv16p_kernel(co
       const bool aff = a.bias || a.scale, res = a.residual != nullptr, relu = a.relu != 0;
       pm_bf16* C16 = reinterpret_cast<pm_bf16*>(a.C);
       const pm_bf16* R16 = reinterpret_cast<const pm_bf16*>(a.residual);
+      // the per-channel constants of BOTH 32-column groups are fetched before the first store of the tile: a register load issued behind a store would wait for it
+      float bi[TN][8], sc[TN][8], sh[TN][8];
+#pragma unroll
+      for (int n = 0; n < TN; ++n) {
+        const int col = n0 + wn * (BN / WN) + n * 32 + cc;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bi[n][e] = 0.f, sc[n][e] = 1.f, sh[n][e] = 0.f;
+        if (aff && col < a.Nn) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if (a.bias) bi[n][e] = a.bias[col + e];
+            if (a.scale) sc[n][e] = a.scale[col + e], sh[n][e] = a.shift[col + e];
+          }
+        }
+      }
 #pragma unroll
       for (int n = 0; n < TN; ++n) {
         const int col = n0 + wn * (BN / WN) + n * 32 + cc;
         const bool cok = col < a.Nn;
-        float bi[8], sc[8], sh[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bi[e] = 0.f, sc[e] = 1.f, sh[e] = 0.f;
-        if (aff && cok) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            if (a.bias) bi[e] = a.bias[col + e];
-            if (a.scale) sc[e] = a.scale[col + e], sh[e] = a.shift[col + e];
-          }
-        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -602,7 +634,7 @@ __global__ __launch_bounds__((8 + NP) * 64, (8 + NP) / 4) void conv16p_kernel(co
             if (row < a.M && cok) {
               if (aff) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (v[e] + bi[e]) * sc[e] + sh[e];
+                for (int e = 0; e < 8; ++e) v[e] = (v[e] + bi[n][e]) * sc[n][e] + sh[n][e];
               }
               if (res) {
                 float q[8];
@@ -614,7 +646,7 @@ __global__ __launch_bounds__((8 + NP) * 64, (8 + NP) / 4) void conv16p_kernel(co
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
               }
-              pm_st8(C16 + row * a.c_pitch + col, v);
+              st8_bf16_untracked(C16 + row * a.c_pitch + col, v);
             }
           }
         }
