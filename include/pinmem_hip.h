@@ -126,7 +126,7 @@ int pm_conv_bwd_weight(const pm_tensor* x, const pm_tensor* dy, float* dw_krsc, 
                        void* ws, size_t ws_bytes, void* stream);
 
 /* ---- PROCESS-GLOBAL DEBUG / A-B SWITCHES (the only mutable global state of the library; SURVEY 8(b) "no global mutable state" holds for everything else) ----------
- * pm_set_winograd, pm_set_winograd_fused, pm_set_conv16, pm_set_bf16_wgrad and pm_profile_enable flip process-wide ROUTING / MEASUREMENT switches. They exist for
+ * pm_set_winograd, pm_set_winograd_fused, pm_set_conv16, pm_set_wgrad16, pm_set_bf16_wgrad and pm_profile_enable flip process-wide ROUTING / MEASUREMENT switches. They exist for
  * same-box A/B runs, kernel tests that must reach a specific kernel, and bench.py's roofline leg; they never change WHAT is computed (every route is parity-tested
  * against the same oracle), only which kernel computes it or whether launches are timed. Contract: call them from ONE thread while no other thread is inside a
  * pm_conv_* entry point (the switches are plain ints read at plan time: a concurrent flip is a benign race between two valid routes for an in-flight PLAN, but the
@@ -158,6 +158,11 @@ int pm_set_conv16(int on);
 /* prec = 2 weight gradients on pixel-contiguous bf16 copies of x (one per tap) and dy instead of the staged-fp32 form: 0 off (default: the
  * copies cost more HBM time than the GEMM saves), 1 on. Process-wide like pm_set_winograd. */
 int pm_set_bf16_wgrad(int on);
+/* bf16 tier, weight gradient with both operands bf16 (nn.Conv2d backward of Resnet.py / deepv3plus.py on bf16 rows): 1 (default) = the LDS-DMA persistent ring of
+ * csrc/wgrad16.hip wherever Cin is a multiple of 128 and Cout >= 128 (one block per CU walks (256 x 128 tile, pixel range) units, producer waves fetch ahead, fragments
+ * through the transpose read), 0 = the register-staged implicit-GEMM kernel everywhere (A/B runs, kernel tests). Same split-K slabs, same fixed-order reduce.
+ * Process-wide like pm_set_winograd; PM_WGRAD16=0 in the environment sets the default. */
+int pm_set_wgrad16(int on);
 
 /* In-library HIP-event timing of the implicit-GEMM kernel (bench.py's roofline leg). While enabled every conv launch is
  * bracketed by two events on its stream; pm_profile_read sums duration and algorithmic FLOPs (2*M*N*K) of one

@@ -1782,6 +1782,11 @@ extern "C" int pm_set_winograd_fused(int on) {
   g_wino_fused = on != 0;
   return PM_OK;
 }
+extern int g_wgrad16;      // wgrad16.hip
+extern "C" int pm_set_wgrad16(int on) {
+  g_wgrad16 = on != 0;
+  return PM_OK;
+}
 extern "C" int pm_set_bf16_wgrad(int on) {
   g_bf16_wgrad = on != 0;
   return PM_OK;
@@ -2203,7 +2208,51 @@ extern "C" int pm_conv_bwd_weight(const pm_tensor* x0, const pm_tensor* dy0, flo
   k.A = (const float*)dy->ptr, k.B = (const float*)x->ptr;
   k.M = (int)M, k.Nn = (int)Nn, k.K = (int)K;
   k.a_bytes = (unsigned)(pm_pixels(dy) * dy->pitch * esz), k.b_bytes = (unsigned)(pm_pixels(x) * x->pitch * esz), k.kmode = dy->w >= (native16 ? 2 * BK : BK) ? 1 : 2;
-  if (wp.use || bw.use) {
+  // round 5, second session: both operands bf16 and Cin a multiple of the 128-channel block -> the LDS-DMA persistent ring of wgrad16.hip. Its units are
+  // (256 x 128 tile, pixel range): the split is re-planned for one block per CU within the slab count the workspace was sized for.
+  pm_wgrad16 w16{};
+  bool use16 = false;
+  if (native16 && !wp.use && !bw.use) {
+    w16.X = (const pm_bf16*)x->ptr, w16.DY = (const pm_bf16*)dy->ptr;
+    w16.N = x->n, w16.H = x->h, w16.W = x->w, w16.Ho = dy->h, w16.Wo = dy->w;
+    w16.x_pitch = x->pitch, w16.dy_pitch = dy->pitch, w16.Cin = x->c, w16.Cout = dy->c;
+    w16.kh = p->kh, w16.kw = p->kw, w16.stride = p->stride, w16.pad = p->pad, w16.dil = p->dil;
+    w16.M = (int)M, w16.Nn = (int)Nn, w16.P = (int)K, w16.kper = 64, w16.c_split = M * Nn;
+    w16.C = dw;
+    use16 = K < (1l << 30) && pm_wgrad16_plan(&w16);
+    if (use16) {
+      const long tiles = (long)w16.tiles_m * w16.tiles_n, steps = (K + 63) / 64;
+      int best_ks = 1;
+      double best = 1e30;
+      for (int ks = 1; ks <= pl.ksplit; ++ks) {
+        const long per = (steps + ks - 1) / ks, kse = (steps + per - 1) / per;
+        const long rounds = (tiles * kse + 255) / 256;
+        // a unit costs its K-steps + ~6 steps of epilogue / hand-over; slabs: written and read back by the reduce (bytes / ~4 TB/s in K-steps of ~1 us)
+        const double cost = (double)rounds * (per + 6) + (kse > 1 ? (double)kse * M * Nn * 8.0 / 4e12 / 1.0e-6 : 0.0);
+        if (cost < best) best = cost, best_ks = (int)kse;
+      }
+      const long per = (steps + best_ks - 1) / best_ks;
+      w16.kper = (int)per * 64, w16.ksplit = (int)((steps + per - 1) / per);
+    }
+  }
+  if (use16) {
+    ProfRec rec;
+    if (g_prof_on) {
+      (void)hipEventCreate(&rec.a), (void)hipEventCreate(&rec.b);
+      rec.mode = MODE_WGRAD, rec.bm = w16.bm, rec.bn = w16.bn, rec.km = 2, rec.prec = 4, rec.nst = 3, rec.M = (int)M, rec.Nn = (int)Nn, rec.K = (int)K, rec.batch = 1, rec.ksplit = w16.ksplit,
+      rec.flops = 2.0 * (double)M * (double)Nn * (double)K;
+      (void)hipEventRecord(rec.a, st);
+    }
+    if (w16.ksplit > 1) w16.C = (float*)ws;
+    const int e = pm_wgrad16_launch(&w16, st);
+    if (g_prof_on) {
+      (void)hipEventRecord(rec.b, st);
+      g_prof.push_back(rec);
+    }
+    if (e) return e;
+    if (w16.ksplit > 1)
+      if (int e2 = splitk_reduce((const float*)ws, w16.ksplit, M, Nn, dw, (long)Nn, nullptr, nullptr, nullptr, nullptr, 0l, 0, st)) return e2;
+  } else if (wp.use || bw.use) {
   } else if (pl.ksplit > 1) {
     k.C = (float*)ws, k.c_pitch = Nn, k.c_split = M * Nn;
     if (int e = launch<MODE_WGRAD>(k, pl, st)) return e;

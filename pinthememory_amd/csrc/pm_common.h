@@ -121,6 +121,22 @@ size_t pm_conv16_slab_bytes(const pm_conv16* k);
 double pm_conv16_executed_fraction(const pm_conv16* k);
 int pm_conv16_launch(const pm_conv16* k, hipStream_t st);
 
+// ---- the weight gradient of the bf16 tier on LDS-DMA (wgrad16.hip): persistent producer / consumer ring over (tile, pixel-range) units ---------------------------------
+struct pm_wgrad16 {
+  const pm_bf16* X;          // bf16 NHWC input of the convolution
+  const pm_bf16* DY;         // bf16 NHWC output gradient
+  float* C;                  // fp32 dw [Cout][taps * Cin] (ksplit == 1) or the split-K slabs [ksplit][Cout][taps * Cin]
+  int N, H, W, Ho, Wo;
+  long x_pitch, dy_pitch;    // bf16 elements between pixels
+  int Cin, Cout, kh, kw, stride, pad, dil;
+  int M, Nn, P;              // GEMM extents: Cout, taps * Cin, output pixels (the reduction)
+  int kper, ksplit;          // pixels per split (a multiple of 64) and number of splits
+  long c_split;              // floats between slabs
+  int bm, bn, tiles_m, tiles_n;      // pm_wgrad16_plan
+};
+bool pm_wgrad16_plan(pm_wgrad16* k);      // false: the shape stays with the register-staged kernel
+int pm_wgrad16_launch(const pm_wgrad16* k, hipStream_t st);
+
 // ---- the streaming 1x1 convolution of the bf16 tier (pw16.hip): persistent blocks, weights resident in LDS, 16-byte stores straight from the accumulators ----------
 bool pm_pw16_ok(long M, int Nn, int K, long x_pitch, long y_pitch, long r_pitch, const void* x, const void* y, const void* r);
 int pm_pw16_launch(const pm_bf16* X, long x_pitch, const pm_bf16* W, pm_bf16* Y, long y_pitch, const pm_bf16* R, long r_pitch, long M, int Nn, int K, const float* bias,

@@ -860,6 +860,12 @@ def set_conv16(on):
     _GEN[0] += 1
 
 
+def set_wgrad16(on):
+    """bf16 tier, weight gradient of bf16 x / dy: True (default) = the LDS-DMA persistent ring (csrc/wgrad16.hip) where the shape allows, False = register-staged everywhere."""
+    check(_lib().pm_set_wgrad16(1 if on else 0), 'pm_set_wgrad16')
+    _GEN[0] += 1
+
+
 def set_bf16_wgrad(on):
     check(_lib().pm_set_bf16_wgrad(1 if on else 0), 'pm_set_bf16_wgrad')
     _GEN[0] += 1

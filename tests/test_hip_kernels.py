@@ -1005,6 +1005,52 @@ def test_conv16_on_the_48x48_maps(K, case):
         assert torch.equal(a, c)
 
 
+WGRAD16_CASES = [  # n, cin, h, w, cout, k, stride, pad, dil
+    (2, 256, 48, 48, 256, 3, 1, 1, 1),       # layer3-like: 4608 pixels, 18 tiles x split
+    (1, 512, 24, 20, 512, 3, 1, 2, 2),       # dilated, 480 pixels: a partial last 64-pixel step
+    (2, 128, 33, 31, 128, 3, 1, 1, 1),       # Cout = 128: the 128 x 256 tile is not taken (Cin % 256), rows beyond Cout of the 256-row tile are masked; odd sizes
+    (1, 256, 40, 40, 384, 1, 1, 0, 1),       # 1x1; Cout = 384 -> three 128-row tiles of the 128 x 256 form
+    (2, 256, 31, 29, 256, 3, 2, 1, 1),       # stride 2 (the first 3x3 of a stage)
+    (1, 1024, 12, 12, 2048, 1, 1, 0, 1),     # wide 1x1, 144 pixels: three K-steps, most units a single split
+    (3, 128, 17, 19, 256, 3, 1, 12, 12),     # dilation beyond the map: most taps see only padding
+]
+
+
+@pytest.mark.parametrize('case', WGRAD16_CASES)
+def test_wgrad16_lds_dma_weight_gradient(K, case):
+    """csrc/wgrad16.hip (round 5): the bf16 tier's weight gradient on the LDS-DMA persistent ring against the fp32 formula on the same bf16 values and against the
+    register-staged kernel (pm_set_wgrad16(0)); repeated launches are bit-identical (fixed-order split-K reduce)."""
+    n, cin, h, w, cout, k, s_, p, d = case
+    r16 = lambda t: t.bfloat16().float()
+    x = r16(rnd(n, cin, h, w, seed=1))
+    wt = rnd(cout, cin, k, k, seed=2, scale=(2.0 / (cin * k * k)) ** 0.5)
+    y_ref = F.conv2d(x, wt, None, stride=s_, padding=p, dilation=d)
+    dy = r16(rnd(*y_ref.shape, seed=4))
+    w2 = wt.clone().requires_grad_(True)
+    F.conv2d(x, w2, None, stride=s_, padding=p, dilation=d).backward(dy)
+    K.set_conv_precision('bf16')
+    outs = {}
+    try:
+        for on in (True, False):
+            K.set_wgrad16(on)
+            K.profile_enable(True)
+            K.profile_read(clear=True)
+            dw, _ = K.conv_bwd_weight(b16(x), b16(dy), (cout, k, k, cin), s_, p, d)
+            dw2, _ = K.conv_bwd_weight(b16(x), b16(dy), (cout, k, k, cin), s_, p, d)
+            taken = any(K.profile_read(mode=2, bm=bm, bn=bn, km=2, nst=3, prec=4)[2] for bm, bn in ((256, 128), (128, 256)))
+            K.profile_enable(False)
+            assert taken == on, 'the LDS-DMA kernel must (not) take this shape'
+            assert torch.equal(dw, dw2)
+            outs[on] = dw
+    finally:
+        K.set_wgrad16(True)
+        K.profile_enable(False)
+        K.set_conv_precision('f32')
+    assert outs[True].dtype == torch.float32
+    assert rel(outs[True].permute(0, 3, 1, 2), w2.grad) < 2e-4
+    assert rel(outs[True], outs[False]) < 2e-5
+
+
 PW16_CASES = [  # n, cin, h, w, cout: pointwise, K = 64 / 128 / 256 after padding
     (2, 64, 37, 41, 256),      # ragged last 64-row tile
     (1, 128, 48, 48, 512),     # two 256-channel chunks
