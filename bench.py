@@ -437,6 +437,11 @@ def dominant_conv_kernel(K, bf16):
         sym = 'conv16_kernel<%d, %d, 2, 2, %d>' % (bm, bn, nst)
         what = 'forward / stride-1 data gradient on bf16 activations, %dx%dx64 tile, %s, %s; FLOPs = 2*M*N*K executed' % (
             bm, bn, 'two LDS stages' if nst == 2 else 'one LDS stage (single-K-step reductions)', PREC_NAMES[5])
+    elif mode == 2 and nst == 3:
+        sym = 'wgrad16_kernel<%d, %d, %s>' % (bm, bn, '4, 2' if bm == 256 else '2, 4')
+        what = ('weight gradient on bf16 activations, persistent form: one block per CU walks (%dx%d tile, 64-pixel steps of a pixel range) units, four producer waves keep '
+                'a three-stage LDS ring of pixel-major dy / x tiles filled by global_load_lds, fragments through ds_read_b64_tr_b16, fp32 split-K slabs reduced in fixed '
+                'order; FLOPs = 2*M*N*K' % (bm, bn))
     else:
         sym = 'conv_igemm_kernel<%d, %d, %d, %s, %d, %d, %d>' % (mode, bm, bn, '4, 1' if bn == 32 else '2, 2', km, kprec, nst)
         what = '%s, %dx%dx32 tile, %s K-state, %s LDS, %s; direct convolutions and the batched Winograd F(4x4,3x3) / F(2x2,3x3) GEMMs; FLOPs = 2*M*N*K executed' % (

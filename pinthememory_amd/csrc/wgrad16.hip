@@ -8,7 +8,7 @@
 // One block per CU walks (tile, pixel-range) units: four producer waves issue the fetches of a three-stage ring that runs on across unit boundaries and own all the
 // index arithmetic (pixel -> image / row / column once per unit and piece, then stepped by 64 pixels); eight waves multiply 64 x 64 sub-tiles and write fp32 partial
 // tiles (split-K slabs, reduced in fixed order by splitk_reduce as before) -- deterministic. Replaces the register-staged conv_igemm_kernel<2, 128, 128, .., 4, 2> where
-// Cin is a multiple of the tile's channel block (every 3x3 / 1x1 of the backbone from 128 channels up).
+// Cin fills the tile's 128-channel blocks at least 3 / 4 (every 3x3 / 1x1 of the backbone from 128 channels up, the decoder's 304-channel concat).
 #include <stdlib.h>
 #include <algorithm>
 
@@ -64,7 +64,7 @@ __global__ __launch_bounds__((8 + NP) * 64, (8 + NP) / 4) void wgrad16_kernel(co
 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int ntiles = a.tiles_m * a.tiles_n, total = ntiles * a.ksplit, G = gridDim.x;
-  const int cpt = a.Cin / BN;      // channel blocks per tap (Cin is a multiple of BN)
+  const int cpt = (a.Cin + BN - 1) / BN;      // channel blocks per tap; the last one may be partial (304 / 320 channels): its missing channels are fetched as zeros and not stored
   auto decode = [&](int v, int& m0, int& tap, int& c0, int& z, int& p0, int& nk) {
     z = v / ntiles;
     const int lid = xcd_remap_g(v - z * ntiles, ntiles);
@@ -83,7 +83,7 @@ __global__ __launch_bounds__((8 + NP) * 64, (8 + NP) / 4) void wgrad16_kernel(co
     constexpr int OOB = 0x7fffffff;
     const int dyb = (int)a.dy_pitch * 2, xb = (int)a.x_pitch * 2;
     // fixed per lane: pixel row inside the stage and (swizzled) channel slot of every piece
-    int a_row[A_IT], a_col[A_IT], b_row[B_IT], b_col[B_IT];
+    int a_row[A_IT], a_col[A_IT], b_row[B_IT], b_src[B_IT], b_col[B_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       const int u = it * FT + t, r = u / A_SL, s = (u % A_SL) ^ ((r & 3) << 2);
@@ -92,7 +92,7 @@ __global__ __launch_bounds__((8 + NP) * 64, (8 + NP) / 4) void wgrad16_kernel(co
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
       const int u = it * FT + t, r = u / B_SL, s = (u % B_SL) ^ ((r & 3) << 2);
-      b_row[it] = r, b_col[it] = s * 16;
+      b_row[it] = r, b_src[it] = s * 16, b_col[it] = s * 16;
     }
     // state of the unit being fetched
     int a_off[A_IT];                          // byte offset of (pixel row, cout slot) relative to the step's first pixel, or OOB for couts beyond Cout
@@ -111,6 +111,8 @@ __global__ __launch_bounds__((8 + NP) * 64, (8 + NP) / 4) void wgrad16_kernel(co
         const int ky = tap / a.kw, kx = tap - ky * a.kw;
         dy0 = ky * a.dil - a.pad, dx0 = kx * a.dil - a.pad;
         b_ch = c0 * 2;
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) b_col[it] = (c0 * 2 + b_src[it] < a.Cin * 2) ? b_src[it] : -1;      // -1: a channel group beyond Cin (partial last block) reads zeros
         // one index decomposition per unit (row 0 of the lane), the other pieces step on from it
         constexpr int RSTEP = FT / B_SL;
         int p = p0 + b_row[0];
@@ -146,7 +148,7 @@ __global__ __launch_bounds__((8 + NP) * 64, (8 + NP) / 4) void wgrad16_kernel(co
 #pragma unroll
       for (int it = 0; it < B_IT; ++it) {
         const int iy = b_oy[it] * a.stride + dy0, ix = b_ox[it] * a.stride + dx0;
-        const bool ok = ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W) & (pix + b_row[it] < pend);
+        const bool ok = ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W) & (pix + b_row[it] < pend) & (b_col[it] >= 0);
         dma16g(rB, lb + (it * FT + wave_u * 64) * 16, ok ? ((b_img[it] * a.H + iy) * a.W + ix) * xb + b_ch + b_col[it] : OOB, 0);
         // this piece's pixel, 64 further on
         b_ox[it] += BKP;
@@ -231,7 +233,8 @@ __global__ __launch_bounds__((8 + NP) * 64, (8 + NP) / 4) void wgrad16_kernel(co
     const int rr0 = lane >> 3, cc = (lane & 7) * 4;
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
-      const int col = tap * a.Cin + c0 + wn * (BN / WN) + n * 32 + cc;      // Cin % BN == 0: the tile never leaves its tap
+      const int cl = c0 + wn * (BN / WN) + n * 32 + cc;      // channel inside the tap: groups of four, Cin % 8 == 0 -- a group is whole or beyond Cin
+      const int col = tap * a.Cin + cl;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -241,7 +244,7 @@ __global__ __launch_bounds__((8 + NP) * 64, (8 + NP) / 4) void wgrad16_kernel(co
           const int rr = r0 + rr0;
           const long row = m0 + wm * (BM / WM) + i * 32 + rr;
           const float4 v = *reinterpret_cast<const float4*>(Ws + rr * LDS_SUB + cc);
-          if (row >= a.M) continue;
+          if (row >= a.M || cl >= a.Cin) continue;
           if ((cp & 3) == 0) st16_untracked_g(Cf + row * cp + col, u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)});
           else {
             const float e[4] = {v.x, v.y, v.z, v.w};
@@ -270,19 +273,21 @@ void launch_wgrad16(const pm_wgrad16& k, hipStream_t st) {
 
 }  // namespace
 
-// The shapes the kernel takes: both tensors bf16 with whole 16-byte channel groups, Cin a multiple of the 128-channel block, at least 128 output channels, 32-bit byte
-// offsets. Fills the tile plan; the pixel split (kper, ksplit) is the caller's (the slabs were sized for it).
+// The shapes the kernel takes: both tensors bf16 with whole 16-byte channel groups, Cin in 128-channel blocks (at least three quarters full in total), at least 128 output
+// channels, 32-bit byte offsets. Fills the tile plan; the pixel split (kper, ksplit) is the caller's (the slabs were sized for it).
 bool pm_wgrad16_plan(pm_wgrad16* k) {
   if (!g_wgrad16) return false;
-  if (k->Cin % 128 || k->Cout < 128 || (k->x_pitch | k->dy_pitch) % 8 || k->kper % BKP) return false;
+  // Cin: 128-channel blocks at least three quarters full in total (the decoder's 304-channel concat: 2.4 blocks, 21 % of the multiplications on zeros)
+  const int cblocks = pm_cdiv(k->Cin, 128);
+  if (k->Cin % 8 || k->Cin < 128 || k->Cin * 4 < cblocks * 128 * 3 || k->Cout < 128 || (k->x_pitch | k->dy_pitch) % 8 || k->kper % BKP) return false;
   if ((long)k->N * k->H * k->W * k->x_pitch * 2 >= (1l << 31) || (long)k->P * k->dy_pitch * 2 >= (1l << 31)) return false;
   if (!pm_aligned16(k->X) || !pm_aligned16(k->DY) || !pm_aligned16(k->C)) return false;
   // 256 couts x 128 cins, or 128 x 256 when that wastes fewer rows (Cout = 128, 384, ...) and Cin allows it
   const int pad256 = pm_cdiv(k->Cout, 256) * 256 - k->Cout, pad128 = pm_cdiv(k->Cout, 128) * 128 - k->Cout;
-  if (pad128 < pad256 && k->Cin % 256 == 0) k->bm = 128, k->bn = 256;
+  if (pad128 < pad256 && k->Cin % 256 == 0) k->bm = 128, k->bn = 256;      // (never with a partial channel block)
   else k->bm = 256, k->bn = 128;
   k->tiles_m = pm_cdiv(k->Cout, k->bm);
-  k->tiles_n = k->kh * k->kw * (k->Cin / k->bn);
+  k->tiles_n = k->kh * k->kw * pm_cdiv(k->Cin, k->bn);
   return true;
 }
 

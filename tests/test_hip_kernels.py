@@ -1013,6 +1013,8 @@ WGRAD16_CASES = [  # n, cin, h, w, cout, k, stride, pad, dil
     (2, 256, 31, 29, 256, 3, 2, 1, 1),       # stride 2 (the first 3x3 of a stage)
     (1, 1024, 12, 12, 2048, 1, 1, 0, 1),     # wide 1x1, 144 pixels: three K-steps, most units a single split
     (3, 128, 17, 19, 256, 3, 1, 12, 12),     # dilation beyond the map: most taps see only padding
+    (1, 304, 40, 36, 256, 3, 1, 1, 1),       # the decoder's concat: 2.5 channel blocks, the last one half empty (zeros fetched, columns beyond Cin not stored)
+    (1, 200, 20, 20, 128, 1, 1, 0, 1),       # 1.56 blocks
 ]
 
 
