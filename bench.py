@@ -196,7 +196,7 @@ def mldg(a):
         if os.environ.get('PM_PROFILE_DUMP'):
             K.profile_dump(os.environ['PM_PROFILE_DUMP'])
         fam = {}
-        for name, mode in (('forward-form kernel (fp32: forward + Winograd GEMMs; bf16: forward + stride-1 data gradients, register-staged)', 0), ('data-gradient-form kernel (fp32: direct data gradients; bf16: stride-2 only)', 1), ('weight gradients', 2), ('LDS-DMA bf16 convolutions (forward + stride-1 data gradients)', 4), ('LDS-DMA bf16 convolutions, wide 256 x 128 ring kernel', 5)):
+        for name, mode in (('forward-form kernel (fp32: forward + Winograd GEMMs; bf16: forward + stride-1 data gradients, register-staged)', 0), ('data-gradient-form kernel (fp32: direct data gradients; bf16: stride-2 only)', 1), ('weight gradients (bf16 tier: the LDS-DMA persistent ring of wgrad16.hip where the shape allows)', 2), ('LDS-DMA bf16 convolutions (forward + stride-1 data gradients)', 4), ('LDS-DMA bf16 convolutions, one block per CU: persistent producer / consumer ring and the 256 x 256 two-stage form', 5)):
             ms, fl, n = K.profile_read(mode=mode)
             if n:
                 fam[name] = {'ms_per_step': round(ms / 2, 3), 'launches_per_step': n / 2, 'achieved_TFLOPs': round(fl / (ms * 1e-3) / 1e12, 1)}
@@ -705,7 +705,7 @@ def main():
                     'all_conv_kernels': {'achieved': round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), 'ms_per_step': round(tot_ms / prof_steps, 3),
                                          'launches_per_step': tot_n / prof_steps,
                                          'timed_region_overlapped': {'achieved': round(ov_fl / (ov_ms * 1e-3) / 1e12, 2), 'ms_per_step': round(ov_ms / ov_steps, 3),
-                                                                     'measured': '%d untimed steps with the stream overlaps of the timed region (weight gradients on a side stream, commit forward of step t under the training forward of step t + 1)' % ov_steps}}}
+                                                                     'measured': '%d untimed steps with the stream overlaps of the timed region (fp32: weight gradients on a side stream; bf16: inline; commit forward of step t under the training forward of step t + 1)' % ov_steps}}}
     side = None
     if a.dtype == 'f32' and not multi and not a.no_side and edge is None:
         # BASELINE configs[2] in the driver's own run: the SAME process, model and batch switched to the bf16 tier after the timed region -- a few untimed steps, a

@@ -262,7 +262,7 @@ class GraphedAggStep:
                 else:
                     self.out = agg_train_step(net, opt, self.x, self.gts, sched=None)
                     self.mem.copy_(m.memory.m_items)
-                if ops.OVERLAP_WGRAD:      # every stream forked into the capture rejoins it (the weight-gradient stream's last event record trails its last join)
+                if ops.overlap_wgrad():      # every stream forked into the capture rejoins it (the weight-gradient stream's last event record trails its last join)
                     torch.cuda.current_stream().wait_stream(ops._side_stream())
             torch.cuda.synchronize()
             # events recorded inside the capture mean nothing to eager code (waiting for one from a non-capturing stream is an error): everything they ordered is complete

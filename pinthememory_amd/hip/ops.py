@@ -77,7 +77,20 @@ def flush_bn_counters():
 # a lower autograd sequence number than every node of that stage. The engine therefore runs `_Defer.backward` -- which makes the
 # main stream wait for the side stream and only then hands the gradient on -- after the whole stage's backward has been
 # launched: AccumulateGrad / DDP hooks / functional-weight graphs never see a gradient that is still being written.
-OVERLAP_WGRAD = _os.environ.get('PM_OVERLAP_WGRAD', '1') == '1'
+# Round 5, second session: on the bf16 tier the weight gradients run INLINE by default. Their kernel there (csrc/wgrad16.hip) is persistent -- one block per CU with
+# 144 KB of LDS -- so a second stream cannot share the chip with it any more and the fork / join only adds contention (same box, captured step: 24.72 side stream,
+# 24.46 inline; eager: level). PM_OVERLAP_WGRAD=0 / 1 forces one form on both tiers; the attribute stays the master switch (bench.py's serialised leg, tests).
+_OVERLAP_ENV = _os.environ.get('PM_OVERLAP_WGRAD')
+OVERLAP_WGRAD = True if _OVERLAP_ENV is None else _OVERLAP_ENV == '1'
+
+
+def overlap_wgrad():
+    """Do the weight gradients of the pass being recorded go to the side stream?"""
+    if not OVERLAP_WGRAD:
+        return False
+    return not (_OVERLAP_ENV is None and K.CONV_PREC == 2 and K.ACT_DTYPE == torch.bfloat16)
+
+
 _side = {}
 _proxy = {}            # id(weight tensor) -> deferred proxy, valid for the current forward only
 
@@ -133,7 +146,7 @@ def begin_forward():
 
 def defer_weights(module):
     """Call right before running `module` (a stage of the network) in training mode with gradients enabled."""
-    if not (OVERLAP_WGRAD and torch.is_grad_enabled()):
+    if not (overlap_wgrad() and torch.is_grad_enabled()):
         return
     for m in module.modules():
         if isinstance(m, torch.nn.Conv2d) and m.bias is None and m.weight.requires_grad and id(m.weight) not in _proxy:

@@ -36,7 +36,7 @@ for name, a in agg.items():
     for k in ('SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE', 'dur'):
         tot[k] += a[k]
 res.sort(key=lambda r: -r['total_ms'])
-conv = [r for r in res if 'conv_igemm' in r['kernel']]
+conv = [r for r in res if any(k in r['kernel'] for k in ('conv_igemm', 'conv16', 'wgrad16', 'pw16_kernel'))]
 conv_busy = sum(agg[r['kernel']]['SQ_VALU_MFMA_BUSY_CYCLES'] for r in conv)
 conv_gui = sum(agg[r['kernel']]['GRBM_GUI_ACTIVE'] for r in conv) / 8.0
 summary = dict(note='MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs); counters serialise the kernels, so durations are '
