@@ -39,4 +39,4 @@ timeout 900 python bench.py --steps 3 --warmup 1 --cpu-batch 8 --no-profile --no
 # round 5 additions: the captured step on both tiers, the per-shape probe of the bf16 forward kernels (default routing / without the wide kernel / wide everywhere)
 timeout 600 python bench.py --no-cpu-baseline --graph --no-side 2>/dev/null | grep '^{' > $O/bench_graph_f32.json; cut -c1-160 $O/bench_graph_f32.json
 timeout 600 python bench.py --no-cpu-baseline --graph --dtype bf16 2>/dev/null | grep '^{' > $O/bench_graph_bf16.json; cut -c1-160 $O/bench_graph_bf16.json
-for r in 1 4 3; do echo "== pm_set_conv16($r)" >> $O/conv16w_probe.txt; PROBE_CONV16=$r timeout 300 python tools/conv16_probe.py 2>&1 | grep -v amdgpu >> $O/conv16w_probe.txt; done; tail -18 $O/conv16w_probe.txt
+for r in 1 4 3 8; do echo "== pm_set_conv16($r)" >> $O/conv16w_probe.txt; PROBE_CONV16=$r timeout 300 python tools/conv16_probe.py 2>&1 | grep -v amdgpu >> $O/conv16w_probe.txt; done; tail -18 $O/conv16w_probe.txt
