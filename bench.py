@@ -118,6 +118,7 @@ def config5(a):
                       'unit': 'imgs/sec', 'n_gpus': 1, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
                       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                       'config': {'workload': 'configs[4]: ResNet-101 DeepLabV2 (network/deepv2.py) 1024x2048 sliding-window inference, side measurement',
+                                 'step_form': 'eager launches', 'host_enqueue_ms': None if a.no_profile else host_enqueue_ms(one),
                                  'tiles': [list(t) for t in tiles], 'flips': 2, 'conv_tflop_per_image': round(tf, 2),
                                  'direct_equivalent_mfma_frac': round(tf * a.steps / dt / PEAK_TFLOPS_F32_MFMA, 4)},
                       'roofline': roof, 'cpu_baseline': None}), flush=True)
@@ -146,7 +147,9 @@ def meminit(a):
                       'unit': 'imgs/sec', 'n_gpus': 1, 'steps': len(batches), 'warmup': a.warmup, 'ms_per_step': round(dt / len(batches) * 1e3, 3),
                       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                       'config': {'workload': 'memory_initalize (train.py:1000-1042): eval-mode forward of each batch + 4-tap soft-label accumulation of the normalised '
-                                             'bot_aspp features, one epoch over %d resident batches, side measurement' % len(batches)},
+                                             'bot_aspp features, one epoch over %d resident batches, side measurement' % len(batches),
+                                 'step_form': 'eager launches',
+                                 'host_enqueue_ms': None if a.no_profile else round(host_enqueue_ms(lambda: harness.memory_initialize(net, batches, epochs=1)) / len(batches), 3)},
                       'roofline': None, 'cpu_baseline': None}), flush=True)
 
 
@@ -214,7 +217,7 @@ def mldg(a):
                                              'inner fwd + bwd (retain_graph), theta\' = theta - inner_lr g for two weight sets (inner_lr 1e-3 at the first iteration, then lr / 4 = 2.5e-3: --inner_lr_anneal), frozen-encoder memory write, meta-test fwd + bwd '
                                              'through the written memory, SGD, eval-mode memory-commit fwd; side measurement' % (h, a.batch - h, a.size, a.size),
                                  'inner_lr_first': harness.INNER_LR, 'inner_lr_last': inner[0], 'peak_memory_GB': round(peak_gb, 2), 'final_losses': {k: round(float(v), 5) for k, v in losses.items()},
-                                 'filter_transforms_per_step': xforms,
+                                 'filter_transforms_per_step': xforms, 'step_form': 'eager launches', 'host_enqueue_ms': None if a.no_profile else host_enqueue_ms(step),
                                  'filter_transforms_note': 'Winograd U = G w G^T (fp32 tier) / bf16 filter copies (bf16 tier) computed inside one step; functional weights '
                                                            '(theta\') are not owner-registered parameters, so their transforms are never kept between calls',
                                  'kernel_families': fam},
