@@ -161,3 +161,23 @@ def test_set_mode_respects_train_overrides():
     net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 1), Frozen(4))
     harness.set_mode(net, True)
     assert net.training and net[0].training and not net[1].training
+
+
+def test_weight_gradient_overlap_default_is_per_tier(monkeypatch):
+    """hip/ops.overlap_wgrad (round 5): unset PM_OVERLAP_WGRAD = side stream on the fp32 tier, inline on the bf16 tier (its weight-gradient kernel is persistent: one block
+    per CU); the module attribute stays the master switch bench.py and the tests flip; an explicit PM_OVERLAP_WGRAD=1 keeps the side stream on both tiers."""
+    from pinthememory_amd.hip import ops, kernels as K
+    prec, act = K.CONV_PREC, K.ACT_DTYPE
+    try:
+        monkeypatch.setattr(ops, '_OVERLAP_ENV', None)
+        monkeypatch.setattr(ops, 'OVERLAP_WGRAD', True)
+        K.set_conv_precision('f32')
+        assert ops.overlap_wgrad()
+        K.set_conv_precision('bf16')
+        assert not ops.overlap_wgrad()
+        monkeypatch.setattr(ops, '_OVERLAP_ENV', '1')
+        assert ops.overlap_wgrad()
+        monkeypatch.setattr(ops, 'OVERLAP_WGRAD', False)
+        assert not ops.overlap_wgrad()
+    finally:
+        K.CONV_PREC, K.ACT_DTYPE = prec, act
