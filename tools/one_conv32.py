@@ -1,0 +1,20 @@
+"""GPU: ONE fp32 forward convolution shape, repeated (kernel durations out of a trace). usage: python tools/one_conv32.py n cin h w cout k pad dil [reps]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pinthememory_amd.hip import kernels as K
+n, cin, h, w, cout, k, p, d = [int(v) for v in sys.argv[1:9]]
+reps = int(sys.argv[9]) if len(sys.argv) > 9 else 10
+K.set_conv_precision('f32')
+x = torch.relu(torch.randn(n, h, w, cin, device='cuda'))
+wt = torch.randn(cout, k, k, cin, device='cuda') * 0.05
+for _ in range(3):
+    y = K.conv_fwd(x, wt, 1, p, d)
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(reps):
+    y = K.conv_fwd(x, wt, 1, p, d)
+e.record(); torch.cuda.synchronize()
+ms = s.elapsed_time(e) / reps
+print('done', tuple(y.shape), '%.4f ms  %.1f TF' % (ms, 2.0 * n * h * w * cout * cin * k * k / ms / 1e9))
