@@ -1053,6 +1053,48 @@ def test_wgrad16_lds_dma_weight_gradient(K, case):
     assert rel(outs[True], outs[False]) < 2e-5
 
 
+@pytest.mark.parametrize('case', [(8, 256, 192, 192, 256, 3, 1, 1),        # decoder final1.3: the persistent ring by the planner's rule (M = 294 912)
+                                  (8, 320, 192, 192, 256, 3, 1, 1),        # decoder final1.0 (304 + 16 zero-pad channels as the concat buffer has them)
+                                  (8, 2048, 48, 48, 256, 3, 12, 12)])      # ASPP rate 12: 288 K-steps, filter rows skipped per tile
+def test_persistent_kernels_at_production_size_under_default_routing(K, case):
+    """BASELINE configs[2] sizes (bs=8, 768^2): the shapes the planner hands to the persistent producer / consumer kernels (conv16w.hip conv16p_kernel, wgrad16.hip) under
+    DEFAULT routing really take them, and agree with the register-staged kernels on the same bf16 values: forward and input gradient to neighbouring bf16 values, the
+    weight gradient to fp32 accumulation order. (The fp32 formula on the CPU would take minutes at this size: the independent kernel is the reference here, each of the
+    two is checked against the formula on small shapes above.)"""
+    n, cin, h, w, cout, k, p, d = case
+    g = torch.Generator(device='cuda').manual_seed(11)
+    x = torch.randn(n, h, w, cin, device='cuda', generator=g).bfloat16()
+    dy = torch.randn(n, h, w, cout, device='cuda', generator=g).bfloat16()
+    wt = torch.randn(cout, k, k, cin, device='cuda', generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    K.set_conv_precision('bf16')
+    outs = {}
+    try:
+        for route in (1, 0):
+            K.set_conv16(route)
+            K.set_wgrad16(route == 1)
+            K.profile_enable(True)
+            K.profile_read(clear=True)
+            y = K.conv_fwd(x, wt, 1, p, d)
+            dx = K.conv_bwd_data(dy, wt, (n, h, w, cin), 1, p, d)
+            dw, _ = K.conv_bwd_weight(x, dy, (cout, k, k, cin), 1, p, d)
+            ring = sum(K.profile_read(mode=5, bm=bm, bn=bn, km=1, nst=3, prec=5)[2] for bm, bn in ((256, 128), (128, 256)))
+            wg = sum(K.profile_read(mode=2, bm=bm, bn=bn, km=2, nst=3, prec=4)[2] for bm, bn in ((256, 128), (128, 256)))
+            K.profile_enable(False)
+            if route == 1:
+                assert ring >= 1 and wg == 1, ('default routing must take the persistent kernels on this shape', ring, wg)
+            else:
+                assert ring == 0 and wg == 0
+            outs[route] = (y, dx, dw)
+    finally:
+        K.profile_enable(False)
+        K.set_conv16(1)
+        K.set_wgrad16(True)
+        K.set_conv_precision('f32')
+    close16(outs[1][0].float(), outs[0][0].float(), ulps=2.5)
+    close16(outs[1][1].float(), outs[0][1].float(), ulps=2.5)
+    assert rel(outs[1][2], outs[0][2]) < 2e-5
+
+
 PW16_CASES = [  # n, cin, h, w, cout: pointwise, K = 64 / 128 / 256 after padding
     (2, 64, 37, 41, 256),      # ragged last 64-row tile
     (1, 128, 48, 48, 512),     # two 256-channel chunks
