@@ -269,6 +269,8 @@ struct Plan {
 // ---- PREC 5 routing (round 6): which fp32 launches run as split-operand bf16 MFMA (conv_split.hip). g_split: 0 never, 1 every eligible launch (default).
 int g_split = getenv("PM_SPLIT") ? atoi(getenv("PM_SPLIT")) : 1;
 int g_split_nst = getenv("PM_SPLIT_NST") ? atoi(getenv("PM_SPLIT_NST")) : 1;
+int g_split_min_k = getenv("PM_SPLIT_MIN_K") ? atoi(getenv("PM_SPLIT_MIN_K")) : 129;      // shorter forward / data-gradient reductions (64 -> 256 @192^2, 128 -> 512 @96^2) are bound by their
+inline bool split_k_ok(int mode, long K) { return mode == MODE_WGRAD || K >= g_split_min_k; }      // output stream, not by the matrix pipe: measured slower on the split path (58 vs 70 TF)
 int g_split_tile = getenv("PM_SPLIT_TILE") ? atoi(getenv("PM_SPLIT_TILE")) : 1;      // 1: the split path prefers the 128 x 128 tile (3.7 VALU per MFMA; 64 x 64: 7.3), 0: the fp32 kernel's tile choice
 Plan make_plan(int mode, long M, long Nn, long K, bool bf16 = false) {
   Plan best_p{};
@@ -282,7 +284,7 @@ Plan make_plan(int mode, long M, long Nn, long K, bool bf16 = false) {
   int bn = Nn > 64 ? 128 : ((Nn > 32 || bf16) ? 64 : 32);      // no bf16-operand instantiation of the 128 x 32 tile: narrow outputs (19 classes) pad to 64
   // bf16 operands (configs[2], direct algorithm everywhere): the MFMA phase is 16x shorter, the kernel is bound by staging its
   // operands through L2 / LDS, so the 128 x 128 tile (half the operand traffic per FLOP of 64 x 64) wins: 73.1 -> see DESIGN
-  const bool big = bf16 || (g_split && g_split_tile);
+  const bool big = bf16 || (g_split && g_split_tile && split_k_ok(mode, K));
   if (mode != MODE_WGRAD && !wide_bn && !big && bn == 128) bn = 64;
   if (force_bn && mode != MODE_WGRAD) bn = force_bn;
   const long ksteps = (K + BK - 1) / BK;
@@ -400,8 +402,8 @@ struct ProfRec {
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 
-inline bool split_takes(int mode, const Plan& p, const ConvK& k) {
-  return g_split != 0 && p.bn >= 64 && k.kmode != K_SMALL && !k.io16;
+inline bool split_takes(int mode, const Plan& p, const ConvK& k, int batch) {      // batched launches (the Winograd point products: their output stays in L2) at every K
+  return g_split != 0 && p.bn >= 64 && !k.io16 && (batch > 1 || split_k_ok(mode, k.K));
 }
 
 template <int MODE>
@@ -415,7 +417,7 @@ int launch(const ConvK& k0, const Plan& p, hipStream_t st, int batch = 1, double
   // staged epilogue: in situ +3 ... +6 % on the convolutions whose output streams to HBM (every unbatched launch), -2 ... -4 % on the
   // batched Winograd GEMMs whose product M[p] stays in L2 / Infinity Cache for the output transform (tools/gpu_env_ab2.sh PM_STAGE_EP)
   if (batch != 1 && !getenv("PM_STAGE_EP")) k.stage_ep = 0;
-  if (k.prec == 0 && split_takes(MODE, p, k)) k.prec = 5;
+  if (k.prec == 0 && split_takes(MODE, p, k, batch)) k.prec = 5;
   ProfRec rec;
   if (g_prof_on) {
     (void)hipEventCreate(&rec.a), (void)hipEventCreate(&rec.b);
@@ -490,6 +492,8 @@ void fill_geom(ConvK& k, const pm_tensor* x, const pm_tensor* y, const pm_conv_p
   k.res_pitch = 0, k.relu = 0, k.stats = nullptr, k.io16 = 0;
   static const int stage_ep = getenv("PM_STAGE_EP") ? atoi(getenv("PM_STAGE_EP")) : 1;
   k.stage_ep = stage_ep;
+  static const int spl_prio = getenv("PM_SPLIT_PRIO") ? atoi(getenv("PM_SPLIT_PRIO")) : 1;
+  k.spl_prio = spl_prio;
   k.a_bs = k.b_bs = k.c_bs = 0;
 }
 

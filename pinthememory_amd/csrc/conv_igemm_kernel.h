@@ -41,6 +41,7 @@ struct ConvK {
   float* stats;               // train-mode BN statistics of the output: (mean, M2) per 32-row slab and channel, or null
   int io16;                   // the bf16 tier: C and `residual` are bf16 tensors (pitches in elements); accumulation and the epilogue arithmetic stay fp32
   int stage_ep;               // 1: epilogue staged through LDS (16-byte row stores); 0: per-element stores (PM_STAGE_EP=0, A/B)
+  int spl_prio;               // PREC 5: 1 = waves in odd hardware wave slots run at s_setprio 2 (see the kernel), 0 = all equal
 };
 
 // conv_split.hip: launches the PREC 5 instantiation of the tile (bm x bn) / K-state mode of `k`; NST = 1 (one LDS stage) when nst1, else two
@@ -121,6 +122,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && BK == 32, "bad tile config");
 
   extern __shared__ __align__(16) float smem[];
+  if constexpr (PREC == 5) {
+    // Two blocks share a CU, i.e. two waves share each SIMD's VALU issue and matrix pipe. Equal waves that start together STAY together: both split (VALU) at the
+    // same time, then both multiply (measured: VALU issue 44 % + matrix pipe 57 % of the kernel's cycles ~ 100 %, no overlap at all). A static priority for the wave
+    // in the odd hardware slot lets it run ahead by one phase, after which the partner's VALU phase fills the leader's MFMA phase and vice versa.
+    if (a.spl_prio && (__builtin_amdgcn_s_getreg(0x1804) & 1)) __builtin_amdgcn_s_setprio(2);      // hwreg(HW_REG_HW_ID, 0, 4): the wave's slot on its SIMD
+  }
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -249,20 +256,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
 
   float4 ra[A_N], rb[B_N];
 
-  auto load_tiles = [&](int kt) {   // branch-free: every lane always issues its loads, invalid ones at offset OOB
+  auto load_tiles = [&](int kt, int which = 0) {   // branch-free: every lane always issues its loads, invalid ones at offset OOB. which: 0 both operands, 1 A only, 2 B only
     const int kbase = k_begin + kt * BKW;
+    const bool doA = which != 2, doB = which != 1;
     if constexpr (MODE == MODE_FWD) {
       const int ky = FAST ? u_ky : a_ky, kx = FAST ? u_kx : a_kx, tap = FAST ? u_tap : a_tap, ch = FAST ? u_ch : a_ch;
       const int dy = ky * a.dil, dx = kx * a.dil;
       const int toff = (dy * a.W + dx) * xp4 + ch * 4;
       const bool tok = tap < T;
+      if (doA)
 #pragma unroll
       for (int i = 0; i < A_N; ++i) {
         const bool ok = ((unsigned)(a_y0[i] + dy) < (unsigned)a.H) & ((unsigned)(a_x0[i] + dx) < (unsigned)a.W) & tok;
         const int off = a_base[i] + toff;
         ra[i] = bload(rA, ok ? off : OOB);
       }
-      const bool kok = FAST ? true : (kbase + g * 4 < k_end);
+      const bool kok = FAST ? (kbase < k_end) : (kbase + g * 4 < k_end);
+      if (doB)
 #pragma unroll
       for (int i = 0; i < B_N; ++i) {
         const int off = b_base[i] + kbase * 4;   // b_base already carries this thread's k-group (g * 16 bytes)
@@ -273,6 +283,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
         const int dy = u_ky * a.dil, dx = u_kx * a.dil;
         const int toff = (dy * a.Wo + dx) * yp4 - u_ch * 4;
         const bool tok = u_tap < T;
+        if (doA)
 #pragma unroll
         for (int i = 0; i < A_N; ++i) {
           const bool ok = ((unsigned)(a_y0[i] - dy) < (unsigned)a.Ho) & ((unsigned)(a_x0[i] - dx) < (unsigned)a.Wo) & tok;
@@ -280,6 +291,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
           ra[i] = bload(rA, ok ? off : OOB);
         }
         const int uoff = (u_ch * Treal + u_tap) * a.Cin * 4;
+        if (doB)
 #pragma unroll
         for (int j = 0; j < B_N; ++j) {
           const int off = b_base[j] + uoff;
@@ -288,6 +300,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
       } else {
         const int dy = (a.ky0 + a.ksy * a_ky) * a.dil, dx = (a.kx0 + a.ksx * a_kx) * a.dil, smask = a.stride - 1;
         const bool kok = a_tap < T;
+        if (doA)
 #pragma unroll
         for (int i = 0; i < A_N; ++i) {
           const int ty = a_y0[i] - dy, tx = a_x0[i] - dx;
@@ -299,6 +312,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
         const bool rok = (b_tap < T) & (kbase + r < k_end);
         const int b_tky = b_tap / a.tk_w, b_tkx = b_tap - b_tky * a.tk_w;
         const int roff = (b_co * Treal + (a.ky0 + a.ksy * b_tky) * a.kw + a.kx0 + a.ksx * b_tkx) * a.Cin * 4;
+        if (doB)
 #pragma unroll
         for (int j = 0; j < B_N; ++j) {
           const int off = roff + b_base[j];
@@ -311,6 +325,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
         const int p = kbase + r + 32 * kk;
         const bool pok = p < k_end;
         const int poff = p * yp4;
+        if (doA)
 #pragma unroll
         for (int j = 0; j < A_NL; ++j) {
           const int off = poff + a_col4[j];
@@ -318,6 +333,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
         }
         const int by = (kk ? q_oy : p_oy) * a.stride, bx = (kk ? q_ox : p_ox) * a.stride;
         const int rowbase = (((kk ? q_img : p_img) * a.H + by) * a.W + bx) * xp4;
+        if (doB)
 #pragma unroll
         for (int j = 0; j < B_NL; ++j) {
           const bool ok = pok & (b_base[j] != OOB) & ((unsigned)(by + b_dy[j]) < (unsigned)a.H) & ((unsigned)(bx + b_dx[j]) < (unsigned)a.W);
@@ -404,34 +420,54 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
     l.x = __uint_as_float(__builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302));
     l.y = __uint_as_float(__builtin_amdgcn_perm(__float_as_uint(s3), __float_as_uint(s2), 0x07060302));
   };
-  auto store_tiles = [&](int buf) {
-    float* As = smem + buf * STAGE;
-    float* Bs = As + A_FLOATS;
+  // PREC 5: the split pieces of the gathered rows wait in registers (sa / sb) between the split -- interleaved with the MFMAs of the running K-step -- and the
+  // LDS write behind the barrier
+  float2 sa[SPL ? A_N : 1][3], sb[SPL ? B_N : 1][3];
+  auto split_a = [&]() {
     if constexpr (SPL) {
 #pragma unroll
+      for (int i = 0; i < A_N; ++i) split4(ra[i], sa[i][0], sa[i][1], sa[i][2]);
+    }
+  };
+  auto split_b = [&]() {
+    if constexpr (SPL) {
+#pragma unroll
+      for (int i = 0; i < B_N; ++i) split4(rb[i], sb[i][0], sb[i][1], sb[i][2]);
+    }
+  };
+  auto write_planes = [&](int buf) {
+    if constexpr (SPL) {
+      float* As = smem + buf * STAGE;
+      float* Bs = As + A_FLOATS;
+#pragma unroll
       for (int i = 0; i < A_N; ++i) {
-        float2 h, m, l;
-        split4(ra[i], h, m, l);
         if constexpr (A_KC) {
           float* d = As + (r + 32 * i) * LD5 + g * 2;
-          *reinterpret_cast<float2*>(d) = h, *reinterpret_cast<float2*>(d + 16) = m, *reinterpret_cast<float2*>(d + 32) = l;
+          *reinterpret_cast<float2*>(d) = sa[i][0], *reinterpret_cast<float2*>(d + 16) = sa[i][1], *reinterpret_cast<float2*>(d + 32) = sa[i][2];
         } else {
           float* d = As + (r * LDA_T + (g + 8 * i) * 4) / 2;
-          *reinterpret_cast<float2*>(d) = h, *reinterpret_cast<float2*>(d + PLANE_A) = m, *reinterpret_cast<float2*>(d + 2 * PLANE_A) = l;
+          *reinterpret_cast<float2*>(d) = sa[i][0], *reinterpret_cast<float2*>(d + PLANE_A) = sa[i][1], *reinterpret_cast<float2*>(d + 2 * PLANE_A) = sa[i][2];
         }
       }
 #pragma unroll
       for (int i = 0; i < B_N; ++i) {
-        float2 h, m, l;
-        split4(rb[i], h, m, l);
         if constexpr (B_KC) {
           float* d = Bs + (r + 32 * i) * LD5 + g * 2;
-          *reinterpret_cast<float2*>(d) = h, *reinterpret_cast<float2*>(d + 16) = m, *reinterpret_cast<float2*>(d + 32) = l;
+          *reinterpret_cast<float2*>(d) = sb[i][0], *reinterpret_cast<float2*>(d + 16) = sb[i][1], *reinterpret_cast<float2*>(d + 32) = sb[i][2];
         } else {
           float* d = Bs + (r * LDB_T + (g + 8 * i) * 4) / 2;
-          *reinterpret_cast<float2*>(d) = h, *reinterpret_cast<float2*>(d + PLANE_B) = m, *reinterpret_cast<float2*>(d + 2 * PLANE_B) = l;
+          *reinterpret_cast<float2*>(d) = sb[i][0], *reinterpret_cast<float2*>(d + PLANE_B) = sb[i][1], *reinterpret_cast<float2*>(d + 2 * PLANE_B) = sb[i][2];
         }
       }
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float* As = smem + buf * STAGE;
+    float* Bs = As + A_FLOATS;
+    if constexpr (SPL) {
+      split_a();
+      split_b();
+      write_planes(buf);
       return;
     }
     if constexpr (NAT16) {      // two pixel rows per thread (r, r + 32), 16 bytes = eight channels per gather, stored as they are
@@ -626,7 +662,51 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
 
   // ---- main loop: the gathers of slab kt+1 are issued (branch-free) ahead of the MFMAs of slab kt, whose 4096 matrix-pipe
   // cycles cover the load latency; LDS is double-buffered, one barrier per K-step ----------------------------------------
-  if constexpr (NST == 1) {
+  if constexpr (SPL && NST == 1) {
+    // PREC 5, one LDS stage, two blocks per CU. A wave's split (VALU) runs in the shadow of its OWN MFMAs -- measured: two equal waves on a SIMD do not fill each
+    // other's phases (VALU issue 44 % + matrix pipe 57 % of the cycles, no overlap) -- so the K-step is software-pipelined inside the wave:
+    //   first 16-k group's MFMAs  | split of the A rows of step kt + 1 (registers -> registers) | A gathers of step kt + 2 issued
+    //   second 16-k group's MFMAs | split of the B rows of step kt + 1                          | B gathers of step kt + 2 issued
+    //   barrier | write the planes of step kt + 1 | barrier
+    // A gather has one K-step (~1.5 k cycles) to land before its split; a gather beyond the last K-step presents out-of-range offsets (no traffic).
+    if (nk > 0) {
+      load_tiles(0);
+      advance();
+      split_a(), split_b();
+      write_planes(0);
+      __syncthreads();
+      load_tiles(1);
+      advance();
+      constexpr int NDS = 3 * (TM * (A_KC ? 1 : 2) + TN * (B_KC ? 1 : 2));      // fragment reads of one 16-k group
+      constexpr int NMF = 6 * TM * TN;                                           // MFMAs of one 16-k group
+      for (int kt = 0; kt < nk; ++kt) {
+        compute_kg(0, 0);
+        split_a();
+        load_tiles(kt + 2, 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
+#pragma unroll
+        for (int q = 0; q < NMF; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x006, 5, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        compute_kg(0, 2);
+        split_b();
+        load_tiles(kt + 2, 2);
+        __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
+#pragma unroll
+        for (int q = 0; q < NMF; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x006, 5, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();          // every wave is done reading the single buffer
+        write_planes(0);          // unconditional (behind the last K-step: zeros nobody reads) and in the same basic block as the splits: a conditional write lets
+        __syncthreads();          // the compiler sink the split arithmetic behind the barrier, out of the MFMAs' shadow
+        advance();                // (its wave-uniform branches end the block: behind the write for the same reason)
+      }
+    }
+  } else if constexpr (NST == 1) {
     if (nk > 0) {
       load_tiles(0);
       advance();

@@ -34,17 +34,19 @@ void launch_split(const ConvK& k, dim3 grid, size_t smem, hipStream_t st) {
   hipLaunchKernelGGL((conv_igemm_kernel<MODE, BM, BN, 2, 2, KM, 5, NST>), grid, dim3(256), bytes, st, k);
 }
 
+template <int MODE, int BM, int BN, int KM>
+void launch_nst(const ConvK& k, dim3 grid, size_t smem, bool nst1, hipStream_t st) {
+  if (nst1) launch_split<MODE, BM, BN, KM, 1>(k, grid, smem, st);
+  else launch_split<MODE, BM, BN, KM, 2>(k, grid, smem, st);
+}
+
 template <int MODE, int BM, int BN>
 void launch_km(const ConvK& k, dim3 grid, size_t smem, bool nst1, hipStream_t st) {
+  if (k.kmode == K_SMALL) return launch_nst<MODE, BM, BN, K_SMALL>(k, grid, smem, nst1, st);
   if constexpr (MODE != MODE_WGRAD) {
-    if (k.kmode == K_FAST) {
-      if (nst1) launch_split<MODE, BM, BN, K_FAST, 1>(k, grid, smem, st);
-      else launch_split<MODE, BM, BN, K_FAST, 2>(k, grid, smem, st);
-      return;
-    }
+    if (k.kmode == K_FAST) return launch_nst<MODE, BM, BN, K_FAST>(k, grid, smem, nst1, st);
   }
-  if (nst1) launch_split<MODE, BM, BN, K_MID, 1>(k, grid, smem, st);
-  else launch_split<MODE, BM, BN, K_MID, 2>(k, grid, smem, st);
+  launch_nst<MODE, BM, BN, K_MID>(k, grid, smem, nst1, st);
 }
 
 template <int MODE>
@@ -72,10 +74,6 @@ size_t pm_conv_split_stage_bytes(int mode, int bm, int bn) {
 
 int pm_conv_split_launch(int mode, int bm, int bn, const ConvK& k, unsigned gx, unsigned gy, unsigned gz, size_t smem, bool nst1, hipStream_t st) {
   const dim3 grid(gx, gy, gz);
-  if (k.kmode == K_SMALL) {
-    pm_set_error("conv_split: K_SMALL shapes stay on the fp32 MFMA kernel");
-    return PM_EUNSUPPORTED;
-  }
   if (mode == MODE_FWD) return launch_tile<MODE_FWD>(bm, bn, k, grid, smem, nst1, st);
   if (mode == MODE_DGRAD) return launch_tile<MODE_DGRAD>(bm, bn, k, grid, smem, nst1, st);
   return launch_tile<MODE_WGRAD>(bm, bn, k, grid, smem, nst1, st);
