@@ -224,6 +224,61 @@ def mldg(a):
                       'roofline': None, 'cpu_baseline': None}), flush=True)
 
 
+def mldg_side(torch, harness, K, net, opt, sched, x, y, tier, steps=5, warm=2):
+    """side.mldg / side.mldg_bf16 of the default line: the regime every pinmem script runs (train_GS_pinmem_DR50V3P.sh:9-10,18 -> train.py:493-632),
+    4 meta-train + 4 meta-test images of the SAME model and batch, inner_lr 1e-3 then lr / 4 (--inner_lr_anneal), timed as eager launches and as ONE hipGraph launch per
+    step (harness.GraphedMldgStep). The reported form follows the side.bf16 rule: the graph form when the eager step's host enqueue exceeds 0.8 x its wall time."""
+    import copy
+    K.set_conv_precision(tier)
+    h = x.shape[0] // 2
+    u1, u2 = copy.deepcopy(net), copy.deepcopy(net)
+    inner = [harness.INNER_LR]
+
+    def step():
+        out = harness.mldg_train_step(net, u1, u2, opt, x[:h], y[:h], x[h:], y[h:], inner_lr=inner[0], sched=sched, inner_lr_anneal=True)
+        inner[0] = out.pop('next_inner_lr')
+        return out
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        le = step()
+    torch.cuda.synchronize()
+    eager_ms = (time.perf_counter() - t0) / steps * 1e3
+    enq = host_enqueue_ms(step)
+    what = ('train_memory_mldg (train.py:493-632; train_GS_pinmem_DR50V3P.sh:9-10,18): %d meta-train + %d meta-test images %dx%d of the same model, inner fwd + bwd (retain_graph), '
+            "theta' = theta - inner_lr g for two weight sets (inner_lr 1e-3, then lr / 4), frozen-encoder memory write, meta-test fwd + bwd through the written memory, SGD, "
+            'eval-mode memory-commit fwd; %s' % (h, x.shape[0] - h, x.shape[2], x.shape[3], 'bf16 tier' if tier == 'bf16' else 'fp32 tier'))
+    rec = {'workload': what, 'ms_per_step': round(eager_ms, 3), 'value': round(x.shape[0] / eager_ms * 1e3, 3), 'unit': 'imgs/sec', 'steps': steps, 'warmup': warm, 'dtype': tier,
+           'form': 'eager launches', 'host_enqueue_ms': enq, 'final_losses': {k: round(float(v), 5) for k, v in le.items()}, 'measured': 'after the timed fp32 region of this run, same process'}
+    try:
+        g = harness.GraphedMldgStep(net, u1, u2, opt, x[:h], y[:h], x[h:], y[h:], inner_lr=inner[0], sched=sched, warmup=0, inner_lr_anneal=True)
+        for _ in range(2):
+            g.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            lg = g.step()
+        torch.cuda.synchronize()
+        graph_ms = (time.perf_counter() - t0) / steps * 1e3
+        enq_g = host_enqueue_ms(lambda: g.step())
+        lg = {k: round(float(v), 5) for k, v in lg.items() if k != 'next_inner_lr'}
+        g.close()
+        graphed = {'ms_per_step': round(graph_ms, 3), 'value': round(x.shape[0] / graph_ms * 1e3, 3), 'host_enqueue_ms': enq_g, 'final_losses': lg,
+                   'form': 'one hipGraph launch per step (harness.GraphedMldgStep; bit-identical to eager steps: tests/test_model_parity.py::test_graphed_mldg_step_is_bit_identical_to_eager)'}
+        if enq > 0.8 * eager_ms:
+            rec['eager'] = {k: rec[k] for k in ('ms_per_step', 'value', 'form', 'host_enqueue_ms', 'final_losses')}
+            rec.update(graphed)
+            rec['form_rule'] = 'host_enqueue_ms %.1f > 0.8 x eager ms_per_step %.1f: the hipGraph form is the one reported' % (enq, eager_ms)
+        else:
+            rec['graphed'] = graphed
+            rec['form_rule'] = 'host_enqueue_ms %.1f <= 0.8 x eager ms_per_step %.1f: eager launches are GPU-bound and stay the reported form' % (enq, eager_ms)
+    except Exception as e:      # noqa: BLE001
+        rec['graphed'] = {'error': repr(e)}
+    return rec
+
+
 def physical_cores():
     """Physical cores of the host: unique (physical id, core id) pairs of /proc/cpuinfo, capped by the CPUs this process may run on."""
     try:
@@ -411,6 +466,9 @@ PREC_NAMES = ('v_mfma_f32_32x32x2_f32', 'v_mfma_f32_32x32x16_bf16 on fp32 tiles 
               'v_mfma_f32_32x32x16_bf16 on bf16 LDS tiles filled by global_load_lds (LDS-DMA), source-side XOR swizzle')
 
 
+DOMINANT = {'split': False}      # set by dominant_conv_kernel: the dominant kernel of the fp32 tier is a split-operand instantiation (bf16 matrix pipe)
+
+
 def dominant_conv_kernel(K, bf16):
     """The convolution-kernel instantiation with the largest total time among the launches recorded since the last clear (in-library HIP events, pm_profile_*):
     -> ((ms, flops, launches), symbol, description) or None. conv_igemm_kernel<mode, bm, bn, wm, wn, km, prec, nst> (csrc/conv_igemm.hip) and, on the bf16 tier,
@@ -421,13 +479,21 @@ def dominant_conv_kernel(K, bf16):
             for bn in (256, 128, 64, 32):
                 for km in (0, 1, 2):
                     for nst in (3, 2, 1):
-                        for prec in ((0,) if not bf16 else ((5,) if mode >= 4 else (2, 4, 3, 1))):
+                        for prec in ((0, 5) if not bf16 else ((5,) if mode >= 4 else (2, 4, 3, 1))):      # fp32 tier: 0 = fp32 MFMA, 5 = split operands on the bf16 pipe
                             r = K.profile_read(mode=mode, bm=bm, bn=bn, km=km, nst=nst, prec=prec)
                             if r[2] and (best is None or r[0] > best[0][0]):
                                 best = (r, (mode, bm, bn, km, nst), prec)
     if best is None:
         return None
     r, (mode, bm, bn, km, nst), kprec = best
+    DOMINANT['split'] = (not bf16) and kprec == 5
+    if DOMINANT['split']:
+        sym = 'conv_igemm_kernel<%d, %d, %d, 2, 2, %d, 5, %d>' % (mode, bm, bn, km, nst)
+        what = ('%s, %dx%dx32 tile, %s K-state, %s LDS; fp32 operands, 3-way exact bf16 split (hi + mid + lo == x) as the gathered rows are stored to LDS, 6 cross products on '
+                'v_mfma_f32_32x32x16_bf16, fp32 accumulate (csrc/conv_split.hip); direct convolutions and the batched Winograd F(4x4,3x3) / F(2x2,3x3) GEMMs; '
+                'FLOPs = 2*M*N*K of the fp32 problem' % (('forward', 'data gradient', 'weight gradient')[mode], bm, bn, ('wave-uniform', 'per-lane', 'per-lane looping')[km],
+                                                        'double-buffered' if nst == 2 else 'single-stage'))
+        return r, sym, what
     if mode == 5 and km == 1:
         sym = 'conv16p_kernel<%d, %d, %s, 4>' % (bm, bn, '4, 2' if bm == 256 else '2, 4')
         what = ('forward / stride-1 data gradient on bf16 activations, persistent form: one block per CU walks %dx%dx64 tiles, four producer waves keep a three-stage LDS '
@@ -699,8 +765,13 @@ def main():
                                        'bench.py --steps 1 --warmup 1; read = 2 x FETCH_SIZE (gfx950), average over all launches of the symbol')
             except (OSError, KeyError, ValueError, IndexError, TypeError):
                 pass
-            roof = {'bound': 'mfma', 'kernel': '%s (%s)' % (sym, what), 'achieved': round(ach, 2),
-                    'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_source': traffic_src,
+            split_dom = DOMINANT['split']
+            # a split-operand kernel executes SIX bf16 MFMA products per fp32 multiply-add: `achieved` is what the matrix pipe really ran (6 x 2*M*N*K) against the bf16
+            # peak; `effective_fp32_tflops` is the fp32 work it delivered (to set beside the 157.3 TF of v_mfma_f32_32x32x2_f32)
+            roof = {'bound': 'mfma', 'kernel': '%s (%s)' % (sym, what), 'achieved': round(ach * (6 if split_dom else 1), 2),
+                    'peak': PEAK_TFLOPS_BF16_MFMA if split_dom else peak, 'unit': 'TFLOP/s', 'frac': round(ach * (6 if split_dom else 1) / (PEAK_TFLOPS_BF16_MFMA if split_dom else peak), 4),
+                    'effective_fp32_tflops': round(ach, 2), 'effective_vs_fp32_mfma_peak': round(ach / PEAK_TFLOPS_F32_MFMA, 4),
+                    'traffic': traffic, 'traffic_source': traffic_src,
                     'traffic_stale': traffic_stale,
                     'launches_per_step': n / prof_steps, 'avg_launch_ms': round(ms / n, 5), 'gflop_per_launch': round(fl / n / 1e9, 3),
                     'measured': '%d extra steps after the timed region (event timing costs ~1.7 ms/step, so the timed region runs without it), all launches '
@@ -785,6 +856,16 @@ def main():
         finally:
             K.set_conv_precision('f32')
             _ops.OVERLAP_WGRAD, harness.COMMIT_OVERLAP = overlap_defaults
+        # the regime every pinmem script runs, on both tiers, eager and captured (never part of `value`; failures are recorded, not raised)
+        for tier, key in (('f32', 'mldg'), ('bf16', 'mldg_bf16')):
+            try:
+                harness.finish_commit(net)
+                torch.cuda.synchronize()
+                side[key] = mldg_side(torch, harness, K, net, opt, sched, x, y, tier)
+            except Exception as e:      # noqa: BLE001
+                side[key] = {'error': repr(e)}
+            finally:
+                K.set_conv_precision('f32')
     if rank == 0:
         imgs = a.batch * world * a.steps
         gf_img = STEP_GFLOP_PER_IMG * (a.size / 768.0) ** 2      # conv FLOPs scale with the pixel count
@@ -795,7 +876,8 @@ def main():
                                       '(fwd + bwd + SGD + eval-mode memory-commit fwd%s)' % ('configs[2]' if bf16 else 'configs[1]', a.batch, a.size, a.size,
                                                                                             {'bf16': 'bf16 tier: bf16 activations and activation gradients between layers, bf16-MFMA convolutions with fp32 accumulation, fp32 statistics / losses / memory / parameters',
                                                                                              'bf16_operands': 'bf16-MFMA convolutions (bf16 operands in HBM and LDS, fp32 accumulation; fp32 activations between layers)',
-                                                                                             'bf16_staged': 'bf16-MFMA (fp32 tiles staged, rounded per fragment)', 'f32': 'fp32'}[a.dtype],
+                                                                                             'bf16_staged': 'bf16-MFMA (fp32 tiles staged, rounded per fragment)',
+                                                                                             'f32': 'fp32 storage / accumulation / results; the contractions run on the bf16 matrix pipe: fp32 operands, 3-way exact bf16 split, 6 products, fp32 accumulate (reductions <= 128 and outputs < 64 columns stay on v_mfma_f32_32x32x2_f32)' if os.environ.get('PM_SPLIT', '1') != '0' else 'fp32'}[a.dtype],
                                                                                             ', decoder skipped in the commit fwd' if a.truncate_second_forward else ''),
                           'global_batch': a.batch * world, 'crop': a.size, 'parallelism': 'dp%d' % world,
                           'ranks_seen': ranks_seen, 'ranks_seen_source': ('ncclCommCount of the direct RCCL communicator' if multi and backend == 'nccl' and ranks_seen == world and _rccl.get(None) is not None

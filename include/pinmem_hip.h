@@ -126,7 +126,7 @@ int pm_conv_bwd_weight(const pm_tensor* x, const pm_tensor* dy, float* dw_krsc, 
                        void* ws, size_t ws_bytes, void* stream);
 
 /* ---- PROCESS-GLOBAL DEBUG / A-B SWITCHES (the only mutable global state of the library; SURVEY 8(b) "no global mutable state" holds for everything else) ----------
- * pm_set_winograd, pm_set_winograd_fused, pm_set_conv16, pm_set_wgrad16, pm_set_bf16_wgrad and pm_profile_enable flip process-wide ROUTING / MEASUREMENT switches. They exist for
+ * pm_set_winograd, pm_set_winograd_fused, pm_set_conv16, pm_set_wgrad16, pm_set_split, pm_set_bf16_wgrad and pm_profile_enable flip process-wide ROUTING / MEASUREMENT switches. They exist for
  * same-box A/B runs, kernel tests that must reach a specific kernel, and bench.py's roofline leg; they never change WHAT is computed (every route is parity-tested
  * against the same oracle), only which kernel computes it or whether launches are timed. Contract: call them from ONE thread while no other thread is inside a
  * pm_conv_* entry point (the switches are plain ints read at plan time: a concurrent flip is a benign race between two valid routes for an in-flight PLAN, but the
@@ -163,6 +163,12 @@ int pm_set_bf16_wgrad(int on);
  * through the transpose read), 0 = the register-staged implicit-GEMM kernel everywhere (A/B runs, kernel tests). Same split-K slabs, same fixed-order reduce.
  * Process-wide like pm_set_winograd; PM_WGRAD16=0 in the environment sets the default. */
 int pm_set_wgrad16(int on);
+/* fp32 tier (round 6): which fp32 convolution / Winograd-GEMM launches run on the bf16 matrix pipe -- fp32 operands, every element split exactly into three bf16
+ * pieces inside the kernel (hi + mid + lo == x), six cross products on v_mfma_f32_32x32x16_bf16, fp32 accumulation, fp32 results (csrc/conv_split.hip; replaces the
+ * nn.Conv2d of Resnet.py:145-150 / deepv3plus.py:72-81,397-414 like the fp32-MFMA kernel it stands in for). 1 (default; PM_SPLIT in the environment) = every eligible
+ * launch (output tiles >= 64 columns wide; forward / data-gradient reductions of >= 129, batched Winograd products of any length), 0 = v_mfma_f32_32x32x2_f32 everywhere
+ * (A/B runs, accuracy tests). Same results to fp32 round-off (tests/test_hip_kernels.py::test_split_path_accuracy_vs_fp64). Process-wide like pm_set_winograd. */
+int pm_set_split(int on);
 
 /* In-library HIP-event timing of the implicit-GEMM kernel (bench.py's roofline leg). While enabled every conv launch is
  * bracketed by two events on its stream; pm_profile_read sums duration and algorithmic FLOPs (2*M*N*K) of one

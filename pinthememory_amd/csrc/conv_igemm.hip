@@ -403,7 +403,11 @@ bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 
 inline bool split_takes(int mode, const Plan& p, const ConvK& k, int batch) {      // batched launches (the Winograd point products: their output stays in L2) at every K
-  return g_split != 0 && p.bn >= 64 && !k.io16 && (batch > 1 || split_k_ok(mode, k.K));
+  static const int modes = getenv("PM_SPLIT_MODES") ? atoi(getenv("PM_SPLIT_MODES")) : 7;      // bisecting knob: bit 0 forward form, 1 data gradient, 2 weight gradient
+  static const int bsel = getenv("PM_SPLIT_BATCH") ? atoi(getenv("PM_SPLIT_BATCH")) : 0;      // bisecting knob: 1 only batched launches, 2 only unbatched ones
+  static const int maxm = getenv("PM_SPLIT_MIN_M") ? atoi(getenv("PM_SPLIT_MIN_M")) : 0;
+  if ((bsel == 1 && batch <= 1) || (bsel == 2 && batch > 1) || k.M < maxm) return false;
+  return g_split != 0 && ((modes >> mode) & 1) && p.bn >= 64 && !k.io16 && (batch > 1 || split_k_ok(mode, k.K));
 }
 
 template <int MODE>
@@ -984,6 +988,10 @@ extern "C" int pm_set_winograd_fused(int on) {
 extern int g_wgrad16;      // wgrad16.hip
 extern "C" int pm_set_wgrad16(int on) {
   g_wgrad16 = on != 0;
+  return PM_OK;
+}
+extern "C" int pm_set_split(int on) {
+  g_split = on ? 1 : 0;
   return PM_OK;
 }
 extern "C" int pm_set_bf16_wgrad(int on) {

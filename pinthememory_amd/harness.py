@@ -232,6 +232,7 @@ class GraphedAggStep:
         self.gts = gts.clone()
         self.lr = torch.zeros(1, dtype=torch.float32, device=x.device)
         prev_overlap, COMMIT_OVERLAP = COMMIT_OVERLAP, False
+        ok = False
         try:
             opt.lr_device = self.lr
             for _ in range(warmup):      # allocates workspaces, momentum buffers, filter caches, sets every kernel's LDS attribute
@@ -271,8 +272,14 @@ class GraphedAggStep:
             ops.commit_done.pop(x.device.index, None)
             ops.last_prefold_event = None
             K.forget_filter_events()
+            ok = True
         finally:
             COMMIT_OVERLAP = prev_overlap
+            if not ok:      # a failed warm-up / capture must not leave the optimizer reading a dead device scalar or the memory pointing into the capture
+                opt.lr_device = None
+                m.memory.m_items = (self.mem if getattr(self, 'mem', None) is not None else m.memory._m_items).detach().clone()
+                m.memory.pending = None
+                ops.commit_done.pop(x.device.index, None)
 
     def _commit(self, main, overlap, into=None):
         """The withheld commit forward of the previous batch: from the static memory buffer, result copied back into it (or into `into`)."""
@@ -445,6 +452,7 @@ def functional_theta(old, lr):
         names.append(k)
         ps.append(p)
     idx = [i for i, p in enumerate(ps) if p.grad is not None]
+    # lr: a python float, or a 0-dim fp32 device tensor (GraphedMldgStep: the annealed inner rate changes between replays) -- the same fp32 multiply either way
     upd = torch._foreach_sub([ps[i] for i in idx], torch._foreach_mul([ps[i].grad for i in idx], lr)) if idx else []
     theta = {k: p.detach() for k, p in zip(names, ps)}
     for i, u in zip(idx, upd):
@@ -504,6 +512,126 @@ def mldg_train_step(net, updated_net, updated_net2, opt, x_tr, y_tr, x_te, y_te,
     if inner_lr_anneal:
         out['next_inner_lr'] = annealed_inner_lr(opt)
     return out
+
+
+def release_functional_state(net, *functional_nets):
+    """Drop every reference the harness objects hold into the autograd graph of an earlier iteration: the functional networks' theta' (rewired to detached views of
+    `net`'s parameters), the memories written without detaching, the deferred weight proxies of the last forward. See GraphedMldgStep.__init__ for why a capture needs it."""
+    import gc
+    plain = {k: p.detach() for k, p in net.named_parameters()}
+    for u in functional_nets:
+        put_theta(u, plain)
+    for m in (net,) + tuple(functional_nets):
+        mem = getattr(m, 'memory', None)
+        if mem is not None:
+            mem._m_items = mem._m_items.detach()
+            mem.last_read = None
+    ops._proxy.clear()
+    gc.collect()
+
+
+class GraphedMldgStep:
+    """One train_memory_mldg iteration (train.py:493-632: inner forward + backward with retain_graph, the two functional weight sets theta' = theta - inner_lr g,
+    frozen-encoder memory write, meta-test forward + backward through the written memory, SGD, eval-mode memory-commit forward) captured in ONE hipGraph and
+    replayed. The regime every pinmem script runs (train_GS_pinmem_DR50V3P.sh:9-10,18) enqueues ~2 400 launches per step: on the bf16 tier 33-35 ms of host time
+    against 30 ms of GPU time -- host-bound as eager launches. What makes it replayable on top of GraphedAggStep's list: the inner learning rate is a device
+    scalar (`--inner_lr_anneal` changes it every iteration: train.py:625-626), the functional networks are rewired once at capture (their theta' tensors live in
+    the graph's memory pool and are recomputed by every replay), the committed memory lives in one static buffer that the captured step reads first and writes last.
+    Bit-identical to eager mldg_train_step calls (tests/test_model_parity.py::test_graphed_mldg_step_is_bit_identical_to_eager). Single process only.
+
+        g = GraphedMldgStep(net, u1, u2, opt, x_tr, y_tr, x_te, y_te, sched=sched, inner_lr_anneal=True)      # warms up eagerly, then captures
+        out = g.step(x_tr, y_tr, x_te, y_te)      # tensors of the returned dict are overwritten by the next replay; out['next_inner_lr'] as mldg_train_step
+        g.close()
+    """
+
+    def __init__(self, net, updated_net, updated_net2, opt, x_tr, y_tr, x_te, y_te, inner_lr=INNER_LR, sched=None, warmup=2, inner_lr_anneal=False):
+        assert x_tr.is_cuda and not D.is_dist(), 'GraphedMldgStep: single-process GPU training only'
+        assert len(opt.param_groups) == 1, 'GraphedMldgStep: one parameter group (optimizer.py:21-25)'
+        self.net, self.u1, self.u2, self.opt, self.sched, self.anneal, self.closed = net, updated_net, updated_net2, opt, sched, inner_lr_anneal, False
+        self.x_tr, self.y_tr, self.x_te, self.y_te = x_tr.clone(), y_tr.clone(), x_te.clone(), y_te.clone()
+        dev = x_tr.device
+        self.lr = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.inner = torch.zeros((), dtype=torch.float32, device=dev)      # 0-dim: torch._foreach_mul's tensor-scalar overload
+        self.inner_lr = float(inner_lr)
+        # Warm-up and capture run on ONE side stream, after every reference into an earlier autograd graph has been dropped. An autograd AccumulateGrad node remembers the
+        # stream it was created on and lives as long as any graph refers to it; the functional networks keep theta' -- hence the graph of the inner step, hence every
+        # parameter's node -- alive BETWEEN iterations. A node born in eager code on the default stream would be reused inside the capture and enqueue its accumulation on
+        # that (non-capturing) stream: hipStreamEndCapture crashes (tools/mldg_graph_probe.py: the bisection). GraphedAggStep never meets this: its graphs die with each step.
+        self.stream = torch.cuda.Stream(device=dev)
+        ok = False
+        try:
+            opt.lr_device = self.lr
+            finish_commit(net)
+            release_functional_state(net, updated_net, updated_net2)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(self.stream):
+                for _ in range(max(1, warmup)):      # allocates workspaces, momentum buffers, filter caches, sets every kernel's LDS attribute; >= 1: the nodes are reborn on this stream
+                    self._eager()
+                self.mem = net.memory.m_items.detach().clone()
+                net.memory.m_items = self.mem
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            self._fill()
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                self.out = mldg_train_step(net, updated_net, updated_net2, opt, self.x_tr, self.y_tr, self.x_te, self.y_te, inner_lr=self.inner, sched=None)
+                self.mem.copy_(net.memory.m_items)
+                if ops.overlap_wgrad():      # every stream forked into the capture rejoins it
+                    torch.cuda.current_stream().wait_stream(ops._side_stream())
+            torch.cuda.synchronize()
+            net.memory.pending = None
+            net.memory.m_items = self.mem
+            ops.commit_done.pop(dev.index, None)
+            ops.last_prefold_event = None
+            K.forget_filter_events()
+            ok = True      # (a capture records, it does not execute: the model is where the warm-up left it)
+        finally:
+            if not ok:      # ADVICE r5: a failed warm-up / capture must not leave the optimizer reading a dead device scalar
+                opt.lr_device = None
+                if getattr(self, 'mem', None) is not None:
+                    net.memory.m_items = self.mem.clone()
+                net.memory.pending = None
+
+    def _fill(self):
+        self.lr.fill_(float(self.opt.param_groups[0]['lr']))
+        self.inner.fill_(self.inner_lr)
+
+    def _after(self):
+        if self.sched is not None:
+            self.sched.step()
+        if self.anneal:
+            self.inner_lr = annealed_inner_lr(self.opt)
+
+    def _eager(self):
+        self._fill()
+        mldg_train_step(self.net, self.u1, self.u2, self.opt, self.x_tr, self.y_tr, self.x_te, self.y_te, inner_lr=self.inner, sched=None)
+        self._after()
+
+    def step(self, x_tr=None, y_tr=None, x_te=None, y_te=None):
+        assert not self.closed, 'GraphedMldgStep.step() after close()'
+        for dst, src in ((self.x_tr, x_tr), (self.y_tr, y_tr), (self.x_te, x_te), (self.y_te, y_te)):
+            if src is not None and src.data_ptr() != dst.data_ptr():
+                dst.copy_(src)
+        self._fill()
+        self.graph.replay()
+        self._after()
+        out = dict(self.out)
+        if self.anneal:
+            out['next_inner_lr'] = self.inner_lr
+        return out
+
+    def close(self):
+        """Hand model and optimizer back to eager code (the memory becomes a private tensor again, the optimizer forgets the capture's device-side learning rate)."""
+        if self.closed:
+            return
+        torch.cuda.synchronize()
+        self.net.memory.m_items = self.mem.clone()
+        self.net.memory.pending = None
+        ops.commit_done.pop(self.x_tr.device.index, None)
+        if getattr(self.opt, 'lr_device', None) is self.lr:
+            self.opt.lr_device = None
+        release_functional_state(self.net, self.u1, self.u2)      # eager code gets fresh autograd nodes on ITS stream (the captured ones were born on the capture stream)
+        self.closed = True
+        torch.cuda.synchronize()
 
 
 # ---- pooled multi-scale / flip evaluation: inference_pool + MeanFusion (eval.py:133-145,277-337) -------------------------

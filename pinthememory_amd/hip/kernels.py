@@ -866,6 +866,13 @@ def set_wgrad16(on):
     _GEN[0] += 1
 
 
+def set_split(on):
+    """fp32 tier: True (default) = eligible fp32 convolutions / Winograd GEMMs on the bf16 matrix pipe (three-way exact bf16 split, six products, fp32 accumulation:
+    csrc/conv_split.hip), False = the fp32-MFMA kernel everywhere."""
+    check(_lib().pm_set_split(1 if on else 0), 'pm_set_split')
+    _GEN[0] += 1
+
+
 def set_bf16_wgrad(on):
     check(_lib().pm_set_bf16_wgrad(1 if on else 0), 'pm_set_bf16_wgrad')
     _GEN[0] += 1

@@ -133,6 +133,7 @@ SIGNATURES = {
     'pm_sgd_momentum': (_i, [_vp, _vp, _vp, _i64, _f, _f, _f, _i, _vp]),
     'pm_set_bf16_wgrad': (_i, [_i]),
     'pm_set_wgrad16': (_i, [_i]),
+    'pm_set_split': (_i, [_i]),
     'pm_conv_bn_partials_bytes': (_sz, [_T, _T, POINTER(PmConvParams)]),
     'pm_bn_partials_finalize': (_i, [_vp, _i64, _i, _f, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
     'pm_sgd_momentum_multi': (_i, [_vp, _i, _f, _f, _f, _vp]),

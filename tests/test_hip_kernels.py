@@ -76,6 +76,52 @@ def test_conv_fwd_bwd(K, case):
         assert rel(db, br.grad) < 2e-5
 
 
+SPLIT_CASES = [
+    # n, cin, h, w, cout, k, stride, pad, dil   -- every gather form of the split path (conv_split.hip): k-contiguous / m-contiguous operands, the three K-state modes
+    (2, 256, 24, 24, 512, 1, 1, 0, 1),      # pointwise, K_FAST forward / data gradient; weight gradient over 1 152 pixels
+    (2, 512, 24, 24, 128, 1, 1, 0, 1),      # 128-column output (128 x 128 or 64 x 128 tile)
+    (1, 160, 20, 20, 192, 3, 1, 1, 1),      # direct 3x3 (channels below the Winograd route's 128 x 128 rule? no: taken -- see wino below), K_FAST
+    (2, 144, 17, 19, 136, 3, 1, 2, 2),      # channel counts that are no multiple of 32: K_MID gathers, ragged tiles
+    (2, 256, 24, 24, 256, 3, 2, 1, 1),      # stride 2: the parity-class data gradient (K_MID), a strided weight gradient
+    (2, 20, 12, 12, 192, 3, 1, 1, 1),       # Cin < 32: K_SMALL forward / weight gradient
+    (1, 2048, 12, 12, 256, 3, 1, 6, 6),     # ASPP-like deep reduction (Winograd F(4x4) point GEMMs when the route is on)
+]
+
+
+@pytest.mark.parametrize('case', SPLIT_CASES)
+def test_split_path_accuracy_vs_fp64(K, case, capsys):
+    """Round 6: the fp32 tier on the bf16 matrix pipe -- fp32 operands split exactly into three bf16 pieces, six cross products, fp32 accumulation --
+    must be an fp32 kernel, not a 16-bit-mantissa one: forward, input gradient and weight gradient against an fp64 convolution, next to the fp32-MFMA kernel
+    (pm_set_split(0)) on the same operands. A dropped or doubled piece would show as ~2^-16 = 1.5e-5 of the output scale (under the 2e-5 bar of the older kernel tests);
+    here the error must stay within 2 x the fp32 kernel's + 2e-7, both printed. With and without the Winograd route."""
+    n, cin, h, w, cout, k, s_, p, d = case
+    x = torch.relu(rnd(n, cin, h, w, seed=1)) + 0.01 * rnd(n, cin, h, w, seed=7)      # post-ReLU-like: mostly one sign, large sums
+    wt = rnd(cout, cin, k, k, seed=2, scale=(2.0 / (cin * k * k)) ** 0.5)
+    xr, wr = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, None, stride=s_, padding=p, dilation=d)
+    dy = rnd(*y_ref.shape, seed=4)
+    y_ref.backward(dy.double())
+    xg, wg, dyg = nhwc(x), wt.permute(0, 2, 3, 1).contiguous().cuda(), nhwc(dy)
+    errs = {}
+    try:
+        for wino in (4, 0):
+            K.set_winograd(wino)
+            for split in (True, False):
+                K.set_split(split)
+                y = K.conv_fwd(xg, wg, s_, p, d)
+                dx = K.conv_bwd_data(dyg, wg, tuple(xg.shape), s_, p, d)
+                dw, _ = K.conv_bwd_weight(xg, dyg, tuple(wg.shape), s_, p, d)
+                errs[(wino, split)] = (rel(nchw(y), y_ref.detach()), rel(nchw(dx), xr.grad), rel(dw.permute(0, 3, 1, 2), wr.grad))
+    finally:
+        K.set_split(True)
+        K.set_winograd(4)
+    with capsys.disabled():
+        print('\n[split vs fp64 %s] ' % (case,) + '; '.join('wino %d %s: y %.1e dx %.1e dw %.1e' % ((wn, 'split' if sp else 'fp32 ') + e) for (wn, sp), e in errs.items()))
+    for wino in (4, 0):
+        for es, e0 in zip(errs[(wino, True)], errs[(wino, False)]):
+            assert es <= 2.0 * e0 + 2e-7, (wino, errs)
+
+
 WINO_CASES = [
     # n, cin, h, w, cout, dil   (3x3, stride 1, pad == dil, both channel counts >= 128 -> Winograd F(2x2,3x3) route)
     (1, 304, 16, 16, 256, 1),
@@ -947,7 +993,8 @@ def test_conv_bf16_activations(K, case, route):
 
 
 @pytest.mark.parametrize('case', [(8, 512, 48, 48, 256, 3, 6, 6), (8, 1024, 48, 48, 512, 1, 0, 1), (8, 256, 47, 49, 256, 3, 1, 1), (5, 512, 48, 48, 19, 1, 0, 1),
-                                  (3, 128, 48, 48, 256, 3, 18, 18), (2, 192, 48, 40, 128, 3, 12, 12)])      # ASPP rates 18 / 12: whole filter rows invisible to the top / bottom tiles (skipped K-steps)
+                                  (3, 128, 48, 48, 256, 3, 18, 18), (2, 192, 48, 40, 128, 3, 12, 12),      # ASPP rates 18 / 12: whole filter rows invisible to the top / bottom tiles (skipped K-steps)
+                                  (1, 256, 192, 192, 256, 3, 1, 1)])      # the decoder's 3x3 at its real map size (36 864 rows: 144 tiles of the persistent ring) against the CPU formula
 def test_conv16_on_the_48x48_maps(K, case):
     """The LDS-DMA kernel at the shapes it carries in the step (bs=8: 18 432 rows, 576 ... 1 152 tiles of 64 x 128 on 256 CUs, a ragged last tile, the 19-column
     fp32 logits): forward with bias / folded scale-shift / residual / ReLU and the data gradient with its fused skip, each against the fp32 formula on the same
@@ -1015,6 +1062,7 @@ WGRAD16_CASES = [  # n, cin, h, w, cout, k, stride, pad, dil
     (3, 128, 17, 19, 256, 3, 1, 12, 12),     # dilation beyond the map: most taps see only padding
     (1, 304, 40, 36, 256, 3, 1, 1, 1),       # the decoder's concat: 2.5 channel blocks, the last one half empty (zeros fetched, columns beyond Cin not stored)
     (1, 200, 20, 20, 128, 1, 1, 0, 1),       # 1.56 blocks
+    (2, 256, 96, 96, 256, 3, 1, 1, 1),       # 18 432 pixels -- a reduction as long per split as the step's (the 48 x 48 maps at bs=8), against the CPU formula
 ]
 
 
@@ -1057,7 +1105,9 @@ def test_wgrad16_lds_dma_weight_gradient(K, case):
                                   (8, 320, 192, 192, 256, 3, 1, 1),        # decoder final1.0 (304 + 16 zero-pad channels as the concat buffer has them)
                                   (8, 2048, 48, 48, 256, 3, 12, 12)])      # ASPP rate 12: 288 K-steps, filter rows skipped per tile
 def test_persistent_kernels_at_production_size_under_default_routing(K, case):
-    """BASELINE configs[2] sizes (bs=8, 768^2): the shapes the planner hands to the persistent producer / consumer kernels (conv16w.hip conv16p_kernel, wgrad16.hip) under
+    """ROUTING + AGREEMENT OF TWO HIP KERNELS, NOT AN ORACLE COMPARISON (the formula checks are test_conv16_on_the_48x48_maps -- incl. 1 x 256 x 192 x 192 -- and
+    test_wgrad16_lds_dma_weight_gradient -- incl. an 18 432-pixel reduction). BASELINE configs[2] sizes (bs=8, 768^2): the shapes the planner hands to the persistent
+    producer / consumer kernels (conv16w.hip conv16p_kernel, wgrad16.hip) under
     DEFAULT routing really take them, and agree with the register-staged kernels on the same bf16 values: forward and input gradient to neighbouring bf16 values, the
     weight gradient to fp32 accumulation order. (The fp32 formula on the CPU would take minutes at this size: the independent kernel is the reference here, each of the
     two is checked against the formula on small shapes above.)"""
