@@ -77,7 +77,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 //           (tap, channel) are wave-uniform -> they live in SGPRs and the per-row work is add / compare / select;
 //   K_MID   channel extent (or Wo for wgrad) >= BK: at most one wrap per step, per-lane state, compare + select;
 //   K_SMALL extent < BK (stem Cin = 4, Cout = 19, tiny test images): per-lane state, looping wrap.
-enum { K_FAST = 0, K_MID = 1, K_SMALL = 2 };
+//   K_PW    (round 6, the split path's instantiations) K_FAST on a pointwise problem -- 1x1 / stride 1 / no padding, and every Winograd point product: a row's validity does
+//           not depend on the K-step, so it is folded into the row's base offset once and a gather costs ONE add per row (K_FAST: two compares, two adds, a select).
+enum { K_FAST = 0, K_MID = 1, K_SMALL = 2, K_PW = 3 };
 
 // Thread -> tile element mapping (256 threads, g = t & 7, r = t >> 3):
 //   k-contiguous (KC) tiles [rows][LDK]: thread owns k-group g (4 floats) of rows r + 32*i   -> 1 K-state, static rows
@@ -93,7 +95,8 @@ template <int MODE, int BM, int BN, int WM, int WN, int KM, int PREC, int NST, b
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   constexpr bool A_KC = (MODE != MODE_WGRAD);  // A tile stored [BM][LDK] (k contiguous) else [BK][BM]
   constexpr bool B_KC = (MODE == MODE_FWD);    // B tile stored [BN][LDK] else [BK][BN]
-  constexpr bool FAST = (KM == K_FAST) && (MODE != MODE_WGRAD);
+  constexpr bool FAST = (KM == K_FAST || KM == K_PW) && (MODE != MODE_WGRAD);
+  constexpr bool PW = (KM == K_PW) && (MODE != MODE_WGRAD);
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   // PREC 3 (weight gradient of the bf16 tier): the pixel-major (m-contiguous) tiles are kept in LDS as bf16 [BK][BM + 32] -- rounded once, as the
   // gathered fp32 rows are stored -- and the MFMA fragments (8 consecutive k per lane) come out of them through the hardware transpose read
@@ -173,7 +176,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
 #pragma unroll
     for (int i = 0; i < A_N; ++i) {
       const int m = m0 + r + 32 * i;
-      if (pointwise) {   // 1x1 / stride 1 / no padding (and every Winograd GEMM): pixel m of the operand, no index decomposition
+      if (PW) {          // the launcher vouches for a pointwise problem: rows beyond M carry an out-of-range base, nothing else is checked per K-step
+        a_y0[i] = a_x0[i] = 0;
+        a_base[i] = m < a.M ? m * (MODE == MODE_FWD ? xp4 : yp4) + g * 16 : OOB;
+      } else if (pointwise) {   // 1x1 / stride 1 / no padding (and every Winograd GEMM): pixel m of the operand, no index decomposition
         a_y0[i] = a_x0[i] = m < a.M ? 0 : -(1 << 28);
         a_base[i] = m < a.M ? m * (MODE == MODE_FWD ? xp4 : yp4) + (FAST ? g * 16 : 0) : 0;
       } else if (m < a.M) {
@@ -259,7 +265,28 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   auto load_tiles = [&](int kt, int which = 0) {   // branch-free: every lane always issues its loads, invalid ones at offset OOB. which: 0 both operands, 1 A only, 2 B only
     const int kbase = k_begin + kt * BKW;
     const bool doA = which != 2, doB = which != 1;
-    if constexpr (MODE == MODE_FWD) {
+    if constexpr (PW) {
+      // wave-uniform offsets; a K-step beyond the reduction (the software pipeline's run-ahead) moves every offset out of the descriptor's range: no traffic
+      const unsigned beyond = 0x80000000u;
+      const bool tok = u_tap < T;
+      if constexpr (MODE == MODE_FWD) {
+        const unsigned toff = (unsigned)(u_ch * 4) + (tok ? 0u : beyond), kb4 = kbase < k_end ? (unsigned)(kbase * 4) : beyond;
+        if (doA)
+#pragma unroll
+        for (int i = 0; i < A_N; ++i) ra[i] = bload(rA, (int)((unsigned)a_base[i] + toff));
+        if (doB)
+#pragma unroll
+        for (int i = 0; i < B_N; ++i) rb[i] = bload(rB, (int)((unsigned)b_base[i] + kb4));
+      } else {
+        const unsigned toff = (unsigned)(u_ch * 4) + (tok ? 0u : beyond), uoff = tok ? (unsigned)((u_ch * Treal + u_tap) * a.Cin * 4) : beyond;
+        if (doA)
+#pragma unroll
+        for (int i = 0; i < A_N; ++i) ra[i] = bload(rA, (int)((unsigned)a_base[i] + toff));
+        if (doB)
+#pragma unroll
+        for (int j = 0; j < B_N; ++j) rb[j] = bload(rB, (int)((unsigned)b_base[j] + uoff));
+      }
+    } else if constexpr (MODE == MODE_FWD) {
       const int ky = FAST ? u_ky : a_ky, kx = FAST ? u_kx : a_kx, tap = FAST ? u_tap : a_tap, ch = FAST ? u_ch : a_ch;
       const int dy = ky * a.dil, dx = kx * a.dil;
       const int toff = (dy * a.W + dx) * xp4 + ch * 4;

@@ -44,6 +44,7 @@ template <int MODE, int BM, int BN>
 void launch_km(const ConvK& k, dim3 grid, size_t smem, bool nst1, hipStream_t st) {
   if (k.kmode == K_SMALL) return launch_nst<MODE, BM, BN, K_SMALL>(k, grid, smem, nst1, st);
   if constexpr (MODE != MODE_WGRAD) {
+    if (k.kmode == K_FAST && k.kh * k.kw == 1 && k.stride == 1 && k.pad == 0 && !k.sub) return launch_nst<MODE, BM, BN, K_PW>(k, grid, smem, nst1, st);
     if (k.kmode == K_FAST) return launch_nst<MODE, BM, BN, K_FAST>(k, grid, smem, nst1, st);
   }
   launch_nst<MODE, BM, BN, K_MID>(k, grid, smem, nst1, st);
