@@ -548,7 +548,9 @@ WinoPlan wino_plan(const pm_tensor* xin, int cout, const pm_conv_params* p, bool
   if (wp.pl.bn == 128 && pm_cdiv(cout, 128) * 128 > cout * 1.12 && pm_cdiv(cout, 64) * 64 < pm_cdiv(cout, 128) * 128) wp.pl.bn = 64;
   // few transform tiles (the 48 x 48 maps with dilation: 1152 ... 4608 rows per GEMM): 128-row blocks leave the last round of the 256 CUs
   // half empty; 64 x 128 blocks measured -0.25 ms/step over those layers in situ (tools/gpu_tile_ab2.sh), nothing gained above
-  if (wp.pl.bm == 128 && wp.g.tiles <= 4608 && !getenv("PM_WINO_BM")) wp.pl.bm = 64;
+  // (the split path keeps 128 rows: 3.7 instead of 5.5 split instructions per MFMA outweigh the half-empty last round -- same box: 52.2 -> 51.7 ms/step, the deep ASPP
+  //  products 160-178 -> 188-200 TF)
+  if (wp.pl.bm == 128 && wp.g.tiles <= 4608 && !getenv("PM_WINO_BM") && !(g_split && g_split_tile)) wp.pl.bm = 64;
   wp.pl.tiles_m = pm_cdiv(wp.g.tiles, wp.pl.bm), wp.pl.tiles_n = pm_cdiv(cout, wp.pl.bn);
   wp.pl.ksplit = 1, wp.pl.kper = wp.Kp, wp.pl.ws_bytes = 0;
   wp.use = true;
