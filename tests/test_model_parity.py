@@ -705,6 +705,92 @@ def test_bf16_tier_assembled_gradients_vs_fp64_oracle(env, capsys):
         assert abs(h16['losses'][k].item() - t.item()) <= 2 * abs(emul['losses'][k].item() - t.item()) + 2e-3 * max(1.0, abs(t.item())), (k, h16['losses'][k].item(), emul['losses'][k].item(), t.item())
 
 
+STAGES = ('layer0', 'layer1', 'layer2', 'layer3', 'layer4', 'aspp', 'bot_', 'final1', 'final2', 'dsn', 'memory')
+
+
+def test_bf16_tier_gradients_at_production_size_vs_fp32_oracle(env, capsys):
+    """the bf16 tier's assembled gradients WHERE THE TIER RUNS -- bs=2 at 768 x 768 (192^2 / 96^2 / 48^2 maps, 4 608+ samples per BatchNorm channel)
+    instead of the 8 x 8 maps of the 128^2 test -- against the fp32 CPU oracle's gradients of the same batch (the step of test_config2_production_size_step_vs_oracle, memoised;
+    its own distance from fp64 is ~1e-3), next to the fp32 HIP path on the same batch. Per stage: median / worst relative error and the cosine to the oracle's gradient, printed;
+    gates at 2 x the values measured when the test was written (round 6) -- a finding to report, not to gate around: see DESIGN 0.4."""
+    from pinthememory_amd.hip import kernels as K
+    x, y = env['synth'].make_batch(2, 768)
+    o32 = _oracle(env, torch.float32, x, y, True)
+    h32 = _hip(env, x, y, True)
+    K.set_conv_precision('bf16')
+    try:
+        h16 = _hip(env, x, y, True)
+    finally:
+        K.set_conv_precision('f32')
+
+    def per_stage(res):
+        out = {}
+        for st in STAGES:
+            errs, cos = [], []
+            for k, t in o32['grads'].items():
+                if not k.startswith(st) or t.norm().item() < 1e-7:
+                    continue
+                g = res['grads'][k]
+                errs.append((g - t).norm().item() / t.norm().item())
+                cos.append((g.flatten() @ t.flatten()).item() / (g.norm().item() * t.norm().item() + 1e-300))
+            if errs:
+                errs.sort()
+                out[st] = (errs[len(errs) // 2], errs[-1], min(cos))
+        return out
+    p16, p32 = per_stage(h16), per_stage(h32)
+    with capsys.disabled():
+        print('\n[bf16 tier gradients vs the fp32 oracle, bs=2 768^2] stage: median / worst relative error, min cosine  (fp32 HIP path: median / worst)')
+        for st in STAGES:
+            if st in p16:
+                print('   %-8s %.3f / %.3f, cos %.4f   (%.1e / %.1e)' % ((st,) + p16[st] + p32[st][:2]))
+    med = sorted(v[0] for v in p16.values())
+    # measured (round 6, this batch): see the printed table; gates = 2 x measured, rounded up
+    assert med[len(med) // 2] < BF16_GRAD_768['median'], med
+    assert max(v[1] for v in p16.values()) < BF16_GRAD_768['worst'], p16
+    assert min(v[2] for v in p16.values()) > BF16_GRAD_768['min_cos'], p16
+    assert max(v[1] for v in p32.values()) < 2e-2, p32      # the fp32 path on the same batch: the gradient gate's own class
+
+
+# measured (round 6, profiles/r06_bf16_grad_768.txt): trunk stages median 0.47-0.52 / worst 0.61 / cosine 0.80-0.86; ASPP 0.30 / 0.56 / 0.83; decoder 0.12-0.26 / 0.31 / 0.95-0.99;
+# final2 0.022; the fp32 HIP path on the same batch 3e-3 ... 4e-3 (worst 6.4e-3). Gates ~1.3 x measured (2 x would allow a relative error of 1).
+BF16_GRAD_768 = dict(median=0.65, worst=0.8, min_cos=0.7)
+
+
+def test_bf16_tier_trajectory_tracks_fp32_path(env, capsys):
+    """does the tier TRAIN like the fp32 path? 60 agg steps at 4 x 256^2 on fresh seeded batches, the bf16 tier and the fp32 HIP path from the same
+    initial weights: the total loss within 1 % at every tenth step (measured: within 0.22 %), the committed memory within 2.5e-2 at the end (GPU only: both sides are this build;
+    the fp32 side is the one every other test of this file pins to the oracle). MEASURED, round 6: max |m_items difference| 1.1e-2 after 60 steps -- the 5e-3 VERDICT r5 asked for
+    is NOT met (reported in DESIGN 0.4, not gated around: the gate is 2 x the measurement)."""
+    from pinthememory_amd.hip import kernels as K
+    synth, h = env['synth'], env['harness']
+    batches = [tuple(t.cuda() for t in synth.make_batch(4, 256, seed=900 + i)) for i in range(6)]
+
+    def run(tier):
+        K.set_conv_precision(tier)
+        try:
+            net = synth.load_det_weights(env['deepv3plus'].DeepR50V3PlusD(synth.model_args(), 19, CRIT, CRIT)).cuda()
+            net.dsn[3].p = 0.0
+            opt, sched = h.make_optimizer(net)
+            losses = []
+            for i in range(60):
+                out = h.agg_train_step(net, opt, *batches[i % 6], sched=sched)
+                if i % 10 == 9:
+                    losses.append(float(out['total']))
+            h.finish_commit(net)
+            torch.cuda.synchronize()
+            return losses, net.memory.m_items.detach().float().cpu()
+        finally:
+            K.set_conv_precision('f32')
+    l32, m32 = run('f32')
+    l16, m16 = run('bf16')
+    dm = (m16 - m32).abs().max().item()
+    with capsys.disabled():
+        print('\n[60 steps, 4 x 256^2] total loss every 10th step: fp32 %s | bf16 tier %s | max |m_items diff| %.2e' % ([round(v, 4) for v in l32], [round(v, 4) for v in l16], dm))
+    for a, b in zip(l16, l32):
+        assert abs(a - b) < 1e-2 * abs(b), (l16, l32)
+    assert dm < 2.5e-2, dm
+
+
 def test_config2_production_size_eval_vs_oracle(env):
     synth = env['synth']
     args = synth.model_args()
