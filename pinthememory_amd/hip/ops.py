@@ -198,6 +198,30 @@ BN_FUSED_FINALIZE = _os.environ.get('PM_BN_FUSED', '1') == '1'      # A/B knob: 
 RELU_MASK_BYTES = _os.environ.get('PM_BN_MASK', '1') == '1'      # A/B knob: 0 = the residual BatchNorms' backward re-reads the forward output for its ReLU mask
 
 
+MERGE_SYNCBN = _os.environ.get('PM_MERGE_SYNCBN', '1') == '1'      # A/B knob: 0 = one exchange per BatchNorm (rounds 1-5)
+
+
+def _bn_train_stats_multi(ys, bns, partials):
+    """Batch statistics of SEVERAL independent SyncBatchNorms of equal width in ONE exchange (ASPP's five branches, a stage's first block's bn3 +
+    downsample.1): local moments of each, one all-gather of their concatenation, one merge + finalise per layer. -> [(mean, invstd)]; running moments updated in place.
+    Same arithmetic per layer as _bn_train_fwd's SyncBN branch (the merge kernel sees the same per-rank moments in the same rank order)."""
+    c = ys[0].shape[3]
+    moms = []
+    for y, part in zip(ys, partials):
+        pixels = y.shape[0] * y.shape[1] * y.shape[2]
+        moms.append(K.bn_partials_moments(part, pixels, c) if part is not None else K.bn_stats(y))
+    n = len(ys)
+    flat, world = D.gather_moments(torch.cat(moms), bns[0].group)
+    parts = flat.view(world, n, 3 * c)
+    return [K.bn_merge_finalize(parts[:, i].contiguous().view(-1), world, c, bn.eps, bn.running_mean, bn.running_var, bn.momentum) for i, bn in enumerate(bns)]
+
+
+def _mergeable(bns, ys):
+    """One exchange for these layers? Every one a SyncBatchNorm of the same process group and width, more than one rank, the fused finalise on."""
+    return (MERGE_SYNCBN and BN_FUSED_FINALIZE and D.is_dist() and len(bns) > 1 and all(b.group is not None and b.group is bns[0].group for b in bns)
+            and len({y.shape[3] for y in ys}) == 1)
+
+
 def _bn_train_fwd(y, gamma, beta, bn, residual, relu, out=None, partials=None, want_mask=False):
     """Batch statistics (merged across ranks for SyncBN) -> normalise + residual + ReLU. Returns (o, mean, invstd).
     partials: the (mean, M2) slab partials the producing convolution's epilogue emitted for y (K.conv_fwd(bn_partials=...)), or None:
@@ -265,14 +289,22 @@ class _Bottleneck(torch.autograd.Function):
         y2 = K.conv_fwd(o1, k2, *geoms[1], keep_v=kv, bn_partials=ps)      # Winograd layers keep the transformed input for the weight gradient
         o2, m2, i2 = _bn_train_fwd(y2, g2, b2, bns[1], None, True, partials=ps[1])
         y3 = K.conv_fwd(o2, k3, *geoms[2], bn_partials=ps)
+        merged = False
         if wd is not None:
             kd = K.krsc(wd)
             yd = K.conv_fwd(xv, kd, *geoms[3], bn_partials=ps)
-            res, md, idd = _bn_train_fwd(yd, gd, bd, bns[3], None, False, partials=ps[3])
+            merged = _mergeable([bns[3], bns[2]], [yd, y3])
+            if merged:      # SyncBN: the two independent statistics exchanges of the block's tail travel as one
+                (md, idd), (m3, i3) = _bn_train_stats_multi([yd, y3], [bns[3], bns[2]], [ps[3], ps[2]])
+                res = K.bn_apply(yd, md, idd, gd, bd, residual=None, relu=False)
+            else:
+                res, md, idd = _bn_train_fwd(yd, gd, bd, bns[3], None, False, partials=ps[3])
         else:
             kd = yd = md = idd = None
             res = xv
-        if RELU_MASK_BYTES:
+        if merged:
+            out, mask3 = K.bn_apply(y3, m3, i3, g3, b3, residual=res, relu=True, want_mask=True) if RELU_MASK_BYTES else (K.bn_apply(y3, m3, i3, g3, b3, residual=res, relu=True), None)
+        elif RELU_MASK_BYTES:
             out, m3, i3, mask3 = _bn_train_fwd(y3, g3, b3, bns[2], res, True, partials=ps[2], want_mask=True)
         else:
             (out, m3, i3), mask3 = _bn_train_fwd(y3, g3, b3, bns[2], res, True, partials=ps[2]), None
@@ -285,7 +317,24 @@ class _Bottleneck(torch.autograd.Function):
         xv, k1, k2, k3, kd, y1, o1, y2, o2, y3, yd, out, m1, i1, m2, i2, m3, i3, md, idd, g1, g2, g3, gd, b1, b2, b3, v2, mask3 = ctx.saved_tensors
         ge, gr, df = ctx.geoms, ctx.groups, ctx.deferred
         dv = _grad_view(dout)
-        dy3, dres, dg3, db3 = _bn_train_bwd(dv, out, y3, m3, i3, g3, b3, True, gr[2], True, True, mask=mask3)
+        pair = None
+        if ctx.has_ds and MERGE_SYNCBN and D.is_dist() and gr[2] is not None and gr[3] is gr[2] and y3.shape[3] == yd.shape[3]:
+            # SyncBN, first block of a stage: bn3's masked gradient (= the skip gradient) is known after bn3's REDUCE pass, before its exchange -- so the downsample
+            # BatchNorm's reduce pass runs on it right away and the two sum exchanges travel as ONE all-reduce; then both apply passes.
+            c3 = y3.shape[3]
+            if mask3 is not None:
+                s3, gm = K.bn_bwd_reduce_mask(dv, mask3, y3, m3, i3, want_gmask=True, with_count=True)
+            else:
+                s3, gm = K.bn_bwd_reduce(dv, out, y3, m3, i3, 1, g3, b3, want_gmask=True, with_count=True)
+            sd, _ = K.bn_bwd_reduce(gm, None, yd, md, idd, 0, gd, None, want_gmask=False, with_count=True)
+            both = D.all_reduce_sum_copy(torch.cat([s3, sd]), gr[2])
+            g3sum, gdsum = both[:s3.numel()], both[s3.numel():]
+            dy3, _ = K.bn_bwd_apply(gm, None, y3, m3, i3, g3, g3sum, -1.0, 0, False)
+            dres, dg3, db3 = gm, s3[c3:2 * c3], s3[:c3]
+            dyd, _ = K.bn_bwd_apply(gm, None, yd, md, idd, gd, gdsum, -1.0, 0, False, None)
+            pair = (dyd, sd[c3:2 * c3], sd[:c3])
+        else:
+            dy3, dres, dg3, db3 = _bn_train_bwd(dv, out, y3, m3, i3, g3, b3, True, gr[2], True, True, mask=mask3)
         dw3, _ = _wgrad(o2, dy3, tuple(k3.shape), ge[2], deferred=df[2])
         do2 = K.conv_bwd_data(dy3, k3, tuple(o2.shape), *ge[2])
         dy2, _, dg2, db2 = _bn_train_bwd(do2, o2, y2, m2, i2, g2, b2, True, gr[1], False, False)
@@ -296,7 +345,10 @@ class _Bottleneck(torch.autograd.Function):
         dwd = dgd = dbd = None
         skip = dres
         if ctx.has_ds:
-            dyd, _, dgd, dbd = _bn_train_bwd(dres, None, yd, md, idd, gd, None, False, gr[3], False, False)
+            if pair is not None:
+                dyd, dgd, dbd = pair
+            else:
+                dyd, _, dgd, dbd = _bn_train_bwd(dres, None, yd, md, idd, gd, None, False, gr[3], False, False)
             dwdk, _ = _wgrad(xv, dyd, tuple(kd.shape), ge[3], deferred=df[3])
             dwd = dwdk.permute(0, 3, 1, 2)
             skip = K.conv_bwd_data(dyd, kd, tuple(xv.shape), *ge[3]) if ctx.needs_input_grad[0] else None
@@ -414,6 +466,64 @@ class _ConvBnAct(torch.autograd.Function):
             dwk, db = _wgrad(xv, dy, tuple(wk.shape), (stride, pad, dil), want_bias=ctx.has_bias, deferred=ctx.deferred, wino_v=vk)
             dw = dwk.permute(0, 3, 1, 2)
         return dx, dw, db, dgamma, dbeta, (nchw(dres) if dres is not None else None), None, None, None, None, None
+
+
+class _ConvBnActN(torch.autograd.Function):
+    """N independent conv -> SyncBatchNorm(train) -> ReLU branches of equal width as ONE autograd node whose BatchNorm exchanges travel together: the
+    five branches of the ASPP head (deepv3plus.py:72-101: four convolutions of the trunk output + the image-pooling branch). Forward: every convolution, every local
+    statistic, ONE all-gather, every finalise + apply; backward: every reduce pass, ONE all-reduce, every apply pass, then the data / weight gradients. Per branch the
+    same kernels on the same values as _ConvBnAct -- only the number of collectives changes (10 -> 2 for the ASPP head). Used only with more than one rank."""
+
+    @staticmethod
+    def forward(ctx, n, geoms, bns, outs, deferreds, *ts):
+        xs, ws, gammas, betas = ts[0:n], ts[n:2 * n], ts[2 * n:3 * n], ts[3 * n:4 * n]
+        xvs, wks = [nhwc(x) for x in xs], [K.krsc(w) for w in ws]
+        ys, kvs, parts = [], [], []
+        for i in range(n):
+            kv, ps = [], []
+            ys.append(K.conv_fwd(xvs[i], wks[i], *geoms[i], keep_v=kv if ctx.needs_input_grad[5 + n + i] else None, bn_partials=ps))
+            kvs.append(kv[0] if kv else None)
+            parts.append(ps[0])
+        stats = _bn_train_stats_multi(ys, bns, parts)
+        os_ = [K.bn_apply(ys[i], stats[i][0], stats[i][1], gammas[i], betas[i], residual=None, relu=True, out=nhwc(outs[i]) if outs[i] is not None else None) for i in range(n)]
+        ctx.n, ctx.geoms, ctx.group, ctx.deferreds = n, geoms, bns[0].group, deferreds
+        ctx.save_for_backward(*xvs, *wks, *ys, *os_, *[st[0] for st in stats], *[st[1] for st in stats], *gammas, *betas, *kvs)
+        return tuple(nchw(o) for o in os_)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        n = ctx.n
+        sv = ctx.saved_tensors
+        xvs, wks, ys, os_, means, invs, gammas, betas, kvs = (sv[i * n:(i + 1) * n] for i in range(9))
+        c = ys[0].shape[3]
+        red = [K.bn_bwd_reduce(_grad_view(douts[i]), os_[i], ys[i], means[i], invs[i], 2, gammas[i], betas[i], want_gmask=False, with_count=True) for i in range(n)]
+        tot = D.all_reduce_sum_copy(torch.cat([r[0] for r in red]), ctx.group)
+        ln = red[0][0].numel()
+        dxs, dws, dgs, dbs = [], [], [], []
+        for i in range(n):
+            dy, _ = K.bn_bwd_apply(_grad_view(douts[i]), os_[i], ys[i], means[i], invs[i], gammas[i], tot[i * ln:(i + 1) * ln], -1.0, 2, False, betas[i])
+            dxs.append(nchw(K.conv_bwd_data(dy, wks[i], tuple(xvs[i].shape), *ctx.geoms[i], dtype=xvs[i].dtype)) if ctx.needs_input_grad[5 + i] else None)
+            dwk, _ = _wgrad(xvs[i], dy, tuple(wks[i].shape), ctx.geoms[i], deferred=ctx.deferreds[i], wino_v=kvs[i])
+            dws.append(dwk.permute(0, 3, 1, 2))
+            dgs.append(red[i][0][c:2 * c]), dbs.append(red[i][0][:c])
+        return (None, None, None, None, None, *dxs, *dws, *dgs, *dbs)
+
+
+def conv_bn_act_n(xs, seqs, outs):
+    """[conv_bn_act(x, seq[0], seq[1], relu=True, out=o)] for independent (x, Sequential(conv, bn, relu)) branches; ONE SyncBatchNorm exchange per direction when the
+    branches qualify (training, gradients on, more than one rank, equal width, no conv bias), the per-branch path otherwise."""
+    convs, bns_m = [q[0] for q in seqs], [q[1] for q in seqs]
+    ok = MERGE_SYNCBN and BN_FUSED_FINALIZE and D.is_dist() and torch.is_grad_enabled() and all(b.training for b in bns_m) and all(cv.bias is None for cv in convs)
+    if ok:
+        groups = [D.bn_group(b) for b in bns_m]
+        ok = all(g is not None and g is groups[0] for g in groups) and len({cv.out_channels for cv in convs}) == 1
+    if not ok:
+        return [conv_bn_act(x, cv, bn, relu=True, out=o) for x, cv, bn, o in zip(xs, convs, bns_m, outs)]
+    states = [BNState(b) for b in bns_m]      # (registers each layer's num_batches_tracked increment: once, here)
+    wd = [_w(cv.weight) for cv in convs]
+    n = len(xs)
+    return list(_ConvBnActN.apply(n, [_geom(cv) for cv in convs], states, list(outs), [d for _, d in wd], *xs, *[w for w, _ in wd],
+                                  *[b.weight for b in bns_m], *[b.bias for b in bns_m]))
 
 
 class _Conv(torch.autograd.Function):

@@ -61,11 +61,14 @@ class _AtrousSpatialPyramidPoolingModule(nn.Module):
             pooled = ops.global_avgpool(xs[0])
         else:                                          # callers may swap the pooling module (eval.py:744-745)
             pooled = self.img_pooling(xs[0])
-        img = run_cbr(self.img_conv, pooled)
-        parts, off = [ops.resize(img, x.shape[2:], out=buf[:, :widths[0]])], widths[0]
-        for f, wd, xi in zip(self.features, widths[1:], xs[1:]):
-            parts.append(run_cbr(f, xi, out=buf[:, off:off + wd]))
+        outs, off = [None], widths[0]
+        for wd in widths[1:]:
+            outs.append(buf[:, off:off + wd])
             off += wd
+        # the five conv -> BatchNorm -> ReLU branches are independent: under SyncBatchNorm their statistics (and gradient sums) travel as ONE exchange per direction
+        # (ops.conv_bn_act_n; the per-branch path of rounds 1-5 with one rank)
+        res = ops.conv_bn_act_n([pooled] + list(xs[1:]), [self.img_conv] + list(self.features), outs)
+        parts = [ops.resize(res[0], x.shape[2:], out=buf[:, :widths[0]])] + res[1:]
         return ops.concat(buf, parts)
 
 

@@ -108,5 +108,8 @@ def test_bench_py_gpus_2_self_launch_on_the_gpu_box(tmp_path, dtype):
     assert abs(d['value'] - 16 / (d['ms_per_step'] * 1e-3)) < 1e-2 * d['value']                 # whole-job rate: both ranks' images over the slowest rank's time
     assert c['final_loss'] == c['final_loss'] and abs(c['final_loss']) < 1e3                     # finite
     # round 5: the line says how the exchanges travelled and how many there were, and what the host spent enqueueing one step
-    assert c['rccl_direct'] is False and 'gloo' in c['rccl_direct_reason'] and c['collectives_per_step'] >= 130      # 65 + 65 SyncBN exchanges, buckets, memory slots
+    assert c['rccl_direct'] is False and 'gloo' in c['rccl_direct_reason']
+    # round 6: 138 -> 122: the independent SyncBatchNorm exchanges travel together -- ASPP's five branches (5 -> 1 per direction), bn3 + downsample.1 of
+    # each stage's first block (2 -> 1 per direction, four stages); what is left: 49 + 49 SyncBN exchanges, the gradient buckets, the memory-slot sum
+    assert 100 <= c['collectives_per_step'] <= 128, c['collectives_per_step']
     assert c['host_enqueue_ms'] > 0 and c['step_form'] == 'eager launches'
