@@ -125,7 +125,26 @@ int pm_conv_bwd_data(const pm_tensor* dy, const float* w_krsc, const pm_tensor* 
 int pm_conv_bwd_weight(const pm_tensor* x, const pm_tensor* dy, float* dw_krsc, float* dbias, const pm_conv_params* p,
                        void* ws, size_t ws_bytes, void* stream);
 
-/* ---- PROCESS-GLOBAL DEBUG / A-B SWITCHES (the only mutable global state of the library; SURVEY 8(b) "no global mutable state" holds for everything else) ----------
+/* ---- ROUTING (round 6): the library's ONLY mutable global state is one pm_routing value -- which kernel takes a call; never WHAT is computed (every route is parity-tested
+ * against the same oracle). It is initialised from the PM_* environment when the library is loaded (the defaults below) and replaced as a whole by pm_routing_set: a
+ * production caller sets it once before the first pm_conv_* call, or never, and the library is then re-entrant with an immutable kernel table. The pm_set_*
+ * entry points further down are thin wrappers that change ONE field -- for kernel tests that must reach a specific kernel and same-box A/B runs. Contract for both: call from
+ * one thread while no other thread is inside a pm_conv_* entry point; repeat size queries (pm_conv_workspace, pm_conv_wxf_bytes, ...) after a change. */
+typedef struct pm_routing {
+  int32_t struct_size;        /* = sizeof(pm_routing): guards against a caller built with another header */
+  int32_t winograd;           /* fp32 tier, wide stride-1 3x3s: 4 prefer F(4x4,3x3) (default), 2 F(2x2,3x3) only, 0 direct */
+  int32_t winograd_fused;     /* F(4x4) point products + output transform in one kernel: 0 (default; PM_WINO_FUSED), 1 */
+  int32_t conv16;             /* bf16 tier, forward / stride-1 data gradient: 1 per shape (default; PM_CONV16), 2 LDS-DMA kernels everywhere, 0 register-staged everywhere */
+  int32_t conv16_wide;        /* the wide LDS-DMA forms (conv16w.hip): 1 by the planner's cost model (default; PM_C16W), 0 never, 2 wherever the shape allows, 3 = 2 with the 256 x 256 tile */
+  int32_t conv16_persistent;  /* the ring tiles run as the persistent producer / consumer kernel: 1 (default; PM_C16P), 0 one block per tile */
+  int32_t wgrad16;            /* bf16 tier, weight gradient on the LDS-DMA persistent ring (wgrad16.hip): 1 (default; PM_WGRAD16), 0 register-staged */
+  int32_t bf16_wgrad;         /* prec = 2 weight gradients on pixel-contiguous bf16 copies: 0 (default), 1 */
+  int32_t split;              /* fp32 tier on the bf16 matrix pipe (conv_split.hip: fp32 operands, 3-way exact bf16 split, 6 products, fp32 accumulate): 1 (default; PM_SPLIT), 0 */
+} pm_routing;
+int pm_routing_get(pm_routing* out);            /* out->struct_size must be set by the caller */
+int pm_routing_set(const pm_routing* r);
+
+/* ---- single-field wrappers over pm_routing (kernel tests, A/B runs) -------------------------------------------------------------------------------------------------------
  * pm_set_winograd, pm_set_winograd_fused, pm_set_conv16, pm_set_wgrad16, pm_set_split, pm_set_bf16_wgrad and pm_profile_enable flip process-wide ROUTING / MEASUREMENT switches. They exist for
  * same-box A/B runs, kernel tests that must reach a specific kernel, and bench.py's roofline leg; they never change WHAT is computed (every route is parity-tested
  * against the same oracle), only which kernel computes it or whether launches are timed. Contract: call them from ONE thread while no other thread is inside a
@@ -151,8 +170,8 @@ int pm_set_winograd_fused(int on);
  * 3 = LDS-DMA everywhere with the wide tile wherever the shape allows it (kernel tests: the PERSISTENT ring -- one block per CU walks the tiles, four producer waves
  * fetch ahead across tile boundaries, eight waves multiply; 7 = the same with the 256 x 256 two-stage form, 8 = the ring with one block per tile), 4 = per shape
  * without the wide kernel (A/B). PM_C16P=0 in the environment keeps the ring out of "per shape" and runs it one block per tile. The HBM-bound 1x1 convolutions
- * with K = 64 / 128 / 256 can take the streaming kernel of csrc/pw16.hip (persistent blocks, weights resident in LDS, 16-byte stores from the accumulators): on every
- * eligible call under 5 (kernel tests), never under 0 / 2 / 3 / 6 / 7 / 8, under 1 only with PM_PW16=1 in the environment (measured level with the tile kernel: off by default).
+ * with K = 64 / 128 / 256 had a streaming kernel of their own in round 5 (measured level with the tile kernel, never the default): it left the library in round 6
+ * (tools/experiments/pw16/); modes 5 and 6 are accepted and mean 1.
  * Process-wide like pm_set_winograd. */
 int pm_set_conv16(int on);
 /* prec = 2 weight gradients on pixel-contiguous bf16 copies of x (one per tap) and dy instead of the staged-fp32 form: 0 off (default: the

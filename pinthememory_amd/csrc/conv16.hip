@@ -318,8 +318,6 @@ void launch_tile(const pm_conv16& k, dim3 grid, hipStream_t st) {
 // Round 5: the WIDE kernel (conv16w.hip: 256 x 128 / 128 x 256 tile, eight waves, ONE block per CU, three-stage ring) where a cost model of whole rounds of the 256 CUs
 // says it wins: its K-step costs ~1.45 x a 64 x 128 step of the narrow kernel for 4 x the tile, but a partly filled last round costs a whole round, so the model picks
 // the K-split that balances the tiles against the CUs. PM_C16W: 0 never, 1 by the model (default), 2 wherever the shape allows it (A/B runs, kernel tests).
-int g_c16w = getenv("PM_C16W") ? atoi(getenv("PM_C16W")) : 1;
-int g_c16p = getenv("PM_C16P") ? atoi(getenv("PM_C16P")) : 1;      // 1: the ring tiles of conv16w.hip run persistent (producer / consumer waves), and the planner hands them the shapes they win; 0: round-5 first-session routing
 namespace {
 struct WidePick {
   bool ok;
@@ -330,10 +328,10 @@ WidePick wide_pick(const pm_conv16* k, int only_cfg = -1) {
   static const int force_ks = getenv("PM_C16W_KS") ? atoi(getenv("PM_C16W_KS")) : 0;
   static const double ovh = getenv("PM_C16W_OVH") ? atof(getenv("PM_C16W_OVH")) : 10.0;      // prologue + epilogue of a block, in K-steps
   WidePick best{false, 0, 0, 0, 1e30};
-  const bool forced = g_c16w >= 2;      // kernel tests: every shape the kernel can express, ragged rows / columns and single K-steps included
+  const bool forced = pm_route.conv16_wide >= 2;      // kernel tests: every shape the kernel can express, ragged rows / columns and single K-steps included
   if (!forced && (k->Nn < 128 || k->M < 2048 || k->ksteps < 4)) return best;
   static const int env_cfg = getenv("PM_C16W_CFG") ? atoi(getenv("PM_C16W_CFG")) : -1;      // 0: 256 x 128, 1: 128 x 256, 2: 256 x 256 (two LDS stages)
-  const int force_cfg = only_cfg >= 0 ? only_cfg : (g_c16w == 3 ? 2 : env_cfg);            // pm_set_conv16(7): the 256 x 256 tile on every shape (kernel tests)
+  const int force_cfg = only_cfg >= 0 ? only_cfg : (pm_route.conv16_wide == 3 ? 2 : env_cfg);            // pm_set_conv16(7): the 256 x 256 tile on every shape (kernel tests)
   for (int cfg = 0; cfg < 3; ++cfg) {
     if (force_cfg >= 0 && cfg != force_cfg) continue;
     const int bm = cfg == 1 ? 128 : 256, bn = cfg == 0 ? 128 : 256;
@@ -387,7 +385,7 @@ void pm_conv16_plan(pm_conv16* k) {
     k->tiles_m = pm_cdiv(k->M, 64), k->tiles_n = k->Nn / 256;
     k->ksteps_per = k->ksteps, k->ksplit = 1;
   }
-  if (g_c16w > 0) {
+  if (pm_route.conv16_wide > 0) {
     // Where the wide tiles win (tools/conv16_probe.py on an MI355X, round 5, profiles/r05_conv16w_probe.txt), all with the 256 x 256 two-stage form (128 FLOP per staged
     // byte, full-N for the 256-channel outputs): the DEEP reductions -- the ASPP 3x3 2048 -> 256 on the 48 x 48 maps (288 K-steps: 690 TF narrow, 764 with skipped filter
     // rows, 733 on 256 x 128, **834-866**), the auxiliary head's 3x3 1024 -> 512 (660 -> 780) -- and the very wide outputs of a medium reduction (3x3 256 -> 2048
@@ -398,8 +396,8 @@ void pm_conv16_plan(pm_conv16* k) {
     // (profiles/r05_conv16p_probe.txt): decoder 3x3 320 -> 256 @192 0.490 -> 0.423-0.438 ms (1030 TF), 256 -> 256 0.380 -> 0.348-0.355; ASPP 3x3 2048 -> 256 (256 x 256
     // form) 0.205 -> 0.191; its data-gradient form 256 -> 2048 0.225 -> 0.205. Not the 1024 -> 512 3x3 of the auxiliary head (0.222 on 256 x 256 vs 0.229-0.241), the
     // 72-K-step 3x3 512 -> 512 (0.126 narrow vs 0.138-0.145) or the short 1x1 reductions (the epilogue of a tile is not overlapped with anything).
-    const bool ring_wins = g_c16p && ((k->M >= 200000 && k->ksteps >= 32 && k->Nn >= 256) || (k->ksteps >= 128 && k->Nn <= 256) || (k->Nn >= 2048 && k->ksteps >= 32));
-    const WidePick w = g_c16w >= 2 ? wide_pick(k) : (ring_wins ? wide_pick(k) : (wins ? wide_pick(k, 2) : WidePick{false, 0, 0, 0, 0}));
+    const bool ring_wins = pm_route.conv16_persistent && ((k->M >= 200000 && k->ksteps >= 32 && k->Nn >= 256) || (k->ksteps >= 128 && k->Nn <= 256) || (k->Nn >= 2048 && k->ksteps >= 32));
+    const WidePick w = pm_route.conv16_wide >= 2 ? wide_pick(k) : (ring_wins ? wide_pick(k) : (wins ? wide_pick(k, 2) : WidePick{false, 0, 0, 0, 0}));
     if (w.ok) {
       k->wide = 1, k->bm = w.bm, k->bn = w.bn;
       k->tiles_m = pm_cdiv(k->M, k->bm), k->tiles_n = pm_cdiv(k->Nn, k->bn);

@@ -17,7 +17,6 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-extern int g_c16p;      // conv16.hip (PM_C16P): the ring tiles run in their persistent producer / consumer form
 
 namespace {
 
@@ -685,13 +684,13 @@ void launch_wide(const pm_conv16& k, dim3 grid, hipStream_t st) {
 }  // namespace
 
 // 1 when pm_conv16w_launch runs this plan in the persistent producer / consumer form (the ring tiles with PM_C16P != 0), 0 for one block per tile
-int pm_conv16w_persistent(const pm_conv16* k) { return g_c16p && k->wide && ((k->bm == 256 && k->bn == 128) || (k->bm == 128 && k->bn == 256)) ? 1 : 0; }
+int pm_conv16w_persistent(const pm_conv16* k) { return pm_route.conv16_persistent && k->wide && ((k->bm == 256 && k->bn == 128) || (k->bm == 128 && k->bn == 256)) ? 1 : 0; }
 
 int pm_conv16w_launch(const pm_conv16* k0, hipStream_t st) {
   pm_conv16 k = *k0;
   dim3 grid(k.tiles_m * k.tiles_n, 1, k.ksplit);
-  if (k.bm == 256 && k.bn == 128 && g_c16p) launch_persistent<256, 128, 4, 2, 4>(k, st);
-  else if (k.bm == 128 && k.bn == 256 && g_c16p) launch_persistent<128, 256, 2, 4, 4>(k, st);
+  if (k.bm == 256 && k.bn == 128 && pm_route.conv16_persistent) launch_persistent<256, 128, 4, 2, 4>(k, st);
+  else if (k.bm == 128 && k.bn == 256 && pm_route.conv16_persistent) launch_persistent<128, 256, 2, 4, 4>(k, st);
   else if (k.bm == 256 && k.bn == 128) launch_wide<256, 128, 4, 2, 3>(k, grid, st);
   else if (k.bm == 128 && k.bn == 256) launch_wide<128, 256, 2, 4, 3>(k, grid, st);
   else if (k.bm == 256 && k.bn == 256) launch_wide<256, 256, 2, 4, 2>(k, grid, st);

@@ -266,8 +266,7 @@ struct Plan {
 //   T(ks) = ceil(blocks / 256 CUs) * (K-steps per block + 2 for prologue/epilogue) + workspace round trip + reduce launch.
 // It fills the 256 CUs when a problem has few output tiles (wgrad: Cout x taps*Cin) without paying for partial slabs
 // when the tile count alone already does.
-// ---- PREC 5 routing (round 6): which fp32 launches run as split-operand bf16 MFMA (conv_split.hip). g_split: 0 never, 1 every eligible launch (default).
-int g_split = getenv("PM_SPLIT") ? atoi(getenv("PM_SPLIT")) : 1;
+// ---- PREC 5 routing (round 6): which fp32 launches run as split-operand bf16 MFMA (conv_split.hip). pm_route.split: 0 never, 1 every eligible launch (default).
 int g_split_nst = getenv("PM_SPLIT_NST") ? atoi(getenv("PM_SPLIT_NST")) : 1;
 int g_split_min_k = getenv("PM_SPLIT_MIN_K") ? atoi(getenv("PM_SPLIT_MIN_K")) : 129;      // shorter forward / data-gradient reductions (64 -> 256 @192^2, 128 -> 512 @96^2) are bound by their
 inline bool split_k_ok(int mode, long K) { return mode == MODE_WGRAD || K >= g_split_min_k; }      // output stream, not by the matrix pipe: measured slower on the split path (58 vs 70 TF)
@@ -284,7 +283,7 @@ Plan make_plan(int mode, long M, long Nn, long K, bool bf16 = false) {
   int bn = Nn > 64 ? 128 : ((Nn > 32 || bf16) ? 64 : 32);      // no bf16-operand instantiation of the 128 x 32 tile: narrow outputs (19 classes) pad to 64
   // bf16 operands (configs[2], direct algorithm everywhere): the MFMA phase is 16x shorter, the kernel is bound by staging its
   // operands through L2 / LDS, so the 128 x 128 tile (half the operand traffic per FLOP of 64 x 64) wins: 73.1 -> see DESIGN
-  const bool big = bf16 || (g_split && g_split_tile && split_k_ok(mode, K));
+  const bool big = bf16 || (pm_route.split && g_split_tile && split_k_ok(mode, K));
   if (mode != MODE_WGRAD && !wide_bn && !big && bn == 128) bn = 64;
   if (force_bn && mode != MODE_WGRAD) bn = force_bn;
   const long ksteps = (K + BK - 1) / BK;
@@ -407,7 +406,7 @@ inline bool split_takes(int mode, const Plan& p, const ConvK& k, int batch) {   
   static const int bsel = getenv("PM_SPLIT_BATCH") ? atoi(getenv("PM_SPLIT_BATCH")) : 0;      // bisecting knob: 1 only batched launches, 2 only unbatched ones
   static const int maxm = getenv("PM_SPLIT_MIN_M") ? atoi(getenv("PM_SPLIT_MIN_M")) : 0;
   if ((bsel == 1 && batch <= 1) || (bsel == 2 && batch > 1) || k.M < maxm) return false;
-  return g_split != 0 && ((modes >> mode) & 1) && p.bn >= 64 && !k.io16 && (batch > 1 || split_k_ok(mode, k.K));
+  return pm_route.split != 0 && ((modes >> mode) & 1) && p.bn >= 64 && !k.io16 && (batch > 1 || split_k_ok(mode, k.K));
 }
 
 template <int MODE>
@@ -507,8 +506,6 @@ void fill_geom(ConvK& k, const pm_tensor* x, const pm_tensor* y, const pm_conv_p
 // Taken when the GEMMs are MFMA-bound (both channel counts >= 128: the expanded V / M streams would otherwise dominate) and the
 // dilation sub-lattices tile the image without too much padding: the m in {4, 2} with the fewest multiplies per output, if that is
 // below 0.6 of the direct algorithm's (m = 4 for d = 1, 2, 6, 12, 18 on the 48x48 maps and d = 1 on 192x192).
-int g_wino_mode = 4;   // 0 off, 2 F(2x2) only, 4 prefer F(4x4)
-int g_wino_fused = getenv("PM_WINO_FUSED") ? atoi(getenv("PM_WINO_FUSED")) : 0;   // F(4x4) GEMMs + output transform in one kernel (opt-in, see wino_conv)
 struct WinoPlan {
   bool use;
   pm_wino_geom g;
@@ -519,7 +516,7 @@ struct WinoPlan {
 WinoPlan wino_plan(const pm_tensor* xin, int cout, const pm_conv_params* p, bool wgrad = false) {
   WinoPlan wp{};
   if (wgrad && (long)xin->c * cout < 256 * 256) return wp;   // two transforms + slabs per GEMM: pays from 256 x 256 channels up
-  if (g_wino_mode == 0 || p->kh != 3 || p->kw != 3 || p->stride != 1 || p->pad != p->dil || p->prec != 0) return wp;
+  if (pm_route.winograd == 0 || p->kh != 3 || p->kw != 3 || p->stride != 1 || p->pad != p->dil || p->prec != 0) return wp;
   const int cin = xin->c;
   if (cin < 128 || cout < 128 || (cout & 3) || (cin & 3)) return wp;
   // multiplies per output relative to the direct algorithm: (m+2)^2 / (9 m^2) x the padding of the sub-lattices to whole tiles
@@ -527,7 +524,7 @@ WinoPlan wino_plan(const pm_tensor* xin, int cout, const pm_conv_params* p, bool
   // measured 1.3x over direct. Above 0.6 the transforms eat the gain.
   int m = 0;
   double best_ratio = 0.6;
-  for (int cand = g_wino_mode; cand >= 2; cand -= 2) {
+  for (int cand = pm_route.winograd; cand >= 2; cand -= 2) {
     const pm_wino_geom g = pm_wino_make_geom(xin->n, xin->h, xin->w, p->dil, cand);
     const double cover = (double)(cand * g.TY * p->dil) * (double)(cand * g.TX * p->dil) / ((double)xin->h * xin->w);
     const double ratio = cover * (cand + 2) * (cand + 2) / (9.0 * cand * cand);
@@ -550,7 +547,7 @@ WinoPlan wino_plan(const pm_tensor* xin, int cout, const pm_conv_params* p, bool
   // half empty; 64 x 128 blocks measured -0.25 ms/step over those layers in situ (tools/gpu_tile_ab2.sh), nothing gained above
   // (the split path keeps 128 rows: 3.7 instead of 5.5 split instructions per MFMA outweigh the half-empty last round -- same box: 52.2 -> 51.7 ms/step, the deep ASPP
   //  products 160-178 -> 188-200 TF)
-  if (wp.pl.bm == 128 && wp.g.tiles <= 4608 && !getenv("PM_WINO_BM") && !(g_split && g_split_tile)) wp.pl.bm = 64;
+  if (wp.pl.bm == 128 && wp.g.tiles <= 4608 && !getenv("PM_WINO_BM") && !(pm_route.split && g_split_tile)) wp.pl.bm = 64;
   wp.pl.tiles_m = pm_cdiv(wp.g.tiles, wp.pl.bm), wp.pl.tiles_n = pm_cdiv(cout, wp.pl.bn);
   wp.pl.ksplit = 1, wp.pl.kper = wp.Kp, wp.pl.ws_bytes = 0;
   wp.use = true;
@@ -583,7 +580,7 @@ int wino_conv(const pm_tensor* xin, const float* w, int w_cout, int w_cin, bool 
   // 32 of the 128 x 128 GEMM tile: 144 KB per 16-k slab per CU, one LDS stage, the stage's write phase (~1900 cycles at 79 B/clk) not overlapped with its
   // 4600 MFMA cycles. Bounds measured on the unfused path: a GEMM that never stores M -3.3 ms/step, no output-transform pass either -5.6 ms/step.
   // Kept as an opt-in (PM_WINO_FUSED=1) with its tests; the default is the batched GEMM + wino_output_kernel.
-  if (g_wino_fused && wp.g.m == 4 && wp.Kp % 16 == 0) {
+  if (pm_route.winograd_fused && wp.g.m == 4 && wp.Kp % 16 == 0) {
     ProfRec rec;
     if (g_prof_on) {
       (void)hipEventCreate(&rec.a), (void)hipEventCreate(&rec.b);
@@ -650,7 +647,6 @@ int wino_wgrad(const pm_tensor* x, const pm_tensor* dy, float* dw, const WinoPla
 // The convolution is handed to the implicit-GEMM kernel as an fp32-typed problem with HALF the input channels: a float of the view is a
 // pair of bf16 channels, a 32-float K-slab is 64 bf16 k-values. Input channels are padded to a multiple of 64 (zero-filled by the cast)
 // so that a slab never straddles a tap and the wave-uniform K-state (K_FAST) applies to every layer.
-int g_conv16 = getenv("PM_CONV16") ? atoi(getenv("PM_CONV16")) : 1;      // pm_set_conv16
 struct Bf16Plan {
   bool use;
   bool c16;                  // the LDS-DMA kernel (conv16.hip) takes the call; k16 holds its geometry and plan (pointers / epilogue filled at launch)
@@ -677,7 +673,7 @@ Bf16Plan bf16_plan(const pm_tensor* xin, const pm_tensor* yout, const pm_conv_pa
   if (b.pl.bn < 64) return b;                                     // no bf16 instantiation of the 128 x 32 tile
   b.use = true;
   // round 4: the LDS-DMA kernel for everything but tiny row counts (the image-pooling branch: M = batch) -- PM_CONV16=0 keeps the register-staged kernel (A/B runs)
-  const int c16_on = g_conv16;
+  const int c16_on = pm_route.conv16;
   static const int c16_min_m = getenv("PM_CONV16_MIN_M") ? atoi(getenv("PM_CONV16_MIN_M")) : 256;
   b.c16 = false;
   if (c16_on && b.M >= c16_min_m && p->stride >= 1) {
@@ -719,24 +715,6 @@ int conv_bf16(const pm_tensor* xin, const float* w, int w_cout, int w_cin, bool 
   if (!(wb_ext && wb_valid))
     if (int e = pm_bf16_cast_weights(w, w_cout, T, w_cin, b.Cp, rotate, wb, st)) return e;
   const long xpitch16 = b.inplace ? xin->pitch : b.Cp;                       // bf16 elements between pixels
-  // round 5: the HBM-bound 1x1 convolutions with a short reduction (K = 64 / 128 / 256) stream through the persistent kernel of pw16.hip
-  if (T == 1 && pe->stride == 1 && pe->pad == 0 && pm_is_bf16(yout) && !e0.bn_partials && xin->h == yout->h && xin->w == yout->w &&
-      pm_pw16_ok(b.M, (int)b.Nn, b.Cp, xpitch16, yout->pitch, e0.residual ? e0.residual_pitch : 0, xb, yout->ptr, e0.residual)) {
-    ProfRec rec;
-    if (g_prof_on) {
-      (void)hipEventCreate(&rec.a), (void)hipEventCreate(&rec.b);
-      rec.mode = 6, rec.bm = b.Cp == 256 ? 32 : 64, rec.bn = b.Cp == 256 ? 128 : 256, rec.km = 0, rec.prec = 5, rec.nst = 4, rec.M = (int)b.M, rec.Nn = (int)b.Nn, rec.K = b.Cp / 2,
-      rec.batch = 1, rec.ksplit = 1, rec.flops = 2.0 * (double)b.M * (double)b.Nn * (double)xin->c;
-      (void)hipEventRecord(rec.a, st);
-    }
-    const int e = pm_pw16_launch((const pm_bf16*)xb, xpitch16, (const pm_bf16*)wb, (pm_bf16*)yout->ptr, yout->pitch, (const pm_bf16*)e0.residual, e0.residual_pitch, b.M,
-                                 (int)b.Nn, b.Cp, e0.bias, e0.scale, e0.shift, e0.relu, st);
-    if (g_prof_on) {
-      (void)hipEventRecord(rec.b, st);
-      g_prof.push_back(rec);
-    }
-    return e;
-  }
   if (b.c16) {
     const bool o16 = pm_is_bf16(yout);
     const bool ep_any = e0.bias || e0.scale || e0.residual || e0.relu;
@@ -839,7 +817,7 @@ struct S2Native {
 S2Native s2_native_plan(const pm_tensor* dy, const pm_tensor* dx, const pm_conv_params* p) {
   S2Native s{};
   static const int on = getenv("PM_S2_NATIVE16") ? atoi(getenv("PM_S2_NATIVE16")) : 1;
-  if (!on || !g_conv16 || p->stride != 2 || p->dil != 1 || !pm_is_bf16(dy) || !pm_is_bf16(dx) || !pm_vec8(dy) || !pm_vec8(dx) || dy->c % 64 || dx->c % 8) return s;
+  if (!on || !pm_route.conv16 || p->stride != 2 || p->dil != 1 || !pm_is_bf16(dy) || !pm_is_bf16(dx) || !pm_vec8(dy) || !pm_vec8(dx) || dy->c % 64 || dx->c % 8) return s;
   size_t off = 0, out_bytes = 0, slab = 0;
   for (int cls = 0; cls < 4; ++cls) {
     const S2Class c = s2_class(cls, dx, p);
@@ -904,7 +882,6 @@ int dgrad_s2_bf16(const pm_tensor* dy, const float* w, const pm_tensor* dx, cons
   return pm_check_launch("dgrad_s2_interleave(native bf16 classes)");
 }
 
-int g_bf16_wgrad = 0;
 struct Bf16WgradPlan {
   bool use;
   long P, M, Nn, Kf;
@@ -913,7 +890,7 @@ struct Bf16WgradPlan {
 };
 Bf16WgradPlan bf16_wgrad_plan(const pm_tensor* x, const pm_tensor* dy, const pm_conv_params* p) {
   Bf16WgradPlan b{};
-  if (p->prec != 2 || !g_bf16_wgrad || x->c < 32 || dy->c < 32) return b;
+  if (p->prec != 2 || !pm_route.bf16_wgrad || x->c < 32 || dy->c < 32) return b;
   b.P = pm_pixels(dy);
   if (b.P % 64) return b;                                           // whole K-slabs of 64 pixels
   const long T = (long)p->kh * p->kw;
@@ -964,40 +941,62 @@ void gemm_dims(int which, const pm_tensor* x, const pm_tensor* y, const pm_conv_
 
 }  // namespace
 
-extern "C" int pm_set_winograd(int mode) {
-  PM_REQUIRE(mode == 0 || mode == 2 || mode == 4, PM_EINVAL, "pm_set_winograd: mode %d (0 off, 2 F(2x2,3x3), 4 prefer F(4x4,3x3))", mode);
-  g_wino_mode = mode;
+// ---- the library's routing state: ONE struct (include/pinmem_hip.h pm_routing), initialised from the PM_* environment at load, replaced as a whole by pm_routing_set.
+// The pm_set_* entry points below are thin wrappers that change one field (kernel tests, A/B runs).
+pm_routing pm_route = {
+    (int32_t)sizeof(pm_routing),
+    4,                                                                  // winograd: prefer F(4x4,3x3)
+    getenv("PM_WINO_FUSED") ? atoi(getenv("PM_WINO_FUSED")) : 0,        // winograd_fused
+    getenv("PM_CONV16") ? atoi(getenv("PM_CONV16")) : 1,                // conv16
+    getenv("PM_C16W") ? atoi(getenv("PM_C16W")) : 1,                    // conv16_wide
+    getenv("PM_C16P") ? atoi(getenv("PM_C16P")) : 1,                    // conv16_persistent
+    getenv("PM_WGRAD16") ? atoi(getenv("PM_WGRAD16")) : 1,              // wgrad16
+    0,                                                                  // bf16_wgrad
+    getenv("PM_SPLIT") ? atoi(getenv("PM_SPLIT")) : 1,                  // split
+};
+extern "C" int pm_routing_get(pm_routing* out) {
+  PM_REQUIRE(out && out->struct_size == (int32_t)sizeof(pm_routing), PM_EINVAL, "pm_routing_get: struct_size %d != %zu (library ABI %d)", out ? out->struct_size : -1,
+             sizeof(pm_routing), PM_ABI_VERSION);
+  *out = pm_route;
   return PM_OK;
 }
-extern int g_c16w;      // conv16.hip: 0 never the wide (conv16w.hip) kernel, 1 by the planner's cost model, 2 wherever the shape allows it
-extern int g_pw16;      // pw16.hip: 0 never the streaming 1x1 kernel, 1 by size, 2 every eligible 1x1
-extern int g_c16p;      // conv16.hip: 1 the ring tiles of conv16w.hip run persistent (producer / consumer waves), 0 one block per tile
+extern "C" int pm_routing_set(const pm_routing* r) {
+  PM_REQUIRE(r && r->struct_size == (int32_t)sizeof(pm_routing), PM_EINVAL, "pm_routing_set: struct_size %d != %zu (library ABI %d)", r ? r->struct_size : -1, sizeof(pm_routing),
+             PM_ABI_VERSION);
+  PM_REQUIRE(r->winograd == 0 || r->winograd == 2 || r->winograd == 4, PM_EINVAL, "pm_routing_set: winograd %d (0, 2 or 4)", r->winograd);
+  PM_REQUIRE(r->conv16 >= 0 && r->conv16 <= 2 && r->conv16_wide >= 0 && r->conv16_wide <= 3, PM_EINVAL, "pm_routing_set: conv16 %d / conv16_wide %d", r->conv16, r->conv16_wide);
+  pm_route = *r;
+  return PM_OK;
+}
+extern "C" int pm_set_winograd(int mode) {
+  PM_REQUIRE(mode == 0 || mode == 2 || mode == 4, PM_EINVAL, "pm_set_winograd: mode %d (0 off, 2 F(2x2,3x3), 4 prefer F(4x4,3x3))", mode);
+  pm_route.winograd = mode;
+  return PM_OK;
+}
 extern "C" int pm_set_conv16(int on) {
   PM_REQUIRE(on >= 0 && on <= 8, PM_EINVAL, "pm_set_conv16: %d (0 register-staged, 1 per shape, 2 LDS-DMA everywhere / narrow tiles only, 3 LDS-DMA everywhere / wide tiles "
-             "wherever the shape allows, 4 per shape without the wide kernel, 5 per shape with the streaming 1x1 kernel on every eligible call, 6 per shape without it, 7 as 3 with the 256 x 256 tile, "
+             "wherever the shape allows, 4 per shape without the wide kernel, 5 / 6 = 1 (the streaming 1x1 kernel left the library in round 6), 7 as 3 with the 256 x 256 tile, "
              "8 as 3 with one block per tile instead of the persistent ring)", on);
-  static const int c16w_default = g_c16w, pw16_default = g_pw16, c16p_default = g_c16p;
-  g_conv16 = (on == 3 || on == 7 || on == 8) ? 2 : ((on == 4 || on == 5 || on == 6) ? 1 : on);
-  g_c16w = (on == 3 || on == 8) ? 2 : (on == 7 ? 3 : ((on == 2 || on == 4) ? 0 : c16w_default));
-  g_c16p = on == 8 ? 0 : (on == 3 ? 1 : c16p_default);
-  g_pw16 = on == 5 ? 2 : ((on == 0 || on == 2 || on == 3 || on == 6 || on == 7 || on == 8) ? 0 : pw16_default);
+  static const pm_routing defaults = pm_route;      // the environment's defaults, as read at load
+  pm_route.conv16 = (on == 3 || on == 7 || on == 8) ? 2 : ((on == 4 || on == 5 || on == 6) ? 1 : on);
+  pm_route.conv16_wide = (on == 3 || on == 8) ? 2 : (on == 7 ? 3 : ((on == 2 || on == 4) ? 0 : defaults.conv16_wide));
+  pm_route.conv16_persistent = on == 8 ? 0 : (on == 3 ? 1 : defaults.conv16_persistent);
   return PM_OK;
 }
 extern "C" int pm_set_winograd_fused(int on) {
-  g_wino_fused = on != 0;
+  pm_route.winograd_fused = on != 0;
   return PM_OK;
 }
-extern int g_wgrad16;      // wgrad16.hip
 extern "C" int pm_set_wgrad16(int on) {
-  g_wgrad16 = on != 0;
+  pm_route.wgrad16 = on != 0;
   return PM_OK;
 }
 extern "C" int pm_set_split(int on) {
-  g_split = on ? 1 : 0;
+  pm_route.split = on ? 1 : 0;
   return PM_OK;
 }
 extern "C" int pm_set_bf16_wgrad(int on) {
-  g_bf16_wgrad = on != 0;
+  pm_route.bf16_wgrad = on != 0;
   return PM_OK;
 }
 extern "C" int pm_profile_enable(int on) {
@@ -1110,9 +1109,6 @@ static bool bn_partials_route(const pm_tensor* x, const pm_tensor* y, const pm_c
   if (pm_is_bf16(y)) {      // bf16 tier: both bf16 kernels carry the statistics in their 8-column staged epilogue (one K split, whole 16-byte groups)
     if (!pm_vec8(y)) return false;
     const Bf16Plan b = bf16_plan(x, y, p);
-    if (b.use && p->kh * p->kw == 1 && p->stride == 1 && p->pad == 0 && x->h == y->h && x->w == y->w &&
-        pm_pw16_ok(b.M, (int)b.Nn, b.Cp, b.inplace ? x->pitch : b.Cp, y->pitch, 0, b.inplace ? x->ptr : y->ptr, y->ptr, nullptr))
-      return false;      // the streaming 1x1 kernel (pw16.hip) has no statistics epilogue
     return b.use && (b.c16 ? (b.k16.ksplit == 1 && !b.k16.wide) : b.pl.ksplit == 1);
   }
   if (pm_is_bf16(x)) return false;

@@ -137,10 +137,9 @@ struct pm_wgrad16 {
 bool pm_wgrad16_plan(pm_wgrad16* k);      // false: the shape stays with the register-staged kernel
 int pm_wgrad16_launch(const pm_wgrad16* k, hipStream_t st);
 
-// ---- the streaming 1x1 convolution of the bf16 tier (pw16.hip): persistent blocks, weights resident in LDS, 16-byte stores straight from the accumulators ----------
-bool pm_pw16_ok(long M, int Nn, int K, long x_pitch, long y_pitch, long r_pitch, const void* x, const void* y, const void* r);
-int pm_pw16_launch(const pm_bf16* X, long x_pitch, const pm_bf16* W, pm_bf16* Y, long y_pitch, const pm_bf16* R, long r_pitch, long M, int Nn, int K, const float* bias,
-                   const float* scale, const float* shift, int relu, hipStream_t st);
+// the library's routing state (conv_igemm.hip): one struct, see include/pinmem_hip.h pm_routing
+extern pm_routing pm_route;
+
 
 // ---- device helpers -------------------------------------------------------------------------------------------
 // eight bf16 channels (16 bytes) <-> eight floats. Round to nearest even on the way out (v_cvt_pk_bf16_f32).

@@ -20,7 +20,6 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-int g_wgrad16 = getenv("PM_WGRAD16") ? atoi(getenv("PM_WGRAD16")) : 1;      // 0: the register-staged weight gradient everywhere (A/B), 1: this kernel where pm_wgrad16_ok
 
 namespace {
 
@@ -276,7 +275,7 @@ void launch_wgrad16(const pm_wgrad16& k, hipStream_t st) {
 // The shapes the kernel takes: both tensors bf16 with whole 16-byte channel groups, Cin in 128-channel blocks (at least three quarters full in total), at least 128 output
 // channels, 32-bit byte offsets. Fills the tile plan; the pixel split (kper, ksplit) is the caller's (the slabs were sized for it).
 bool pm_wgrad16_plan(pm_wgrad16* k) {
-  if (!g_wgrad16) return false;
+  if (!pm_route.wgrad16) return false;
   // Cin: 128-channel blocks at least three quarters full in total (the decoder's 304-channel concat: 2.4 blocks, 21 % of the multiplications on zeros)
   const int cblocks = pm_cdiv(k->Cin, 128);
   if (k->Cin % 8 || k->Cin < 128 || k->Cin * 4 < cblocks * 128 * 3 || k->Cout < 128 || (k->x_pitch | k->dy_pitch) % 8 || k->kper % BKP) return false;

@@ -1,5 +1,6 @@
 """Raw (non-autograd) launches of the HIP kernels on torch-owned NHWC fp32 tensors.
 Every function enqueues on torch's current stream and returns torch tensors; no CPU fallback exists."""
+import ctypes
 from ctypes import byref
 
 import os
@@ -864,6 +865,24 @@ def set_wgrad16(on):
     """bf16 tier, weight gradient of bf16 x / dy: True (default) = the LDS-DMA persistent ring (csrc/wgrad16.hip) where the shape allows, False = register-staged everywhere."""
     check(_lib().pm_set_wgrad16(1 if on else 0), 'pm_set_wgrad16')
     _GEN[0] += 1
+
+
+def routing(**fields):
+    """The library's routing state (include/pinmem_hip.h pm_routing) as a dict; keyword arguments replace fields -- ONE pm_routing_set call, the form a production caller
+    uses (once, before the first convolution). Returns the state before the change."""
+    from .lib import PmRouting
+    r = PmRouting()
+    r.struct_size = ctypes.sizeof(PmRouting)
+    check(_lib().pm_routing_get(byref(r)), 'pm_routing_get')
+    before = {k: getattr(r, k) for k, _ in PmRouting._fields_ if k != 'struct_size'}
+    if fields:
+        for k, v in fields.items():
+            if k not in before:
+                raise KeyError('pm_routing has no field %r' % k)
+            setattr(r, k, int(v))
+        check(_lib().pm_routing_set(byref(r)), 'pm_routing_set')
+        _GEN[0] += 1
+    return before
 
 
 def set_split(on):

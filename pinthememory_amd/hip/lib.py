@@ -33,6 +33,12 @@ class PmConvParams(ctypes.Structure):
                 ('wxf', c_void_p), ('wxf_bytes', c_int64), ('wxf_valid', c_int32)]
 
 
+class PmRouting(ctypes.Structure):
+    """include/pinmem_hip.h pm_routing: the library's one piece of mutable state -- which kernel takes a call."""
+    _fields_ = [('struct_size', c_int32), ('winograd', c_int32), ('winograd_fused', c_int32), ('conv16', c_int32), ('conv16_wide', c_int32),
+                ('conv16_persistent', c_int32), ('wgrad16', c_int32), ('bf16_wgrad', c_int32), ('split', c_int32)]
+
+
 class PmConvEpilogue(ctypes.Structure):
     _fields_ = [('struct_size', c_int64), ('bias', c_void_p), ('scale', c_void_p), ('shift', c_void_p), ('residual', c_void_p),
                 ('residual_pitch', c_int64), ('relu', c_int32), ('bn_partials', c_void_p), ('bn_partials_bytes', c_int64)]
@@ -134,6 +140,8 @@ SIGNATURES = {
     'pm_set_bf16_wgrad': (_i, [_i]),
     'pm_set_wgrad16': (_i, [_i]),
     'pm_set_split': (_i, [_i]),
+    'pm_routing_get': (_i, [POINTER(PmRouting)]),
+    'pm_routing_set': (_i, [POINTER(PmRouting)]),
     'pm_conv_bn_partials_bytes': (_sz, [_T, _T, POINTER(PmConvParams)]),
     'pm_bn_partials_finalize': (_i, [_vp, _i64, _i, _f, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
     'pm_sgd_momentum_multi': (_i, [_vp, _i, _f, _f, _f, _vp]),

@@ -55,3 +55,33 @@ def test_argument_validation_without_gpu():
     assert lib.pm_mem_colsoftmax(None, None, 0, 19, None, None, 0, None) == -1
     assert b'mem_colsoftmax' in lib.pm_last_error()
     assert lib.pm_sgd_momentum(None, None, None, 10, 0.1, 0.9, 0.0, 1, None) == -1
+
+
+def test_routing_is_one_struct_with_single_field_wrappers():
+    """Round 6: the library's only mutable global state is ONE pm_routing value -- struct_size-guarded, read and replaced as a whole; the pm_set_*
+    entry points change one field of it. No compute: which kernel WOULD take a call."""
+    import ctypes
+    from ctypes import byref
+    lib = L.load()
+    r = L.PmRouting()
+    r.struct_size = ctypes.sizeof(L.PmRouting)
+    assert lib.pm_routing_get(byref(r)) == 0
+    before = {k: getattr(r, k) for k, _ in L.PmRouting._fields_}
+    assert before['winograd'] in (0, 2, 4) and before['split'] in (0, 1) and before['conv16'] in (0, 1, 2)
+    bad = L.PmRouting()
+    bad.struct_size = ctypes.sizeof(L.PmRouting) - 4                 # "another header"
+    assert lib.pm_routing_get(byref(bad)) == -1 and b'struct_size' in lib.pm_last_error()
+    assert lib.pm_routing_set(byref(bad)) == -1
+    try:
+        assert lib.pm_set_split(0) == 0 and lib.pm_set_winograd(2) == 0 and lib.pm_set_conv16(8) == 0
+        assert lib.pm_routing_get(byref(r)) == 0
+        assert (r.split, r.winograd, r.conv16, r.conv16_wide, r.conv16_persistent) == (0, 2, 2, 2, 0)
+        assert lib.pm_set_conv16(5) == 0 and lib.pm_routing_get(byref(r)) == 0 and r.conv16 == 1      # the streaming 1x1 kernel left the library: 5 / 6 mean 1
+        r.winograd = 3
+        assert lib.pm_routing_set(byref(r)) == -1 and b'winograd' in lib.pm_last_error()              # validated as a whole, nothing applied
+        assert lib.pm_routing_get(byref(r)) == 0 and r.winograd == 2
+    finally:
+        for k, v in before.items():
+            setattr(r, k, v)
+        assert lib.pm_routing_set(byref(r)) == 0
+    assert lib.pm_routing_get(byref(r)) == 0 and {k: getattr(r, k) for k, _ in L.PmRouting._fields_} == before
