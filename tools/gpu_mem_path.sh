@@ -1,6 +1,6 @@
 #!/bin/bash
 # memory read / write / read-loss path: HIP-event timing + FETCH_SIZE / WRITE_SIZE passes of tools/mem_probe.py
-cd "$GRAFT_REPO_ROOT" || exit 1
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 export TMPDIR=/tmp
 O=gpurun_out/$1; mkdir -p $O
 timeout 300 python tools/mem_probe.py 2>&1 | grep -v amdgpu.ids | tee $O/mem_probe.txt; cp gpurun_out/mem_probe.json $O/mem_probe.json

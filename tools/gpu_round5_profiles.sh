@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-5 evidence set in one gpurun call. usage: gpu_round5_profiles.sh <tag> <prefix>   -> gpurun_out/<tag>/, profiles/<prefix>_* on the box (copy back from gpurun_out)
-cd "$GRAFT_REPO_ROOT" || exit 1
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 export TMPDIR=/tmp
 O=gpurun_out/$1; P=$2; mkdir -p $O
 for DT in f32 bf16; do
