@@ -658,12 +658,9 @@ template <int BM, int BN, int WM, int WN, int NP>
 void launch_persistent(const pm_conv16& k, hipStream_t st) {
   constexpr size_t smem = (size_t)3 * (BM + BN) * BKB;
   static_assert(smem <= 160 * 1024, "LDS budget");
-  static const int ncu = [] {
+  const int ncu = pm_device_once([] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv16p_kernel<BM, BN, WM, WN, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n > 0 ? n : 256;
-  }();
+  });
   const int total = k.tiles_m * k.tiles_n * k.ksplit;
   hipLaunchKernelGGL((conv16p_kernel<BM, BN, WM, WN, NP>), dim3(std::min(total, ncu)), dim3((8 + NP) * 64), smem, st, k);
 }
@@ -673,11 +670,9 @@ void launch_wide(const pm_conv16& k, dim3 grid, hipStream_t st) {
   constexpr size_t stage_bytes = (size_t)NST * (BM + BN) * BKB, ep_bytes = (size_t)8 * 32 * (BN / WN + 4) * sizeof(float);
   constexpr size_t smem = stage_bytes > ep_bytes ? stage_bytes : ep_bytes;
   static_assert(smem <= 160 * 1024, "LDS budget");
-  static const bool attr_set = [] {
+  (void)pm_device_once([] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv16w_kernel<BM, BN, WM, WN, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    return true;
-  }();
-  (void)attr_set;
+  });
   hipLaunchKernelGGL((conv16w_kernel<BM, BN, WM, WN, NST>), grid, dim3(NT), smem, st, k);
 }
 

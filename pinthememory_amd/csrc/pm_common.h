@@ -137,6 +137,23 @@ struct pm_wgrad16 {
 bool pm_wgrad16_plan(pm_wgrad16* k);      // false: the shape stays with the register-staged kernel
 int pm_wgrad16_launch(const pm_wgrad16* k, hipStream_t st);
 
+// One-time setup per DEVICE of a kernel that needs it (the > 64 KB dynamic-LDS opt-in) and the CU count of the current device (persistent kernels size their grid by
+// it). ADVICE r5: a `static` per process served the device that happened to be current at the first call -- a later launch on another device asked for 144 KB of LDS
+// without the attribute and sized its grid by device 0. The static lives in this template, i.e. once per call site (each passes its own lambda type).
+template <typename F>
+inline int pm_device_once(F&& setup) {
+  static int ncu[32] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
+  if (!ncu[dev]) {
+    setup();
+    int n = 256;
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    ncu[dev] = n > 0 ? n : 256;
+  }
+  return ncu[dev];
+}
+
 // the library's routing state (conv_igemm.hip): one struct, see include/pinmem_hip.h pm_routing
 extern pm_routing pm_route;
 

@@ -260,12 +260,9 @@ template <int BM, int BN, int WM, int WN>
 void launch_wgrad16(const pm_wgrad16& k, hipStream_t st) {
   constexpr size_t smem = (size_t)3 * BKP * (BM + BN) * 2;
   static_assert(smem <= 160 * 1024, "LDS budget");
-  static const int ncu = [] {
+  const int ncu = pm_device_once([] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad16_kernel<BM, BN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n > 0 ? n : 256;
-  }();
+  });
   const int total = k.tiles_m * k.tiles_n * k.ksplit;
   hipLaunchKernelGGL((wgrad16_kernel<BM, BN, WM, WN>), dim3(std::min(total, ncu)), dim3((8 + NP) * 64), smem, st, k);
 }

@@ -86,9 +86,24 @@ def sync_commit(net=None):
     ops.wait_commit()
 
 
+_WITHHELD = {}      # id(Memory_sup) -> weakref to the open GraphedAggStep(pipelined=True) whose last commit is withheld (m_items is one commit behind between replays)
+
+
+def _check_not_withheld(net, what):
+    """with GraphedAggStep(pipelined=True) open, `m_items` is one commit behind between replays -- a checkpoint, a validation pass or an mldg step that read it
+    would silently see stale memory. Raise instead (as restore_snapshot does for an owed cross-rank commit): read g.committed_memory(), or g.close() first."""
+    m = net.module if hasattr(net, 'module') else net
+    ref = _WITHHELD.get(id(getattr(m, 'memory', None)))
+    g = ref() if ref is not None else None
+    if g is not None and not g.closed:
+        raise RuntimeError('%s: a GraphedAggStep(pipelined=True) is open on this model -- its last memory commit is withheld until the next replay, so net.memory.m_items is '
+                           'one commit behind. Use g.committed_memory() for the up-to-date memory, or g.close() before handing the model to eager code.' % what)
+
+
 def save_checkpoint(path, net, optimizer=None, scheduler=None, epoch=0, mean_iu=0.0):
     """utils/misc.py:195-216 for the harness: EVERY rank calls it (it finishes a pending memory commit collectively), rank 0 writes the file."""
     from . import checkpoint
+    _check_not_withheld(net, 'save_checkpoint')
     finish_commit(net)
     if not D.is_dist() or torch.distributed.get_rank() == 0:
         checkpoint.save_snapshot(path, net, optimizer, scheduler, epoch, mean_iu)
@@ -242,6 +257,8 @@ class GraphedAggStep:
             self.mem = m.memory.m_items.detach().clone()
             m.memory.m_items = self.mem
             if pipelined:
+                import weakref
+                _WITHHELD[id(m.memory)] = weakref.ref(self)
                 # one more eager step whose commit is withheld: the state every replay starts from (weights after SGD t, memory committed through t - 1, batch t in x_prev)
                 self.x_prev, self.gts_prev = self.x.clone(), self.gts.clone()
                 self.lr.fill_(float(opt.param_groups[0]['lr']))
@@ -329,6 +346,7 @@ class GraphedAggStep:
         torch.cuda.synchronize()
         if self.pipelined:
             self._commit(torch.cuda.current_stream(), overlap=False)
+            _WITHHELD.pop(id(self.m.memory), None)
         self.m.memory.m_items = self.mem.clone()
         self.m.memory.pending = None
         ops.commit_done.pop(self.x.device.index, None)
@@ -480,6 +498,7 @@ def mldg_train_step(net, updated_net, updated_net2, opt, x_tr, y_tr, x_te, y_te,
     WRITTEN memory into the write graph (memory.py:323-324 only detaches when writing), outer step, memory commit.
     inner_lr: the reference's default 1e-3 (train.py:1208); with inner_lr_anneal the returned dict carries `next_inner_lr` = lr / 4 of the
     outer schedule after this step (train.py:625-626) for the caller to pass into the next iteration."""
+    _check_not_withheld(net, 'mldg_train_step')
     set_mode(net, True)
     finish_commit(net)          # every rank is here: a memory commit deferred by a preceding agg step is finished before m_items is read
     mem_t = net.memory.m_items.clone().detach()
