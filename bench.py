@@ -466,7 +466,7 @@ PREC_NAMES = ('v_mfma_f32_32x32x2_f32', 'v_mfma_f32_32x32x16_bf16 on fp32 tiles 
               'v_mfma_f32_32x32x16_bf16 on bf16 LDS tiles filled by global_load_lds (LDS-DMA), source-side XOR swizzle')
 
 
-DOMINANT = {'split': False}      # set by dominant_conv_kernel: the dominant kernel of the fp32 tier is a split-operand instantiation (bf16 matrix pipe)
+DOMINANT = {'split': False, 'bytes': 0.0}      # set by dominant_conv_kernel: the dominant kernel of the fp32 tier is a split-operand instantiation (bf16 matrix pipe)
 
 
 def dominant_conv_kernel(K, bf16):
@@ -477,12 +477,13 @@ def dominant_conv_kernel(K, bf16):
     for mode in ((0, 1, 2) if not bf16 else (0, 1, 2, 4, 5)):
         for bm in (256, 128, 64):
             for bn in (256, 128, 64, 32):
-                for km in (0, 1, 2):
+                for km in (0, 1, 2, 3):      # 3 = K_PW: the split path's pointwise K-state
                     for nst in (3, 2, 1):
                         for prec in ((0, 5) if not bf16 else ((5,) if mode >= 4 else (2, 4, 3, 1))):      # fp32 tier: 0 = fp32 MFMA, 5 = split operands on the bf16 pipe
                             r = K.profile_read(mode=mode, bm=bm, bn=bn, km=km, nst=nst, prec=prec)
                             if r[2] and (best is None or r[0] > best[0][0]):
                                 best = (r, (mode, bm, bn, km, nst), prec)
+                                DOMINANT['bytes'] = K.profile_read_bytes(mode=mode, bm=bm, bn=bn, km=km, nst=nst, prec=prec)
     if best is None:
         return None
     r, (mode, bm, bn, km, nst), kprec = best
@@ -491,7 +492,7 @@ def dominant_conv_kernel(K, bf16):
         sym = 'conv_igemm_kernel<%d, %d, %d, 2, 2, %d, 5, %d>' % (mode, bm, bn, km, nst)
         what = ('%s, %dx%dx32 tile, %s K-state, %s LDS; fp32 operands, 3-way exact bf16 split (hi + mid + lo == x) as the gathered rows are stored to LDS, 6 cross products on '
                 'v_mfma_f32_32x32x16_bf16, fp32 accumulate (csrc/conv_split.hip); direct convolutions and the batched Winograd F(4x4,3x3) / F(2x2,3x3) GEMMs; '
-                'FLOPs = 2*M*N*K of the fp32 problem' % (('forward', 'data gradient', 'weight gradient')[mode], bm, bn, ('wave-uniform', 'per-lane', 'per-lane looping')[km],
+                'FLOPs = 2*M*N*K of the fp32 problem' % (('forward', 'data gradient', 'weight gradient')[mode], bm, bn, ('wave-uniform', 'per-lane', 'per-lane looping', 'wave-uniform pointwise (row validity folded into the base offset)')[km],
                                                         'double-buffered' if nst == 2 else 'single-stage'))
         return r, sym, what
     if mode == 5 and km == 1:
@@ -773,6 +774,10 @@ def main():
                     'effective_fp32_tflops': round(ach, 2), 'effective_vs_fp32_mfma_peak': round(ach / PEAK_TFLOPS_F32_MFMA, 4),
                     'traffic': traffic, 'traffic_source': traffic_src,
                     'traffic_stale': traffic_stale,
+                    'algorithmic_bytes_per_launch': round(DOMINANT['bytes'] / n) if DOMINANT.get('bytes') else None,
+                    'traffic_over_algorithmic': round(traffic / (DOMINANT['bytes'] / n), 3) if (traffic and DOMINANT.get('bytes')) else None,
+                    'algorithmic_bytes_note': 'both operands once + the output (every slab of a split-K launch), averaged over the launches of the symbol in the serialised pass',
+                    'achieved_GBps_algorithmic': round(DOMINANT['bytes'] / n / (ms / n * 1e-3) / 1e9, 1) if DOMINANT.get('bytes') else None,
                     'launches_per_step': n / prof_steps, 'avg_launch_ms': round(ms / n, 5), 'gflop_per_launch': round(fl / n / 1e9, 3),
                     'measured': '%d extra steps after the timed region (event timing costs ~1.7 ms/step, so the timed region runs without it), all launches '
                                 'serialised on one stream (with the weight gradients on their side stream and the commit forward on its own every concurrent kernel\'s duration inflates)' % prof_steps,

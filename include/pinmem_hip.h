@@ -198,6 +198,9 @@ int pm_profile_dump(const char* csv_path);   /* one line per recorded launch: mo
 int pm_profile_read(int mode, int bm, int bn, int km, int nst, double* total_ms, double* total_flops, int64_t* launches, int clear);
 /* the same, additionally keyed by the operand form of the instantiation (prec 0 / 1 / 2 of pm_conv_params; negative = any) */
 int pm_profile_read_prec(int mode, int bm, int bn, int km, int nst, int prec, double* total_ms, double* total_flops, int64_t* launches, int clear);
+/* Sum of the ALGORITHMIC HBM bytes of the recorded launches of one implicit-GEMM instantiation (same keys, negative = any): both operands once + the output (every slab of a
+ * split-K launch) -- the figure bench.py's roofline.traffic (PMC counters) is held against. Call before the pm_profile_read* that clears the records. */
+int pm_profile_read_bytes(int mode, int bm, int bn, int km, int nst, int prec, double* total_bytes);
 
 /* ---- K4 BatchNorm2d (mynn.py:8-14 -> nn.BatchNorm2d / SyncBatchNorm, eps 1e-5, momentum 0.1) -------------------
  * stats: per-channel shifted sums -> (count, mean, M2) so that ranks can be merged exactly (SyncBN, train.py:95).

@@ -397,6 +397,7 @@ struct ProfRec {
   int mode, bm, bn, km, prec, nst;
   int M, Nn, K, batch, ksplit;
   double flops;
+  double bytes;      // algorithmic HBM bytes of the launch: both operands once (their descriptor extents) + the output (split-K: every slab) -- what `traffic` is held against
 };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
@@ -421,10 +422,11 @@ int launch(const ConvK& k0, const Plan& p, hipStream_t st, int batch = 1, double
   // batched Winograd GEMMs whose product M[p] stays in L2 / Infinity Cache for the output transform (tools/gpu_env_ab2.sh PM_STAGE_EP)
   if (batch != 1 && !getenv("PM_STAGE_EP")) k.stage_ep = 0;
   if (k.prec == 0 && split_takes(MODE, p, k, batch)) k.prec = 5;
-  ProfRec rec;
+  ProfRec rec{};
   if (g_prof_on) {
     (void)hipEventCreate(&rec.a), (void)hipEventCreate(&rec.b);
-    rec.mode = MODE, rec.bm = p.bm, rec.bn = p.bn, rec.km = (MODE == MODE_WGRAD && k.kmode == K_FAST) ? K_MID : k.kmode, rec.prec = k.prec, rec.nst = (MODE != MODE_WGRAD && k.kmode == K_FAST && p.bn >= 64 && k.kper <= nst1_max_steps() * BK) ? 1 : 2, rec.M = k.M, rec.Nn = k.Nn, rec.K = k.K, rec.batch = batch, rec.ksplit = p.ksplit, rec.flops = flops >= 0.0 ? flops : 2.0 * (double)k.M * (double)k.Nn * (double)k.K * batch;
+    rec.mode = MODE, rec.bm = p.bm, rec.bn = p.bn, rec.km = (MODE == MODE_WGRAD && k.kmode == K_FAST) ? K_MID : ((k.prec == 5 && MODE != MODE_WGRAD && k.kmode == K_FAST && k.kh * k.kw == 1 && k.stride == 1 && k.pad == 0 && !k.sub) ? K_PW : k.kmode), rec.prec = k.prec, rec.nst = (MODE != MODE_WGRAD && k.kmode == K_FAST && p.bn >= 64 && k.kper <= nst1_max_steps() * BK) ? 1 : 2, rec.M = k.M, rec.Nn = k.Nn, rec.K = k.K, rec.batch = batch, rec.ksplit = p.ksplit, rec.flops = flops >= 0.0 ? flops : 2.0 * (double)k.M * (double)k.Nn * (double)k.K * batch;
+    rec.bytes = (double)batch * ((double)k.a_bytes + (double)k.b_bytes + ((k.io16 && p.ksplit == 1) ? 2.0 : 4.0) * (double)k.M * (double)k.Nn * (double)p.ksplit);
     (void)hipEventRecord(rec.a, st);
   }
   constexpr bool akc = MODE != MODE_WGRAD, bkc = MODE == MODE_FWD;
@@ -581,7 +583,7 @@ int wino_conv(const pm_tensor* xin, const float* w, int w_cout, int w_cin, bool 
   // 4600 MFMA cycles. Bounds measured on the unfused path: a GEMM that never stores M -3.3 ms/step, no output-transform pass either -5.6 ms/step.
   // Kept as an opt-in (PM_WINO_FUSED=1) with its tests; the default is the batched GEMM + wino_output_kernel.
   if (pm_route.winograd_fused && wp.g.m == 4 && wp.Kp % 16 == 0) {
-    ProfRec rec;
+    ProfRec rec{};
     if (g_prof_on) {
       (void)hipEventCreate(&rec.a), (void)hipEventCreate(&rec.b);
       rec.mode = 3, rec.bm = 32, rec.bn = 32, rec.km = 0, rec.prec = 0, rec.nst = 1, rec.M = (int)wp.g.tiles, rec.Nn = cout, rec.K = wp.Kp, rec.batch = wp.P, rec.ksplit = 1;
@@ -727,7 +729,7 @@ int conv_bf16(const pm_tensor* xin, const float* w, int w_cout, int w_cin, bool 
       k.A = (const pm_bf16*)xb, k.B = (const pm_bf16*)wb;
       // EXECUTED FLOPs: the K-steps of filter rows that no row of a tile can see are skipped by the kernel (dilated ASPP branches) and are not counted
       const double fl = 2.0 * (double)b.M * (double)b.Nn * (double)T * (double)xin->c * (g_prof_on ? pm_conv16_executed_fraction(&k) : 1.0);
-      ProfRec rec;
+      ProfRec rec{};
       if (g_prof_on) {
         (void)hipEventCreate(&rec.a), (void)hipEventCreate(&rec.b);
         rec.mode = k.wide ? 5 : 4, rec.bm = k.bm, rec.bn = k.bn, rec.km = pm_conv16w_persistent(&k), rec.prec = 5, rec.nst = k.wide ? 3 : (k.ksteps_per == 1 ? 1 : 2), rec.M = k.M, rec.Nn = k.Nn, rec.K = k.K / 2, rec.batch = 1,
@@ -857,7 +859,7 @@ int dgrad_s2_bf16(const pm_tensor* dy, const float* w, const pm_tensor* dx, cons
     pm_conv16 k = s.k[cls];
     k.A = (const pm_bf16*)dy->ptr, k.B = (const pm_bf16*)((char*)ws + s.wb_off[cls]);
     void* out = (char*)ws + s.out_off[cls];
-    ProfRec rec;
+    ProfRec rec{};
     if (g_prof_on) {
       (void)hipEventCreate(&rec.a), (void)hipEventCreate(&rec.b);
       rec.mode = 4, rec.bm = k.bm, rec.bn = k.bn, rec.km = 0, rec.prec = 5, rec.nst = k.ksteps_per == 1 ? 1 : 2, rec.M = k.M, rec.Nn = k.Nn, rec.K = k.K / 2, rec.batch = 1,
@@ -1028,6 +1030,20 @@ extern "C" int pm_profile_read_prec(int mode, int bm, int bn, int km, int nst, i
   if (total_ms) *total_ms = ms;
   if (total_flops) *total_flops = fl;
   if (launches) *launches = n;
+  return PM_OK;
+}
+
+// sum of the algorithmic bytes (operands once + output) of the recorded launches of one instantiation (negative key = any); for records other entry points file
+// (the fused Winograd kernel, the bf16 tier's LDS-DMA kernels) the field is 0 unless they fill it
+extern "C" int pm_profile_read_bytes(int mode, int bm, int bn, int km, int nst, int prec, double* total_bytes) {
+  double b = 0.0;
+  for (const ProfRec& r : g_prof) {
+    if ((mode >= 0 && r.mode != mode) || (bm >= 0 && r.bm != bm) || (bn >= 0 && r.bn != bn) || (km >= 0 && r.km != km) || (nst >= 0 && r.nst != nst) ||
+        (prec >= 0 && r.prec != prec))
+      continue;
+    b += r.bytes;
+  }
+  if (total_bytes) *total_bytes = b;
   return PM_OK;
 }
 
@@ -1441,7 +1457,7 @@ extern "C" int pm_conv_bwd_weight(const pm_tensor* x0, const pm_tensor* dy0, flo
     }
   }
   if (use16) {
-    ProfRec rec;
+    ProfRec rec{};
     if (g_prof_on) {
       (void)hipEventCreate(&rec.a), (void)hipEventCreate(&rec.b);
       rec.mode = MODE_WGRAD, rec.bm = w16.bm, rec.bn = w16.bn, rec.km = 2, rec.prec = 4, rec.nst = 3, rec.M = (int)M, rec.Nn = (int)Nn, rec.K = (int)K, rec.batch = 1, rec.ksplit = w16.ksplit,

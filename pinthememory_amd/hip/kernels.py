@@ -905,6 +905,13 @@ def profile_dump(path):
     check(_lib().pm_profile_dump(str(path).encode()), 'pm_profile_dump')
 
 
+def profile_read_bytes(mode=-1, bm=-1, bn=-1, km=-1, nst=-1, prec=-1):
+    """-> algorithmic HBM bytes (operands once + output) summed over the recorded launches of one instantiation: what bench.py's roofline.traffic is held against."""
+    b = ctypes.c_double(0)
+    check(_lib().pm_profile_read_bytes(mode, bm, bn, km, nst, prec, byref(b)), 'pm_profile_read_bytes')
+    return b.value
+
+
 def profile_read(mode=-1, bm=-1, bn=-1, km=-1, nst=-1, clear=False, prec=-1):
     """-> (total_ms, total_flops, launches) of the conv_igemm_kernel<mode, bm, bn, .., km, prec, nst> launches recorded since the last clear."""
     import ctypes

@@ -82,6 +82,7 @@ SIGNATURES = {
     'pm_profile_dump': (_i, [ctypes.c_char_p]),
     'pm_profile_read': (_i, [_i, _i, _i, _i, _i, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64), _i]),
     'pm_profile_read_prec': (_i, [_i, _i, _i, _i, _i, _i, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64), _i]),
+    'pm_profile_read_bytes': (_i, [_i, _i, _i, _i, _i, _i, POINTER(ctypes.c_double)]),
     'pm_bn_workspace': (_sz, [_T]),
     'pm_bn_stats': (_i, [_T, _vp, _vp, _sz, _vp]),
     'pm_bn_merge': (_i, [_vp, _i, _i, _vp, _vp]),

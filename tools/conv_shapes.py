@@ -6,7 +6,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0
 agg = {}
 for r in rows:
-    key = tuple(int(r[k]) for k in ('mode', 'bm', 'bn', 'km', 'nst', 'M', 'N', 'K', 'batch', 'ksplit'))
+    key = tuple(int(r[k]) for k in ('mode', 'bm', 'bn', 'km', 'nst', 'M', 'N', 'K', 'batch', 'ksplit')) + (int(r.get('prec', 0)),)
     a = agg.setdefault(key, [0, 0.0, 0.0])
     a[0] += 1; a[1] += float(r['ms']); a[2] += float(r['gflop'])
 tot = sum(a[1] for a in agg.values()) / steps
@@ -17,6 +17,6 @@ for k, (n, ms, gf) in agg.items():
     lost = ms - gf / 135.0
     out.append((lost / steps, ms / steps, n / steps, tf, k))
 out.sort(reverse=True)
-print('%8s %8s %6s %7s  mode bm  bn km nst      M     N      K  batch ksplit' % ('lost/st', 'ms/st', 'n/st', 'TF'))
+print('%8s %8s %6s %7s  mode bm  bn km nst      M     N      K  batch ksplit prec' % ('lost/st', 'ms/st', 'n/st', 'TF'))
 for lost, ms, n, tf, k in out[:int(sys.argv[3]) if len(sys.argv) > 3 else 45]:
-    print('%8.3f %8.3f %6.1f %7.1f  %4d %3d %3d %2d %3d %7d %5d %6d %5d %5d' % ((lost, ms, n, tf) + k))
+    print('%8.3f %8.3f %6.1f %7.1f  %4d %3d %3d %2d %3d %7d %5d %6d %5d %5d %4d' % ((lost, ms, n, tf) + k))
