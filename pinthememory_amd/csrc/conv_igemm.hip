@@ -422,6 +422,12 @@ int launch(const ConvK& k0, const Plan& p, hipStream_t st, int batch = 1, double
   // batched Winograd GEMMs whose product M[p] stays in L2 / Infinity Cache for the output transform (tools/gpu_env_ab2.sh PM_STAGE_EP)
   if (batch != 1 && !getenv("PM_STAGE_EP")) k.stage_ep = 0;
   if (k.prec == 0 && split_takes(MODE, p, k, batch)) k.prec = 5;
+  {      // whole (batch, K-slice) units per XCD (conv_igemm_kernel.h): the unit count's remainder mod 8 must cut evenly into runs of tiles
+    static const int batch_xcd = getenv("PM_BATCH_XCD") ? atoi(getenv("PM_BATCH_XCD")) : 3;      // bit 0: batched launches, bit 1: split-K launches
+    const int units = batch * p.ksplit, rem = units & 7, ntile = p.tiles_m * p.tiles_n;
+    const bool want = p.ksplit > 1 ? (batch_xcd & 2) != 0 : (batch_xcd & 1) != 0;
+    k.batch_xcd = want && units >= 8 && (rem == 0 || ((rem == 1 || rem == 2 || rem == 4) && ntile % (8 / rem) == 0));
+  }
   ProfRec rec{};
   if (g_prof_on) {
     (void)hipEventCreate(&rec.a), (void)hipEventCreate(&rec.b);
@@ -499,6 +505,9 @@ void fill_geom(ConvK& k, const pm_tensor* x, const pm_tensor* y, const pm_conv_p
   k.stage_ep = stage_ep;
   static const int spl_prio = getenv("PM_SPLIT_PRIO") ? atoi(getenv("PM_SPLIT_PRIO")) : 1;
   k.spl_prio = spl_prio;
+  static const int n_group = getenv("PM_N_GROUP") ? atoi(getenv("PM_N_GROUP")) : 8;
+  k.n_group = n_group;
+  k.batch_xcd = 0;
   k.a_bs = k.b_bs = k.c_bs = 0;
 }
 

@@ -41,6 +41,9 @@ struct ConvK {
   float* stats;               // train-mode BN statistics of the output: (mean, M2) per 32-row slab and channel, or null
   int io16;                   // the bf16 tier: C and `residual` are bf16 tensors (pitches in elements); accumulation and the epilogue arithmetic stay fp32
   int stage_ep;               // 1: epilogue staged through LDS (16-byte row stores); 0: per-element stores (PM_STAGE_EP=0, A/B)
+  int n_group;                // > 0: N tiles are walked in groups of n_group columns (tile order inside a group: M outer, N inner), so that one XCD's co-resident
+                              // blocks cover a squarer patch of the output and the weight columns of the group stay in that XCD's L2 over the whole sweep of M
+  int batch_xcd;              // 1: gridDim.y >= 8 batches are dealt to the XCDs whole (see the kernel); set by the launcher when the counts divide
   int spl_prio;               // PREC 5: 1 = waves in odd hardware wave slots run at s_setprio 2 (see the kernel), 0 = all equal
 };
 
@@ -139,17 +142,40 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvK a) {
   const int g = t & 7, r = t >> 3;
 
   const int ntile = a.tiles_m * a.tiles_n;
-  const int lid = xcd_remap(blockIdx.x, ntile);
-  const int tile_m = lid / a.tiles_n, tile_n = lid % a.tiles_n;
+  // Batched / split-K launches (the 36 / 16 point GEMMs of a Winograd layer; the K slices of a weight gradient): whole (batch, K-slice) units go to one XCD (unit u -> XCD
+  // u mod 8; a remainder of 1 / 2 / 4 units is cut into 8 / 4 / 2 runs of tiles), so that both operands of a unit pass through ONE L2 instead of the weight tile of a
+  // point (the activation rows of a K slice) being fetched by every XCD that holds a few of its tiles. The linear workgroup id is dealt round-robin to the XCDs
+  // (MI355X_MICROARCH.md "Workgroup dispatch"); a wrong guess costs locality only.
+  int lid, by, z;
+  if (a.batch_xcd) {
+    const int L = blockIdx.x + ntile * (blockIdx.y + gridDim.y * blockIdx.z), xcd = L & 7, idx = L >> 3;
+    const int units = (int)(gridDim.y * gridDim.z), whole = units >> 3, rem = units & 7;
+    int u;
+    if (idx < whole * ntile) {
+      u = xcd + 8 * (idx / ntile), lid = idx % ntile;
+    } else {
+      const int share = 8 / rem, per = ntile / share;
+      u = whole * 8 + xcd / share, lid = (xcd % share) * per + (idx - whole * ntile);
+    }
+    by = u % (int)gridDim.y, z = u / (int)gridDim.y;
+  } else {
+    lid = xcd_remap(blockIdx.x, ntile), by = blockIdx.y, z = blockIdx.z;
+  }
+  int tile_m, tile_n;
+  if (a.n_group > 0 && a.tiles_n > a.n_group) {
+    const int gsz = a.tiles_m * a.n_group, grp = lid / gsz, rem = lid - grp * gsz;
+    const int gw = min(a.n_group, a.tiles_n - grp * a.n_group);      // the last group may be narrower
+    tile_m = rem / gw, tile_n = grp * a.n_group + rem % gw;
+  } else {
+    tile_m = lid / a.tiles_n, tile_n = lid % a.tiles_n;
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int z = blockIdx.z;
   const int k_begin = z * a.kper;
   const int k_end = min(a.K, k_begin + a.kper);
   const int nk = (k_end - k_begin + BKW - 1) / BKW;
   const int T = a.T_eff;                 // taps iterated by this launch
   const int Treal = a.kh * a.kw;         // tap stride of the KRSC weight layout
 
-  const int by = blockIdx.y;
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A + by * a.a_bs), 0, (int)a.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.B + by * a.b_bs), 0, (int)a.b_bytes, 0x00020000);
   const int xp4 = (int)a.x_pitch * (NAT16 ? 2 : 4), yp4 = (int)a.y_pitch * (NAT16 ? 2 : 4);      // bytes between pixels

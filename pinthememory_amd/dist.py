@@ -60,11 +60,21 @@ def bn_group(bn):
 
 
 def _direct(t, group):
-    """The same-stream RCCL communicator (rccl.py) for small fp32 GPU tensors; None -> torch.distributed."""
+    """The same-stream RCCL communicator (rccl.py) for small fp32 GPU tensors; None -> torch.distributed. While the current stream is being captured into a hipGraph
+    (harness.GraphedAggStep under N > 1) None is an error: only the direct communicator's calls are plain kernel nodes on the capturing stream."""
+    comm = None
     if t.is_cuda and t.is_contiguous() and t.dtype == torch.float32:
         from . import rccl
-        return rccl.get(group)
-    return None
+        comm = rccl.get(group)
+    if comm is None and t.is_cuda and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError('a collective on a %s %s tensor would go through torch.distributed inside a hipGraph capture (%s)'
+                           % (t.dtype, 'contiguous' if t.is_contiguous() else 'strided', direct_fallback_reason()))
+    return comm
+
+
+def direct_ready(device, group=None):
+    """Is the direct same-stream communicator up for `group` on this device (creates it on first use, collectively -- every rank asks at the same point)?"""
+    return _direct(torch.zeros(1, dtype=torch.float32, device=device), group) is not None
 
 
 def all_reduce_sum(t, group=None):

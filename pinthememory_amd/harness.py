@@ -237,9 +237,18 @@ class GraphedAggStep:
         g.close()                                                # model, optimizer and memory are consistent for eager code again
     """
 
-    def __init__(self, net, opt, x, gts, sched=None, warmup=3, pipelined=False):
+    def __init__(self, net, opt, x, gts, sched=None, warmup=3, pipelined=False, buckets=None):
         global COMMIT_OVERLAP
-        assert x.is_cuda and not D.is_dist(), 'GraphedAggStep: single-process GPU training only'
+        assert x.is_cuda, 'GraphedAggStep: GPU training only'
+        if D.is_dist():
+            # N > 1 (round 6): the serial form only, with the build's GradBuckets, and only while EVERY exchange of the step (SyncBN moments / backward sums, the
+            # memory-slot sum, the gradient buckets) is an RCCL call enqueued on the capturing stream through the direct communicator (rccl.py): those are
+            # ordinary kernel nodes of the graph, replayed in the captured order on every rank. torch.distributed's own process group hops to an internal
+            # stream and keeps host-side work objects -- not something to bake into a graph -- so dist.py raises if a capture would reach it.
+            assert not pipelined, 'GraphedAggStep: pipelined=True is single-process (the withheld commit would defer a collective across a graph boundary)'
+            assert buckets is not None and not hasattr(net, 'module'), 'GraphedAggStep under torch.distributed: pass the bare module and a dist.GradBuckets'
+            assert D.direct_ready(x.device), 'GraphedAggStep under torch.distributed needs the direct RCCL communicator: ' + D.direct_fallback_reason()
+        self.buckets = buckets
         assert len(opt.param_groups) == 1, 'GraphedAggStep: one parameter group (optimizer.py:21-25)'
         self.net, self.opt, self.sched, self.pipelined, self.closed = net, opt, sched, pipelined, False
         m = self.m = net.module if hasattr(net, 'module') else net
@@ -252,7 +261,7 @@ class GraphedAggStep:
             opt.lr_device = self.lr
             for _ in range(warmup):      # allocates workspaces, momentum buffers, filter caches, sets every kernel's LDS attribute
                 self.lr.fill_(float(opt.param_groups[0]['lr']))
-                agg_train_step(net, opt, self.x, self.gts, sched=sched)
+                agg_train_step(net, opt, self.x, self.gts, sched=sched, buckets=buckets)
             finish_commit(net)
             self.mem = m.memory.m_items.detach().clone()
             m.memory.m_items = self.mem
@@ -278,7 +287,7 @@ class GraphedAggStep:
                     self.x_prev.copy_(self.x)
                     self.gts_prev.copy_(self.gts)
                 else:
-                    self.out = agg_train_step(net, opt, self.x, self.gts, sched=None)
+                    self.out = agg_train_step(net, opt, self.x, self.gts, sched=None, buckets=buckets)
                     self.mem.copy_(m.memory.m_items)
                 if ops.overlap_wgrad():      # every stream forked into the capture rejoins it (the weight-gradient stream's last event record trails its last join)
                     torch.cuda.current_stream().wait_stream(ops._side_stream())

@@ -206,6 +206,7 @@ def test_direct_rccl_communicator_one_rank():
 _STEP_PROBE = r'''
 import hashlib, os, sys, torch
 mode = sys.argv[2]                 # '0' plain single process | '1' N > 1 path with the build's GradBuckets | '2' N > 1 path under the reference's DDP wrapper
+                                   # '3' as '1', the second step replayed from a hipGraph (harness.GraphedAggStep(buckets=...): every RCCL call a node of the graph)
 force = mode != '0'
 if force:
     import torch.distributed as dist
@@ -224,7 +225,7 @@ if force:                          # train.py:95: every BatchNorm incl. Memory_s
     assert not any(type(m) is torch.nn.BatchNorm2d for m in net.modules())
     assert sum(isinstance(m, torch.nn.SyncBatchNorm) for m in net.modules()) == 65
 opt, sched = harness.make_optimizer(net)
-buckets = D.GradBuckets(net.parameters()) if mode == '1' else None
+buckets = D.GradBuckets(net.parameters()) if mode in '13' else None
 if mode == '2':                    # network/__init__.py:25-33: DistributedDataParallel(net, device_ids=[gpuid], find_unused_parameters=True)
     from pinthememory_amd.network import warp_network_in_dataparallel
     from pinthememory_amd.hip import ops
@@ -232,8 +233,16 @@ if mode == '2':                    # network/__init__.py:25-33: DistributedDataP
     net = warp_network_in_dataparallel(net, 0)
 x, y = synth.make_batch(2, 128)
 x, y = x.cuda(), y.cuda()
-for _ in range(2):
-    out = harness.agg_train_step(net, opt, x, y, sched=sched, buckets=buckets)
+if mode == '3':
+    n0 = D.COLLECTIVES[0]
+    g = harness.GraphedAggStep(net, opt, x, y, sched=sched, warmup=1, buckets=buckets)      # one eager step, then the capture (records, does not execute)
+    per_step = (D.COLLECTIVES[0] - n0) // 2
+    assert per_step > 100, per_step                                                          # the capture went through every exchange of the step
+    out = g.step(x, y)
+    g.close()
+else:
+    for _ in range(2):
+        out = harness.agg_train_step(net, opt, x, y, sched=sched, buckets=buckets)
 harness.finish_commit(net)          # every rank: the memory commit of the last step is finished explicitly (an attribute read never hides a collective)
 torch.cuda.synchronize()
 h = hashlib.sha256()
@@ -254,17 +263,19 @@ def test_one_rank_rccl_step_equals_plain_step():
     """SyncBN moments through all-gather + merge (incl. the memory's own two BatchNorms, converted as train.py:95 does), bucketed gradient
     all-reduce on the step's single communicator, memory-slot all-reduce: with one rank every exchange is the identity, so parameters,
     buffers and memory after two agg steps carry the same bits as the plain path -- with the build's GradBuckets (mode 1) and with the
-    network wrapped by the reference's own `warp_network_in_dataparallel` (DDP reducer over the side-stream weight gradients, mode 2)."""
+    network wrapped by the reference's own `warp_network_in_dataparallel` (DDP reducer over the side-stream weight gradients, mode 2). Mode 3
+    (VERDICT r5 item 6b): the same N > 1 path with the second step replayed from a hipGraph -- the RCCL calls of the direct communicator are captured
+    on the step's stream like any other kernel; the total loss is the replayed step's."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     digests = []
-    for force in ('0', '1', '2'):
+    for force in ('0', '1', '2', '3'):
         r = subprocess.run([sys.executable, '-c', _STEP_PROBE, str(_free_port()), force], cwd=root, capture_output=True, text=True, timeout=600)
         lines = [l for l in r.stdout.splitlines() if l.startswith('STEP_DIGEST')]
         assert lines, r.stdout[-2000:] + r.stderr[-4000:]
         digests.append(lines[0].split()[1:])
-    assert digests[0] == digests[1] == digests[2], digests
+    assert digests[0] == digests[1] == digests[2] == digests[3], digests
 
 
 # ---- GPU: two REAL ranks (gloo, sharing the one GPU of the box) against the single-process big batch ------------------------------------
