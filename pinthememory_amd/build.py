@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libpinmem_hip.so')
-SOURCES = ['misc.hip', 'act16.hip', 'bf16.hip', 'conv_igemm.hip', 'conv_split.hip', 'conv16.hip', 'conv16w.hip', 'wgrad16.hip', 'winograd.hip', 'bn.hip', 'pool_resize.hip', 'loss.hip', 'memory.hip']
+SOURCES = ['misc.hip', 'act16.hip', 'bf16.hip', 'conv_igemm.hip', 'conv_split.hip', 'pwstream.hip', 'conv16.hip', 'conv16w.hip', 'wgrad16.hip', 'winograd.hip', 'bn.hip', 'pool_resize.hip', 'loss.hip', 'memory.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=fast', '-Wall', '-Wno-unused-function']
 
 

@@ -435,6 +435,24 @@ int launch(const ConvK& k0, const Plan& p, hipStream_t st, int batch = 1, double
     rec.bytes = (double)batch * ((double)k.a_bytes + (double)k.b_bytes + ((k.io16 && p.ksplit == 1) ? 2.0 : 4.0) * (double)k.M * (double)k.Nn * (double)p.ksplit);
     (void)hipEventRecord(rec.a, st);
   }
+  if constexpr (MODE != MODE_WGRAD) {      // short pointwise reductions of the fp32 tier stream wave by wave (pwstream.hip): the split path's arithmetic, no tiles
+    if (pm_route.split && k.prec != 1 && !k.io16 && batch == 1 && p.ksplit == 1 && !k.stats && k.kh * k.kw == 1 && k.stride == 1 && k.pad == 0 && !k.sub) {
+      pm_gemm_pw g;
+      g.A = k.A, g.B = k.B, g.C = k.C, g.bias = k.bias, g.scale = k.scale, g.shift = k.shift, g.residual = k.residual;
+      g.a_pitch = MODE == MODE_FWD ? k.x_pitch : k.y_pitch, g.c_pitch = k.c_pitch, g.res_pitch = k.res_pitch;
+      g.b_sn = MODE == MODE_FWD ? k.K : 1, g.b_sk = MODE == MODE_FWD ? 1 : k.Nn;
+      g.M = k.M, g.Nn = k.Nn, g.K = k.K, g.relu = k.relu;
+      if (pm_pwstream_ok(&g)) {
+        if (g_prof_on) rec.bm = 32, rec.bn = 64, rec.km = 4, rec.prec = 5, rec.nst = 0;
+        const int e = pm_pwstream_launch(&g, st);
+        if (g_prof_on) {
+          (void)hipEventRecord(rec.b, st);
+          g_prof.push_back(rec);
+        }
+        return e;
+      }
+    }
+  }
   constexpr bool akc = MODE != MODE_WGRAD, bkc = MODE == MODE_FWD;
   if (k.prec == 5) {      // fp32 operands, three-way bf16 split, six products on the bf16 matrix pipe (conv_split.hip)
     const size_t stage = pm_conv_split_stage_bytes(MODE, p.bm, p.bn);

@@ -137,6 +137,20 @@ struct pm_wgrad16 {
 bool pm_wgrad16_plan(pm_wgrad16* k);      // false: the shape stays with the register-staged kernel
 int pm_wgrad16_launch(const pm_wgrad16* k, hipStream_t st);
 
+// pwstream.hip: a pointwise fp32 GEMM C[M x Nn] = A[M x K] . B^T with a short reduction (K = 64 / 128), streamed wave by wave (split-operand bf16 MFMA arithmetic)
+struct pm_gemm_pw {
+  const float* A;            // rows of K floats, a_pitch floats apart
+  const float* B;            // element (n, k) at B[n * b_sn + k * b_sk]
+  float* C;                  // rows of Nn floats, c_pitch floats apart
+  const float *bias, *scale, *shift, *residual;      // v = (acc + bias) * scale + shift (+ residual) (relu): the tile kernels' epilogue
+  long a_pitch, c_pitch, res_pitch;
+  int b_sn, b_sk;
+  long M;
+  int Nn, K, relu;
+};
+bool pm_pwstream_ok(const pm_gemm_pw* g);
+int pm_pwstream_launch(const pm_gemm_pw* g, hipStream_t st);
+
 // One-time setup per DEVICE of a kernel that needs it (the > 64 KB dynamic-LDS opt-in) and the CU count of the current device (persistent kernels size their grid by
 // it). ADVICE r5: a `static` per process served the device that happened to be current at the first call -- a later launch on another device asked for 144 KB of LDS
 // without the attribute and sized its grid by device 0. The static lives in this template, i.e. once per call site (each passes its own lambda type).

@@ -122,6 +122,70 @@ def test_split_path_accuracy_vs_fp64(K, case, capsys):
             assert es <= 2.0 * e0 + 2e-7, (wino, errs)
 
 
+PWSTREAM_CASES = [
+    # n, cin, h, w, cout: pointwise, stride 1 -- the forward takes the streaming kernel when cin is 64 / 128, the data gradient when cout is
+    (2, 64, 192, 192, 256),       # layer1 conv3 / downsample (Resnet.py:145-150): K = 64, four 64-column slabs, whole 32-row tiles
+    (1, 64, 257, 257, 64),        # one slab, a last tile of ONE row (66 049 rows): the predicated store path
+    (2, 128, 192, 192, 512),      # layer2-like: K = 128, eight slabs
+    (2, 256, 192, 192, 64),       # data gradient: K = cout = 64 (weights read with the transposed strides), N = cin = 256
+    (2, 512, 160, 208, 128),      # data gradient: K = 128, N = 512, 66 560 rows
+]
+
+
+@pytest.mark.parametrize('case', PWSTREAM_CASES)
+def test_pwstream_short_pointwise_reductions(K, case, capsys):
+    """Round 6: the wave-streamed pointwise GEMM of csrc/pwstream.hip (K = 64 / 128, >= 65 536 rows) against fp64, next to the fp32-MFMA tile kernel (pm_set_split(0))
+    on the same operands -- same bar as the split tile kernel (<= 2 x the fp32 kernel's error + 2e-7) -- with the launch record proving which kernel ran. Then the
+    epilogue forms it carries: eval-mode fold + residual + ReLU into a channel slice of a wider buffer from a channel slice of a wider input, and the data gradient's fused add."""
+    n, cin, h, w, cout = case
+    x = torch.relu(rnd(n, cin, h, w, seed=1)) + 0.01 * rnd(n, cin, h, w, seed=7)
+    wt = rnd(cout, cin, 1, 1, seed=2, scale=(2.0 / cin) ** 0.5)
+    dy = rnd(n, cout, h, w, seed=4)
+    xg, wg, dyg = nhwc(x), wt.permute(0, 2, 3, 1).contiguous().cuda(), nhwc(dy)
+    w64 = wg.view(cout, cin).double()
+    y_ref = (xg.view(-1, cin).double() @ w64.t()).view(n, h, w, cout)
+    dx_ref = (dyg.view(-1, cout).double() @ w64).view(n, h, w, cin)
+    fwd_streams, bwd_streams = cin in (64, 128), cout in (64, 128)
+    errs = {}
+    try:
+        for split in (True, False):
+            K.set_split(split)
+            K.profile_enable(True)
+            K.profile_read(clear=True)
+            y = K.conv_fwd(xg, wg, 1, 0, 1)
+            nf = K.profile_read(mode=0, bm=32, bn=64, km=4)[2]
+            dx = K.conv_bwd_data(dyg, wg, tuple(xg.shape), 1, 0, 1)
+            nb = K.profile_read(mode=1, bm=32, bn=64, km=4, clear=True)[2]
+            K.profile_enable(False)
+            assert nf == (1 if (split and fwd_streams) else 0) and nb == (1 if (split and bwd_streams) else 0), (split, nf, nb)
+            errs[split] = (rel(y, y_ref), rel(dx, dx_ref))
+    finally:
+        K.profile_enable(False)
+        K.set_split(True)
+    with capsys.disabled():
+        print('\n[pwstream vs fp64 %s] stream: y %.1e dx %.1e; fp32 tile kernel: y %.1e dx %.1e' % ((case,) + errs[True] + errs[False]))
+    for es, e0 in zip(errs[True], errs[False]):
+        assert es <= 2.0 * e0 + 2e-7, errs
+    if fwd_streams:       # epilogue + slices: pitch-padded input rows, output into channels [64, 64 + cout) of a wider buffer
+        sc, sh, res = (rnd(cout, seed=3).abs() + 0.5).cuda(), rnd(cout, seed=5).cuda(), nhwc(rnd(n, cout, h, w, seed=6))
+        wide = torch.zeros(n, h, w, cin + 32, device='cuda')
+        wide[..., :cin] = xg
+        xin = wide[..., :cin]                 # rows of K floats, K + 32 apart
+        buf = torch.zeros(n, h, w, cout + 96, device='cuda')
+        K.profile_enable(True)
+        K.profile_read(clear=True)
+        out = K.conv_fwd(xin, wg, 1, 0, 1, scale=sc, shift=sh, residual=res, relu=True, out=buf[..., 64:64 + cout])
+        assert K.profile_read(mode=0, bm=32, bn=64, km=4, clear=True)[2] == 1
+        K.profile_enable(False)
+        ref = torch.relu(y_ref * sc.double() + sh.double() + res.double())
+        assert rel(out, ref) < 2e-6
+        assert buf[..., :64].abs().max().item() == 0 and buf[..., 64 + cout:].abs().max().item() == 0
+    if bwd_streams:
+        add = nhwc(rnd(n, cin, h, w, seed=8))
+        dx = K.conv_bwd_data(dyg, wg, tuple(xg.shape), 1, 0, 1, add=add)
+        assert rel(dx, dx_ref + add.double()) < 2e-6
+
+
 WINO_CASES = [
     # n, cin, h, w, cout, dil   (3x3, stride 1, pad == dil, both channel counts >= 128 -> Winograd F(2x2,3x3) route)
     (1, 304, 16, 16, 256, 1),

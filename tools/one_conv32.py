@@ -11,7 +11,12 @@ x = torch.relu(torch.randn(n, h, w, cin, device='cuda'))
 wt = torch.randn(cout, k, k, cin, device='cuda') * 0.05
 mode = os.environ.get('ONE_MODE', 'fwd')
 dy = torch.randn(n, h + 2 * p - d * (k - 1), w + 2 * p - d * (k - 1), cout, device='cuda')
-run = {'fwd': lambda: K.conv_fwd(x, wt, 1, p, d), 'wgrad': lambda: K.conv_bwd_weight(x, dy, tuple(wt.shape), 1, p, d)[0],
+ring = int(os.environ.get('ONE_RING', '0'))      # > 0: the forward writes into `ring` different outputs in turn (as in a training step: the output never sits in the Infinity Cache already)
+outs, turn = [torch.empty_like(dy) for _ in range(ring)], [0]
+def fwd_ring():
+    turn[0] += 1
+    return K.conv_fwd(x, wt, 1, p, d, out=outs[turn[0] % ring])
+run = {'fwd': fwd_ring if ring else (lambda: K.conv_fwd(x, wt, 1, p, d)), 'wgrad': lambda: K.conv_bwd_weight(x, dy, tuple(wt.shape), 1, p, d)[0],
        'dgrad': lambda: K.conv_bwd_data(dy, wt, tuple(x.shape), 1, p, d)}[mode]
 for _ in range(3):
     y = run()
