@@ -34,7 +34,6 @@ struct PwsK {
   unsigned a_bytes, c_bytes, res_bytes;               // buffer extents: rows >= M read zeros / are not stored
   int b_sn, b_sk;
   int M, Nn, row_tiles, relu;
-  int dbg;      // timing experiments only (PM_PWSTREAM_DBG): 1 = no stores, 2 = no loads
 };
 
 __device__ __forceinline__ v4f pws_load(__amdgpu_buffer_rsrc_t r, unsigned off) {
@@ -101,11 +100,6 @@ __global__ __launch_bounds__(256, 2) void pwstream_kernel(PwsK a) {
   const int first = grp * 4 + wave, stride = groups * 4;
   v4f raw[NB][2 * KG];
   auto load = [&](v4f* dst, int tile) {
-    if (a.dbg == 2) {
-#pragma unroll
-      for (int q = 0; q < 2 * KG; ++q) dst[q] = v4f{1.f + q, 2.f, 3.f, (float)tile};
-      return;
-    }
     const unsigned off = (unsigned)(tile * 32 + l31) * a_row + (unsigned)h * 16u;
 #pragma unroll
     for (int q = 0; q < 2 * KG; ++q) dst[q] = pws_load(rA, off + (unsigned)q * 32u);
@@ -146,7 +140,6 @@ __global__ __launch_bounds__(256, 2) void pwstream_kernel(PwsK a) {
     // (no barrier: a wave's LDS operations execute in order) and leaves as 16-byte stores of 8 rows x 128 contiguous bytes -- whole cache lines, a quarter of the
     // store instructions of the dword form, which was bound by store ISSUE (~20 cycles per instruction and CU whatever its width). Rows beyond M (a last, partial
     // tile) fall outside the buffer extents: read as zero, not stored.
-    if (a.dbg == 1 && acc[0][0] != 12345.678f) return;
     char* stg = lds + KG * 2 * 3 * 1024 + 3 * 64 * 4 + wave * (32 * 144);
     const int rr = lane >> 3, cg = lane & 7;
 #pragma unroll
@@ -217,17 +210,11 @@ int pm_pwstream_launch(const pm_gemm_pw* g, hipStream_t st) {
   k.c_bytes = (unsigned)((g->M - 1) * g->c_pitch * 4 + (long)g->Nn * 4);
   k.res_bytes = g->residual ? (unsigned)((g->M - 1) * g->res_pitch * 4 + (long)g->Nn * 4) : 0u;
   k.b_sn = g->b_sn, k.b_sk = g->b_sk, k.M = (int)g->M, k.Nn = g->Nn, k.row_tiles = (int)((g->M + 31) / 32), k.relu = g->relu;
-  static const int dbg = getenv("PM_PWSTREAM_DBG") ? atoi(getenv("PM_PWSTREAM_DBG")) : 0;
-  k.dbg = dbg;
-  static const int per_cu = getenv("PM_PWSTREAM_PER_CU") ? atoi(getenv("PM_PWSTREAM_PER_CU")) : 2;      // tuning: blocks per CU
-  static const int nb64 = getenv("PM_PWSTREAM_NB") ? atoi(getenv("PM_PWSTREAM_NB")) : 2;
-  const int slabs = g->Nn / 64, grid = 8 * slabs * std::max(1, 32 * per_cu / slabs);
-  if (g->K == 64) {
-    if (nb64 == 4) pws_launch<4, 4>(k, grid, st);
-    else if (nb64 == 3) pws_launch<4, 3>(k, grid, st);
-    else pws_launch<4, 2>(k, grid, st);
-  } else {
-    pws_launch<8, 2>(k, grid, st);
-  }
+
+  // 512 blocks = two per CU, one tile in flight behind the one being multiplied: three / four blocks per CU and two / three tiles in flight measured level
+  // (94 - 102 us on 64 -> 256 @192^2; profiles/README.md round 6) -- the kernel is bound by its stores, not by load latency
+  const int slabs = g->Nn / 64, grid = 8 * slabs * std::max(1, 64 / slabs);
+  if (g->K == 64) pws_launch<4, 2>(k, grid, st);
+  else pws_launch<8, 2>(k, grid, st);
   return pm_check_launch("pwstream");
 }
