@@ -882,7 +882,7 @@ def main():
                                                                                             {'bf16': 'bf16 tier: bf16 activations and activation gradients between layers, bf16-MFMA convolutions with fp32 accumulation, fp32 statistics / losses / memory / parameters',
                                                                                              'bf16_operands': 'bf16-MFMA convolutions (bf16 operands in HBM and LDS, fp32 accumulation; fp32 activations between layers)',
                                                                                              'bf16_staged': 'bf16-MFMA (fp32 tiles staged, rounded per fragment)',
-                                                                                             'f32': 'fp32 storage / accumulation / results; the contractions run on the bf16 matrix pipe: fp32 operands, 3-way exact bf16 split, 6 products, fp32 accumulate (reductions <= 128 and outputs < 64 columns stay on v_mfma_f32_32x32x2_f32)' if os.environ.get('PM_SPLIT', '1') != '0' else 'fp32'}[a.dtype],
+                                                                                             'f32': 'fp32 storage / accumulation / results; the contractions run on the bf16 matrix pipe: fp32 operands, 3-way exact bf16 split, 6 products, fp32 accumulate (the pointwise 64- / 128-channel reductions on the 192^2 / 96^2 maps in the wave-streamed form of csrc/pwstream.hip; other reductions <= 128 and outputs < 64 columns stay on v_mfma_f32_32x32x2_f32)' if os.environ.get('PM_SPLIT', '1') != '0' else 'fp32'}[a.dtype],
                                                                                             ', decoder skipped in the commit fwd' if a.truncate_second_forward else ''),
                           'global_batch': a.batch * world, 'crop': a.size, 'parallelism': 'dp%d' % world,
                           'ranks_seen': ranks_seen, 'ranks_seen_source': ('ncclCommCount of the direct RCCL communicator' if multi and backend == 'nccl' and ranks_seen == world and _rccl.get(None) is not None
