@@ -436,7 +436,7 @@ int launch(const ConvK& k0, const Plan& p, hipStream_t st, int batch = 1, double
     (void)hipEventRecord(rec.a, st);
   }
   if constexpr (MODE != MODE_WGRAD) {      // short pointwise reductions of the fp32 tier stream wave by wave (pwstream.hip): the split path's arithmetic, no tiles
-    if (pm_route.split && k.prec != 1 && !k.io16 && batch == 1 && p.ksplit == 1 && !k.stats && k.kh * k.kw == 1 && k.stride == 1 && k.pad == 0 && !k.sub) {
+    if (pm_route.split && (k.prec == 0 || k.prec == 5) && !k.io16 && batch == 1 && p.ksplit == 1 && !k.stats && k.kh * k.kw == 1 && k.stride == 1 && k.pad == 0 && !k.sub) {      // fp32 operands only (prec 1 / 2: bf16-operand forms of the older tier)
       pm_gemm_pw g;
       g.A = k.A, g.B = k.B, g.C = k.C, g.bias = k.bias, g.scale = k.scale, g.shift = k.shift, g.residual = k.residual;
       g.a_pitch = MODE == MODE_FWD ? k.x_pitch : k.y_pitch, g.c_pitch = k.c_pitch, g.res_pitch = k.res_pitch;

@@ -186,6 +186,28 @@ def test_pwstream_short_pointwise_reductions(K, case, capsys):
         assert rel(dx, dx_ref + add.double()) < 2e-6
 
 
+def test_pwstream_leaves_the_bf16_operand_forms_alone(K):
+    """The stream computes on fp32 operands. With bf16 OPERANDS requested on fp32 tensors (BASELINE configs[2] before round 4's bf16 activations: conv precision 'bf16') the
+    launcher hands the kernel a float-typed view of bf16 pairs -- 256 bf16 channels look like a 128-float reduction -- and must keep such a launch away from the stream
+    (a round-6 review finding: the first hook only excluded the staged form). Shape: 256 -> 128 on 2 x 192 x 192 pixels; oracle: fp32 convolution of bf16-rounded operands."""
+    n, cin, h, w, cout = 2, 256, 192, 192, 128
+    r16 = lambda t: t.bfloat16().float()
+    x, wt = rnd(n, cin, h, w, seed=1), rnd(cout, cin, 1, 1, seed=2, scale=(2.0 / cin) ** 0.5)
+    xg, wg = nhwc(x), wt.permute(0, 2, 3, 1).contiguous().cuda()
+    y_ref = (r16(xg).view(-1, cin).double() @ r16(wg).view(cout, cin).double().t()).view(n, h, w, cout)
+    K.set_conv_precision('bf16')
+    try:
+        K.profile_enable(True)
+        K.profile_read(clear=True)
+        y = K.conv_fwd(xg, wg, 1, 0, 1, out_dtype=torch.float32)      # fp32 in, fp32 out, bf16 operands: the launch that looked like an fp32 128-float reduction
+        taken = K.profile_read(mode=0, bm=32, bn=64, km=4, clear=True)[2]
+    finally:
+        K.profile_enable(False)
+        K.set_conv_precision('f32')
+    assert taken == 0 and y.dtype == torch.float32
+    assert rel(y, y_ref) < 1e-4
+
+
 WINO_CASES = [
     # n, cin, h, w, cout, dil   (3x3, stride 1, pad == dil, both channel counts >= 128 -> Winograd F(2x2,3x3) route)
     (1, 304, 16, 16, 256, 1),
